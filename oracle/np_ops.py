@@ -1,0 +1,344 @@
+"""ORACLE (test infrastructure, not product code): numpy restatement of every arithmetic
+step on the hot path of Hunger-Prevails/3D-Pose-Estimation-with-Previleged-Information.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product path (the package's HIP kernels behind include/p3d_hip.h) never does.
+
+Each function cites the reference file:line whose arithmetic it restates.  The reference
+itself is eager PyTorch (nn.Conv2d / nn.BatchNorm2d / nn.MaxPool2d / F.relu / optim.Adam);
+where the reference line is a torch call the restatement follows torch's documented
+semantics for that call.  Pinned against the reference by tests/golden/*.npz, which
+tests/golden/make_golden.py produced by importing and running the real reference modules
+(tests/test_oracle_golden.py).
+
+All functions take/return numpy arrays in NCHW.  `acc` is the accumulation dtype: float64
+(default) gives the tightest yardstick for the fp32 GPU kernels; float32 mimics the
+reference's own arithmetic width.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------
+# convolution (nn.Conv2d: depthnet.py:16-33,65-89,138,156; resnet.py:142,160-172;
+#              fusionnet.py:135,164-165; downsample depthnet.py:167-173)
+# --------------------------------------------------------------------------------------
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def im2col(x, kh, kw, stride, pad, dil):
+    """x [N,C,H,W] -> cols [N, C, kh, kw, Ho, Wo] (zero padded taps)."""
+    n, c, h, w = x.shape
+    ho = conv_out_size(h, kh, stride, pad, dil)
+    wo = conv_out_size(w, kw, stride, pad, dil)
+    xp = np.zeros((n, c, h + 2 * pad, w + 2 * pad), dtype=x.dtype)
+    xp[:, :, pad:pad + h, pad:pad + w] = x
+    cols = np.empty((n, c, kh, kw, ho, wo), dtype=x.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            cols[:, :, r, s] = xp[:, :, r * dil:r * dil + stride * (ho - 1) + 1:stride,
+                                  s * dil:s * dil + stride * (wo - 1) + 1:stride]
+    return cols
+
+
+def col2im(cols, x_shape, stride, pad, dil):
+    """Adjoint of im2col: cols [N,C,kh,kw,Ho,Wo] -> x [N,C,H,W]."""
+    n, c, h, w = x_shape
+    _, _, kh, kw, ho, wo = cols.shape
+    xp = np.zeros((n, c, h + 2 * pad, w + 2 * pad), dtype=cols.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            xp[:, :, r * dil:r * dil + stride * (ho - 1) + 1:stride,
+               s * dil:s * dil + stride * (wo - 1) + 1:stride] += cols[:, :, r, s]
+    return xp[:, :, pad:pad + h, pad:pad + w]
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dil=1, acc=np.float64):
+    n, c, h, ww = x.shape
+    k, c2, kh, kw = w.shape
+    assert c == c2
+    cols = im2col(x.astype(acc), kh, kw, stride, pad, dil)
+    ho, wo = cols.shape[-2:]
+    y = np.einsum('km,nmp->nkp', w.reshape(k, -1).astype(acc), cols.reshape(n, c * kh * kw, ho * wo), optimize=True)
+    y = y.reshape(n, k, ho, wo)
+    if bias is not None:
+        y = y + bias.astype(acc).reshape(1, k, 1, 1)
+    return y.astype(np.float32)
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, dil=1, acc=np.float64):
+    n, k, ho, wo = dy.shape
+    _, c, kh, kw = w.shape
+    cols = np.einsum('km,nkp->nmp', w.reshape(k, -1).astype(acc), dy.reshape(n, k, ho * wo).astype(acc), optimize=True)
+    cols = cols.reshape(n, c, kh, kw, ho, wo)
+    return col2im(cols, x_shape, stride, pad, dil).astype(np.float32)
+
+
+def conv2d_wgrad(dy, x, w_shape, stride=1, pad=0, dil=1, acc=np.float64):
+    k, c, kh, kw = w_shape
+    n = x.shape[0]
+    cols = im2col(x.astype(acc), kh, kw, stride, pad, dil)
+    ho, wo = cols.shape[-2:]
+    dw = np.einsum('nkp,nmp->km', dy.reshape(n, k, ho * wo).astype(acc), cols.reshape(n, c * kh * kw, ho * wo), optimize=True)
+    return dw.reshape(w_shape).astype(np.float32)
+
+
+def conv2d_bgrad(dy, acc=np.float64):
+    return dy.astype(acc).sum(axis=(0, 2, 3)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# batch norm (nn.BatchNorm2d: depthnet.py:25,34,71,82,90,139,174; momentum 0.1, eps 1e-5)
+# --------------------------------------------------------------------------------------
+
+def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, acc=np.float64):
+    """Train-mode BN: biased variance normalises, unbiased variance updates running_var.
+    Returns y, mean, invstd, new_running_mean, new_running_var."""
+    xa = x.astype(acc)
+    m = x.shape[0] * x.shape[2] * x.shape[3]
+    mean = xa.mean(axis=(0, 2, 3))
+    var = ((xa - mean.reshape(1, -1, 1, 1)) ** 2).mean(axis=(0, 2, 3))
+    invstd = 1.0 / np.sqrt(var + eps)
+    y = (xa - mean.reshape(1, -1, 1, 1)) * (invstd * gamma.astype(acc)).reshape(1, -1, 1, 1) + beta.astype(acc).reshape(1, -1, 1, 1)
+    new_rm = new_rv = None
+    if running_mean is not None:
+        unbiased = var * (m / max(m - 1, 1))
+        new_rm = ((1 - momentum) * running_mean.astype(acc) + momentum * mean).astype(np.float32)
+        new_rv = ((1 - momentum) * running_var.astype(acc) + momentum * unbiased).astype(np.float32)
+    return y.astype(np.float32), mean.astype(np.float32), invstd.astype(np.float32), new_rm, new_rv
+
+
+def bn_train_bwd(dy, x, mean, invstd, gamma, acc=np.float64):
+    """Returns dx, dgamma, dbeta for train-mode BN."""
+    dya = dy.astype(acc)
+    m = x.shape[0] * x.shape[2] * x.shape[3]
+    xhat = (x.astype(acc) - mean.astype(acc).reshape(1, -1, 1, 1)) * invstd.astype(acc).reshape(1, -1, 1, 1)
+    dbeta = dya.sum(axis=(0, 2, 3))
+    dgamma = (dya * xhat).sum(axis=(0, 2, 3))
+    scale = (gamma.astype(acc) * invstd.astype(acc)).reshape(1, -1, 1, 1)
+    dx = scale * (dya - dbeta.reshape(1, -1, 1, 1) / m - xhat * dgamma.reshape(1, -1, 1, 1) / m)
+    return dx.astype(np.float32), dgamma.astype(np.float32), dbeta.astype(np.float32)
+
+
+def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps=1e-5, acc=np.float64):
+    """Eval-mode BN (model.eval(), depth_train.py:611; freeze_batchnorm depthnet.py:158-161)."""
+    scale = gamma.astype(acc) / np.sqrt(running_var.astype(acc) + eps)
+    shift = beta.astype(acc) - running_mean.astype(acc) * scale
+    return (x.astype(acc) * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)).astype(np.float32)
+
+
+def bn_eval_bwd(dy, x, gamma, beta, running_mean, running_var, eps=1e-5, acc=np.float64):
+    """Frozen-statistics BN backward: dx = dy*scale; dgamma = sum(dy*xhat); dbeta = sum(dy)."""
+    invstd = 1.0 / np.sqrt(running_var.astype(acc) + eps)
+    dya = dy.astype(acc)
+    xhat = (x.astype(acc) - running_mean.astype(acc).reshape(1, -1, 1, 1)) * invstd.reshape(1, -1, 1, 1)
+    dx = dya * (gamma.astype(acc) * invstd).reshape(1, -1, 1, 1)
+    return dx.astype(np.float32), (dya * xhat).sum(axis=(0, 2, 3)).astype(np.float32), dya.sum(axis=(0, 2, 3)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# ReLU / residual add (F.relu, out + res: depthnet.py:44,53-56,101,105,113-116)
+# --------------------------------------------------------------------------------------
+
+def relu_fwd(x):
+    return np.maximum(x, 0).astype(np.float32)
+
+
+def relu_bwd(dy, y):
+    """Gradient masked by the *output* being positive (identical to input > 0)."""
+    return (dy * (y > 0)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# max pool 3x3 stride 2 pad 1 (nn.MaxPool2d: depthnet.py:140,192; on the veil partial_depthnet.py:220)
+# --------------------------------------------------------------------------------------
+
+def maxpool3x3s2_fwd(x):
+    """Returns y and the argmax tap index (0..8, row-major in the window; first maximum wins,
+    as torch's CPU kernel does with its strict '>' comparison)."""
+    n, c, h, w = x.shape
+    ho = conv_out_size(h, 3, 2, 1, 1)
+    wo = conv_out_size(w, 3, 2, 1, 1)
+    xp = np.full((n, c, h + 2, w + 2), -np.inf, dtype=x.dtype)
+    xp[:, :, 1:1 + h, 1:1 + w] = x
+    best = np.full((n, c, ho, wo), -np.inf, dtype=x.dtype)
+    idx = np.zeros((n, c, ho, wo), dtype=np.uint8)
+    for r in range(3):
+        for s in range(3):
+            tap = xp[:, :, r:r + 2 * (ho - 1) + 1:2, s:s + 2 * (wo - 1) + 1:2]
+            better = tap > best
+            best = np.where(better, tap, best)
+            idx = np.where(better, np.uint8(r * 3 + s), idx)
+    return best.astype(np.float32), idx
+
+
+def maxpool3x3s2_bwd(dy, idx, x_shape):
+    n, c, h, w = x_shape
+    ho, wo = dy.shape[-2:]
+    dxp = np.zeros((n, c, h + 2, w + 2), dtype=np.float64)
+    for r in range(3):
+        for s in range(3):
+            dxp[:, :, r:r + 2 * (ho - 1) + 1:2, s:s + 2 * (wo - 1) + 1:2] += dy * (idx == r * 3 + s)
+    return dxp[:, :, 1:1 + h, 1:1 + w].astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# partial convolution (partial_conv.py:32-57; multi_channel=False so the mask has 1 channel
+# and slide_winsize = kh*kw, partial_conv.py:26-28)
+# --------------------------------------------------------------------------------------
+
+def mask_count_fwd(mask, kh, kw, stride, pad, dil):
+    """partial_conv.py:35-43: cnt = conv(mask, ones); mult = k*k/(cnt+1e-6) * clamp(cnt,0,1);
+    mask_out = clamp(cnt,0,1).  mask [N,1,H,W] -> mult, mask_out [N,1,Ho,Wo] (float32 arithmetic
+    as in the reference: the mask path runs in fp32 under no_grad)."""
+    cols = im2col(mask.astype(np.float32), kh, kw, stride, pad, dil)
+    cnt = cols.sum(axis=(2, 3), dtype=np.float32)
+    mult = np.float32(kh * kw) / (cnt + np.float32(1e-6))
+    mask_out = np.clip(cnt, 0, 1).astype(np.float32)
+    mult = (mult * mask_out).astype(np.float32)
+    return mult, mask_out
+
+
+def partial_conv_fwd(x, mask, w, bias=None, stride=1, pad=0, dil=1, acc=np.float64):
+    """partial_conv.py:32-57.  Returns (out, mask_out, mult)."""
+    kh, kw = w.shape[2:]
+    mult, mask_out = mask_count_fwd(mask, kh, kw, stride, pad, dil)
+    raw = conv2d_fwd(x * mask, w, bias, stride, pad, dil, acc=acc)
+    if bias is not None:
+        b = bias.reshape(1, -1, 1, 1)
+        out = ((raw - b) * mult + b) * mask_out          # partial_conv.py:48-51
+    else:
+        out = raw * mult                                   # partial_conv.py:53
+    return out.astype(np.float32), mask_out, mult
+
+
+def partial_conv_bwd(dout, x, mask, w, mult, stride=1, pad=0, dil=1, acc=np.float64):
+    """Bias-free case (all partial convs in partial_depthnet.py are bias=False).
+    d raw = dout * mult; dx = dgrad(d raw) * mask; dw = wgrad(d raw, x*mask)."""
+    draw = (dout * mult).astype(np.float32)
+    dx = conv2d_dgrad(draw, w, x.shape, stride, pad, dil, acc=acc) * mask
+    dw = conv2d_wgrad(draw, (x * mask).astype(np.float32), w.shape, stride, pad, dil, acc=acc)
+    return dx.astype(np.float32), dw
+
+
+# --------------------------------------------------------------------------------------
+# volumetric soft-argmax head (utils.py:154-194)
+# --------------------------------------------------------------------------------------
+
+def to_heatmap(z, depth, num_joints, height, width, acc=np.float64):
+    """utils.py:154-175: channel = d*J + j (depth-major) -> [B,J,H,W,D], stable softmax over H*W*D."""
+    b = z.shape[0]
+    heat = z.reshape(b, depth, num_joints, height, width).transpose(0, 2, 3, 4, 1).astype(acc)
+    flat = heat.reshape(b, num_joints, -1)
+    flat = np.exp(flat - flat.max(axis=2, keepdims=True))
+    flat = flat / flat.sum(axis=2, keepdims=True)
+    return flat.reshape(b, num_joints, height, width, depth)
+
+
+def decode(heat, depth_range):
+    """utils.py:178-194: marginals, expectation against linspace(0,2,n), stack (x,y,z) * depth_range."""
+    heat_y = heat.sum(axis=(3, 4))
+    heat_x = heat.sum(axis=(2, 4))
+    heat_z = heat.sum(axis=(2, 3))
+    gy = np.linspace(0.0, 2.0, heat_y.shape[-1]).reshape(1, 1, -1)
+    gx = np.linspace(0.0, 2.0, heat_x.shape[-1]).reshape(1, 1, -1)
+    gz = np.linspace(0.0, 2.0, heat_z.shape[-1]).reshape(1, 1, -1)
+    cy = (gy * heat_y).sum(axis=2)
+    cx = (gx * heat_x).sum(axis=2)
+    cz = (gz * heat_z).sum(axis=2)
+    return np.stack((cx, cy, cz), axis=2) * depth_range
+
+
+def softargmax3d_fwd(z, depth, num_joints, height, width, depth_range, acc=np.float64):
+    """to_heatmap followed by decode: z [B, D*J, H, W] -> coords [B, J, 3] (x, y, z)."""
+    return decode(to_heatmap(z, depth, num_joints, height, width, acc), depth_range).astype(np.float32)
+
+
+def softargmax3d_bwd(dcoords, z, depth, num_joints, height, width, depth_range, acc=np.float64):
+    """Closed form: with p = softmax(l), E_a = sum_i p_i g_a(i):  dL/dl_i = p_i * sum_a dc_a (g_a(i) - E_a) * range."""
+    b = z.shape[0]
+    p = to_heatmap(z, depth, num_joints, height, width, acc)                     # [B,J,H,W,D]
+    gy = np.linspace(0.0, 2.0, height).reshape(1, 1, -1, 1, 1)
+    gx = np.linspace(0.0, 2.0, width).reshape(1, 1, 1, -1, 1)
+    gz = np.linspace(0.0, 2.0, depth).reshape(1, 1, 1, 1, -1)
+    coords = decode(p, 1.0)                                                      # expectations, unit range
+    dc = dcoords.astype(acc) * depth_range
+    t = (dc[:, :, 0, None, None, None] * (gx - coords[:, :, 0, None, None, None])
+         + dc[:, :, 1, None, None, None] * (gy - coords[:, :, 1, None, None, None])
+         + dc[:, :, 2, None, None, None] * (gz - coords[:, :, 2, None, None, None]))
+    dl = p * t                                                                   # [B,J,H,W,D]
+    dz = dl.transpose(0, 4, 1, 2, 3).reshape(b, depth * num_joints, height, width)
+    return dz.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# loss block (depth_train.py:397-405; train.py:166-174 is the same with loss_div = 1)
+# --------------------------------------------------------------------------------------
+
+def pose_loss_fwd_bwd(relat, true_cam, true_val, key_index, loss_div, criterion='SmoothL1', acc=np.float64):
+    """relat [B,J,3] (decode output), true_cam [B,J,3], true_val [B,J] bool.
+    spec = relat - relat[:,key] + true_cam[:,key]; loss = criterion(spec[valid]/div, true[valid]/div), mean
+    over the 3*n_valid selected scalars.  Returns (loss, spec_cam, d loss / d relat)."""
+    relat = relat.astype(acc)
+    tc = true_cam.astype(acc)
+    spec = relat - relat[:, key_index:key_index + 1] + tc[:, key_index:key_index + 1]
+    val = true_val.astype(bool)
+    nsel = int(val.sum()) * 3
+    diff = (spec - tc) / loss_div
+    if criterion == 'SmoothL1':          # nn.SmoothL1Loss(beta=1, reduction='mean')
+        a = np.abs(diff)
+        per = np.where(a < 1.0, 0.5 * diff * diff, a - 0.5)
+        dper = np.where(a < 1.0, diff, np.sign(diff))
+    elif criterion == 'L1':
+        per = np.abs(diff)
+        dper = np.sign(diff)
+    elif criterion == 'MSE':
+        per = diff * diff
+        dper = 2.0 * diff
+    else:
+        raise ValueError(criterion)
+    m = val[:, :, None]
+    loss = (per * m).sum() / max(nsel, 1)
+    dspec = dper * m / (loss_div * max(nsel, 1))
+    drelat = dspec.copy()
+    drelat[:, key_index] -= dspec.sum(axis=1)
+    return np.float32(loss), spec.astype(np.float32), drelat.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# gradient clipping + Adam (depth_train.py:455-456, :83; torch.optim.Adam coupled L2 weight decay)
+# --------------------------------------------------------------------------------------
+
+def clip_grad_norm(grads, max_norm, acc=np.float64):
+    """nn.utils.clip_grad_norm_: total = ||g||_2 over all tensors; coef = max_norm/(total+1e-6) clamped to 1."""
+    total = np.sqrt(sum(float((g.astype(acc) ** 2).sum()) for g in grads))
+    coef = min(max_norm / (total + 1e-6), 1.0)
+    return total, coef
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, acc=np.float64):
+    """torch.optim.Adam (non-amsgrad): g' = g*grad_scale + wd*p; m,v EMA; bias-corrected update.
+    `step` is the 1-based count *after* increment.  Returns new (p, m, v)."""
+    pa, ga = p.astype(acc), g.astype(acc) * grad_scale
+    ga = ga + weight_decay * pa
+    m2 = beta1 * m.astype(acc) + (1 - beta1) * ga
+    v2 = beta2 * v.astype(acc) + (1 - beta2) * ga * ga
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = np.sqrt(v2) / np.sqrt(bc2) + eps
+    p2 = pa - (lr / bc1) * m2 / denom
+    return p2.astype(np.float32), m2.astype(np.float32), v2.astype(np.float32)
+
+
+def adapt_learn_rate(epoch, learn_rate, warmup=1, warmup_factor=0.2, learn_decay=0.2):
+    """depth_train.py:621-638."""
+    if epoch - 1 < warmup:
+        return learn_rate * warmup_factor
+    if epoch - 1 < 15:
+        return learn_rate
+    if epoch - 1 < 20:
+        return learn_rate * learn_decay
+    if epoch - 1 < 25:
+        return learn_rate * learn_decay * learn_decay
+    return learn_rate * learn_decay * learn_decay * learn_decay
