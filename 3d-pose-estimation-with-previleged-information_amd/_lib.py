@@ -1,0 +1,80 @@
+"""ctypes binding of libp3d_hip.so (the C ABI declared in include/p3d_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the
+caller gets a P3DError.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libp3d_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'p3d_hip.h')
+
+
+class P3DError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """struct p3d_conv_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'dil', 'Ho', 'Wo', 'c_total', 'c_offset',
+                 'accumulate', 'reserved')]
+
+
+_i32, _i64, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_ptr, _sz = ctypes.c_void_p, ctypes.c_size_t
+_desc = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every function of include/p3d_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    'p3d_version': (_i32, []),
+    'p3d_last_error': (ctypes.c_char_p, []),
+    'p3d_conv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_conv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_conv2d_wgrad_workspace_bytes': (_sz, [_desc]),
+    'p3d_conv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr]),
+    'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
+    'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'p3d_bn_train_fwd': (_i32, [_ptr] * 9 + [_i32, _i32, _i32, _f32, _f32, _i32, _ptr, _sz, _ptr]),
+    'p3d_bn_train_bwd': (_i32, [_ptr] * 10 + [_i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
+    'p3d_bn_eval_fwd': (_i32, [_ptr] * 7 + [_i32, _i32, _i32, _f32, _i32, _ptr]),
+    'p3d_bn_eval_bwd': (_i32, [_ptr] * 10 + [_i32, _i32, _i32, _f32, _i32, _ptr, _sz, _ptr]),
+    'p3d_relu_fwd': (_i32, [_ptr, _ptr, _i64, _ptr]),
+    'p3d_relu_bwd': (_i32, [_ptr, _ptr, _ptr, _i64, _ptr]),
+    'p3d_maxpool3x3s2_fwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    'p3d_maxpool3x3s2_bwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    'p3d_softargmax3d_fwd': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
+    'p3d_softargmax3d_bwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
+    'p3d_pose_loss_fwd_bwd': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _f32, _i32, _f32, _ptr, _ptr]),
+    'p3d_l2norm_sq_accum': (_i32, [_ptr, _i64, _ptr, _ptr]),
+    'p3d_adam_step': (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _ptr, _f32, _ptr]),
+    'p3d_augment_colour': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    'p3d_augment_erase': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises P3DError if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P3DError('libp3d_hip.so is not built (%s missing): run __graft_entry__.build() or `make -C %s`'
+                           % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().p3d_last_error()
+        raise P3DError('%s failed (%d): %s' % (what, code, msg.decode() if msg else ''))

@@ -1,0 +1,141 @@
+"""Shared building blocks of the four network families (depthnet / resnet / fusionnet /
+partial_depthnet).  The reference repeats these classes in every file (depthnet.py:10-116,
+resnet.py:21-119, fusionnet.py:21-127, partial_depthnet.py:11-157); here they are written once,
+on the fused HIP layers, and the family modules only re-export them under the reference's names.
+
+Module attribute names (conv1/bn1/.../downsample.0/.1, layerN.i) reproduce the reference's
+state_dict keys so checkpoints interchange (log.py:32-40).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import BatchNorm2d, Conv2d, MaxPool2d, Sequential
+from .partial_conv import PartialConv
+
+
+def stage_geometry(stride):
+    """(stride2, stride3, stride4), (dilate2, dilate3, dilate4) from the network stride (depthnet.py:130-136)."""
+    lg = float(np.log2(stride))
+    s2 = int(min(max(lg, 2), 3) - 1)
+    s3 = int(min(max(lg, 3), 4) - 2)
+    s4 = int(min(max(lg, 4), 5) - 3)
+    return (s2, s3, s4), (3 - s2, (3 - s2) * (3 - s3), (3 - s2) * (3 - s3) * (3 - s4))
+
+
+class _ResidualBlock(nn.Module):
+    """conv-bn-relu chain + identity/downsample shortcut; the last BN kernel also adds the shortcut and
+    applies the closing ReLU (one pass over the tensor instead of three)."""
+    expansion = 1
+    kind = 'basic'
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, skip_relu=False, partial=False):
+        super().__init__()
+        conv = PartialConv if partial else Conv2d
+        if self.kind == 'basic':
+            self.conv1 = conv(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation, padding=dilation, bias=False)
+            self.bn1 = BatchNorm2d(planes)
+            self.conv2 = conv(planes, planes, kernel_size=3, padding=1, bias=False)
+            self.bn2 = BatchNorm2d(planes)
+            self._chain = (('conv1', 'bn1'), ('conv2', 'bn2'))
+        else:
+            self.conv1 = conv(inplanes, planes, kernel_size=1, bias=False)
+            self.bn1 = BatchNorm2d(planes)
+            self.conv2 = conv(planes, planes, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+            self.bn2 = BatchNorm2d(planes)
+            self.conv3 = conv(planes, planes * 4, kernel_size=1, bias=False)
+            self.bn3 = BatchNorm2d(planes * 4)
+            self._chain = (('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3'))
+        self.downsample = downsample
+        self.stride = stride
+        self.skip_relu = skip_relu
+        self.partial = partial
+
+    def _shortcut(self, x):
+        if self.downsample is None:
+            return x
+        return self.downsample[1](self.downsample[0](x))
+
+    def forward(self, x):
+        if self.partial:                      # partial_depthnet.py:44-46: blocks receive an (x, veil) tuple
+            return self.forward_partial(*x)
+        out = x
+        last = len(self._chain) - 1
+        for i, (cname, bname) in enumerate(self._chain):
+            out = getattr(self, cname)(out)
+            if i < last:
+                out = getattr(self, bname)(out, relu=True)
+            else:
+                out = getattr(self, bname)(out, res=self._shortcut(x), relu=not self.skip_relu)
+        return out
+
+    def forward_partial(self, x, veil):
+        out = x
+        last = len(self._chain) - 1
+        for i, (cname, bname) in enumerate(self._chain):
+            out, veil = getattr(self, cname)(out, veil)
+            if i < last:
+                out = getattr(self, bname)(out, relu=True)
+            else:
+                out = getattr(self, bname)(out, res=self._shortcut(x), relu=True)   # shortcut stays dense (partial_depthnet.py:70-75)
+        return out, veil
+
+
+class BasicBlock(_ResidualBlock):
+    expansion = 1
+    kind = 'basic'
+
+
+class Bottleneck(_ResidualBlock):
+    expansion = 4
+    kind = 'bottleneck'
+
+
+def kaiming_fan_out_(module):
+    """Init loop of depthnet.py:148-154 / partial_depthnet.py:187-193."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+def normal_fan_out_(module):
+    """Init loop of resnet.py:151-158 / fusionnet.py:186-193."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, (2.0 / n) ** 0.5)
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+class TrunkBase(nn.Module):
+    """Holds `inplanes` bookkeeping and the stage factory shared by every family."""
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1, skip_relu=False, partial=False):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = Sequential(
+                Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                BatchNorm2d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, dilation, downsample, partial=partial)]
+        self.inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            layers.append(block(self.inplanes, planes, skip_relu=(skip_relu and i == blocks - 1), partial=partial))
+        return Sequential(*layers)
+
+    def freeze_batchnorm(self):
+        """depthnet.py:158-161"""
+        for module in self.modules():
+            if isinstance(module, nn.BatchNorm2d):
+                module.eval()
+
+
+def stem(conv, bn, pool, x):
+    """conv -> BN+ReLU (one kernel) -> maxpool."""
+    return pool(bn(conv(x), relu=True))

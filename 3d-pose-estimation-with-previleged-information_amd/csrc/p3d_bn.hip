@@ -1,0 +1,372 @@
+// BatchNorm2d (train + eval) with fused residual add and ReLU, NCHW fp32, gfx950.
+//
+// Replaces nn.BatchNorm2d + F.relu + `out + res` (depthnet.py:42-56,98-116,139,189-190; fusionnet.py:140).
+// HBM-bound: per element the train forward reads x twice (+res once) and writes y once; the backward
+// reads dy,x,y twice and writes dx (+dres) once.  Channel statistics are reduced in fp64 (per-thread
+// fp64 accumulators -> wavefront shuffles -> LDS -> per-split partials in the workspace), so the batch
+// mean/variance do not depend on the fp32 summation order.
+//
+// Grid: (C, SPLIT).  Block (c, s) owns images n = s, s+SPLIT, ... of channel c, so every per-channel
+// constant is block-uniform (kept in SGPRs) and global accesses are 16-B per lane along H*W.
+#include "p3d_common.h"
+
+namespace p3d {
+
+constexpr int BN_MAX_SPLIT = 64;
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red /*[8]*/) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[4 + w] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+    __syncthreads();
+}
+
+// partial[(c*split + s)*2 + {0,1}] = sum x, sum x^2 over this block's images
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int N, int C, int HW) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = s; n < N; n += split) {
+        const float* src = x + ((size_t)n * C + c) * HW;
+        if constexpr (VEC) {
+            const float4* v = reinterpret_cast<const float4*>(src);
+            for (int i = threadIdx.x; i < HW / 4; i += 256) {
+                const float4 q = v[i];
+                s1 += (double)q.x + (double)q.y + (double)q.z + (double)q.w;
+                s2 += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                const double q = src[i];
+                s1 += q; s2 += q * q;
+            }
+        }
+    }
+    __shared__ double red[8];
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * split + s) * 2 + 0] = s1;
+        partial[((size_t)c * split + s) * 2 + 1] = s2;
+    }
+}
+
+// y = act((x-mean)*invstd*gamma + beta + res); block (c,0) also publishes save_mean/save_invstd and running stats
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const double* __restrict__ partial, int nsplit,
+                                                       float* running_mean, float* running_var, float* __restrict__ y,
+                                                       float* save_mean, float* save_invstd, int N, int C, int HW, float momentum,
+                                                       float eps, int relu) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nsplit; ++i) {
+        s1 += partial[((size_t)c * nsplit + i) * 2 + 0];
+        s2 += partial[((size_t)c * nsplit + i) * 2 + 1];
+    }
+    const double cnt = (double)N * HW;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    if (s == 0 && threadIdx.x == 0) {
+        save_mean[c] = fmean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+    const float sc = invstd * gamma[c];
+    const float sh = beta[c] - fmean * sc;
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + c) * HW;
+        if constexpr (VEC) {
+            const float4* xv = reinterpret_cast<const float4*>(x + off);
+            const float4* rv = res ? reinterpret_cast<const float4*>(res + off) : nullptr;
+            float4* yv = reinterpret_cast<float4*>(y + off);
+            for (int i = threadIdx.x; i < HW / 4; i += 256) {
+                float4 q = xv[i];
+                q.x = fmaf(q.x, sc, sh); q.y = fmaf(q.y, sc, sh); q.z = fmaf(q.z, sc, sh); q.w = fmaf(q.w, sc, sh);
+                if (rv) { const float4 r = rv[i]; q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w; }
+                if (relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+                yv[i] = q;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float q = fmaf(x[off + i], sc, sh);
+                if (res) q += res[off + i];
+                if (relu) q = fmaxf(q, 0.f);
+                y[off + i] = q;
+            }
+        }
+    }
+}
+
+// eval-mode forward: statistics come from running_mean / running_var
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv_,
+                                                      float* __restrict__ y, int N, int C, int HW, float eps, int relu) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const float sc = gamma[c] / sqrtf(rv_[c] + eps);
+    const float sh = beta[c] - rm[c] * sc;
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + c) * HW;
+        if constexpr (VEC) {
+            const float4* xv = reinterpret_cast<const float4*>(x + off);
+            const float4* rv = res ? reinterpret_cast<const float4*>(res + off) : nullptr;
+            float4* yv = reinterpret_cast<float4*>(y + off);
+            for (int i = threadIdx.x; i < HW / 4; i += 256) {
+                float4 q = xv[i];
+                q.x = fmaf(q.x, sc, sh); q.y = fmaf(q.y, sc, sh); q.z = fmaf(q.z, sc, sh); q.w = fmaf(q.w, sc, sh);
+                if (rv) { const float4 r = rv[i]; q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w; }
+                if (relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+                yv[i] = q;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float q = fmaf(x[off + i], sc, sh);
+                if (res) q += res[off + i];
+                if (relu) q = fmaxf(q, 0.f);
+                y[off + i] = q;
+            }
+        }
+    }
+}
+
+// backward pass 1: partial sums of g and g*xhat with g = relu ? dy*(y>0) : dy.
+// `stat2_is_var`: stat2 holds a variance (eval mode) instead of invstd.
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ stat2, int stat2_is_var,
+                                                            float eps, double* __restrict__ partial, int N, int C, int HW, int relu) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const float mu = mean[c];
+    const float is = stat2_is_var ? 1.f / sqrtf(stat2[c] + eps) : stat2[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + c) * HW;
+        if constexpr (VEC) {
+            const float4* gv = reinterpret_cast<const float4*>(dy + off);
+            const float4* xv = reinterpret_cast<const float4*>(x + off);
+            const float4* yv = reinterpret_cast<const float4*>(y + off);
+            for (int i = threadIdx.x; i < HW / 4; i += 256) {
+                float4 g = gv[i];
+                const float4 q = xv[i];
+                if (relu) {
+                    const float4 o = yv[i];
+                    g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                }
+                s1 += (double)g.x + (double)g.y + (double)g.z + (double)g.w;
+                s2 += (double)(g.x * ((q.x - mu) * is)) + (double)(g.y * ((q.y - mu) * is)) + (double)(g.z * ((q.z - mu) * is)) +
+                      (double)(g.w * ((q.w - mu) * is));
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float g = dy[off + i];
+                if (relu && !(y[off + i] > 0.f)) g = 0.f;
+                s1 += g;
+                s2 += (double)(g * ((x[off + i] - mu) * is));
+            }
+        }
+    }
+    __shared__ double red[8];
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * split + s) * 2 + 0] = s1;
+        partial[((size_t)c * split + s) * 2 + 1] = s2;
+    }
+}
+
+// backward pass 2: dx (+ dres) and, from block (c,0), dgamma/dbeta.
+// train: dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); eval (frozen stats): dx = gamma*invstd*g
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ stat2, int stat2_is_var, float eps,
+                                                           const double* __restrict__ partial, int nsplit, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* dgamma, float* dbeta, int N, int C, int HW,
+                                                           int relu, int train) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nsplit; ++i) {
+        s1 += partial[((size_t)c * nsplit + i) * 2 + 0];
+        s2 += partial[((size_t)c * nsplit + i) * 2 + 1];
+    }
+    if (s == 0 && threadIdx.x == 0) {
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+    }
+    const float mu = mean[c];
+    const float is = stat2_is_var ? 1.f / sqrtf(stat2[c] + eps) : stat2[c];
+    const float gs = gamma[c] * is;
+    const double cnt = (double)N * HW;
+    const float k1 = train ? (float)(s1 / cnt) : 0.f;
+    const float k2 = train ? (float)(s2 / cnt) : 0.f;
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + c) * HW;
+        if constexpr (VEC) {
+            const float4* gv = reinterpret_cast<const float4*>(dy + off);
+            const float4* xv = reinterpret_cast<const float4*>(x + off);
+            const float4* yv = reinterpret_cast<const float4*>(y + off);
+            float4* dxv = reinterpret_cast<float4*>(dx + off);
+            float4* drv = dres ? reinterpret_cast<float4*>(dres + off) : nullptr;
+            for (int i = threadIdx.x; i < HW / 4; i += 256) {
+                float4 g = gv[i];
+                const float4 q = xv[i];
+                if (relu) {
+                    const float4 o = yv[i];
+                    g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                }
+                if (drv) drv[i] = g;
+                float4 d;
+                d.x = gs * (g.x - k1 - (q.x - mu) * is * k2);
+                d.y = gs * (g.y - k1 - (q.y - mu) * is * k2);
+                d.z = gs * (g.z - k1 - (q.z - mu) * is * k2);
+                d.w = gs * (g.w - k1 - (q.w - mu) * is * k2);
+                dxv[i] = d;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float g = dy[off + i];
+                if (relu && !(y[off + i] > 0.f)) g = 0.f;
+                if (dres) dres[off + i] = g;
+                dx[off + i] = gs * (g - k1 - (x[off + i] - mu) * is * k2);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+static int pick_split(int N, int C) {
+    int split = (int)ceil_div(2048, C);      // >= ~8 blocks per CU over the chip
+    if (split > N) split = N;
+    if (split > BN_MAX_SPLIT) split = BN_MAX_SPLIT;
+    if (split < 1) split = 1;
+    return split;
+}
+
+static bool vec_ok(int HW, const void* a, const void* b, const void* c, const void* d, const void* e) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return (HW % 4 == 0) && al(a) && al(b) && al(c) && al(d) && al(e);
+}
+
+}  // namespace p3d
+
+using namespace p3d;
+
+extern "C" {
+
+size_t p3d_bn_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
+    (void)N; (void)HW;
+    return (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double);
+}
+
+int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* y, float* save_mean, float* save_invstd, int32_t N, int32_t C, int32_t HW,
+                         float momentum, float eps, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "bn_train_fwd: null tensor");
+    P3D_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad shape %d %d %d", N, C, HW);
+    P3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats must come as a pair");
+    if (!workspace || workspace_bytes < p3d_bn_workspace_bytes(N, C, HW)) {
+        set_error("bn_train_fwd: workspace too small");
+        return P3D_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int split = pick_split(N, C);
+    dim3 grid(C, split);
+    double* partial = (double*)workspace;
+    if (vec_ok(HW, x, res, y, nullptr, nullptr)) {
+        hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(256), 0, st, x, partial, N, C, HW);
+        hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, st, x, res, gamma, beta, partial, split, running_mean, running_var, y,
+                           save_mean, save_invstd, N, C, HW, momentum, eps, relu);
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(256), 0, st, x, partial, N, C, HW);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, st, x, res, gamma, beta, partial, split, running_mean, running_var, y,
+                           save_mean, save_invstd, N, C, HW, momentum, eps, relu);
+    }
+    return check_launch("bn_train_fwd");
+}
+
+static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* stat2,
+                             int stat2_is_var, float eps, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
+                             int32_t HW, int32_t relu, int train, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(dy && x && gamma && mean && stat2 && dx && dgamma && dbeta, "bn_bwd: null tensor");
+    P3D_REQUIRE(!relu || y, "bn_bwd: relu backward needs the forward output");
+    P3D_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd: bad shape %d %d %d", N, C, HW);
+    if (!workspace || workspace_bytes < p3d_bn_workspace_bytes(N, C, HW)) {
+        set_error("bn_bwd: workspace too small");
+        return P3D_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int split = pick_split(N, C);
+    dim3 grid(C, split);
+    double* partial = (double*)workspace;
+    const float* yy = y ? y : x;
+    if (vec_ok(HW, dy, x, yy, dx, dres)) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
+                           dx, dres, dgamma, dbeta, N, C, HW, relu, train);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
+                           dx, dres, dgamma, dbeta, N, C, HW, relu, train);
+    }
+    return check_launch("bn_bwd");
+}
+
+int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                         const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
+                         int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_bwd_common(dy, x, y, gamma, save_mean, save_invstd, 0, 0.f, dx, dres, dgamma, dbeta, N, C, HW, relu, 1, workspace,
+                         workspace_bytes, stream);
+}
+
+int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float* y, int32_t N, int32_t C, int32_t HW, float eps, int32_t relu, void* stream) {
+    P3D_REQUIRE(x && gamma && beta && running_mean && running_var && y, "bn_eval_fwd: null tensor");
+    P3D_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_eval_fwd: bad shape %d %d %d", N, C, HW);
+    const int split = pick_split(N, C);
+    dim3 grid(C, split);
+    if (vec_ok(HW, x, res, y, nullptr, nullptr))
+        hipLaunchKernelGGL(bn_eval_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, running_mean, running_var, y, N, C, HW, eps, relu);
+    else
+        hipLaunchKernelGGL(bn_eval_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, running_mean, running_var, y, N, C, HW, eps, relu);
+    return check_launch("bn_eval_fwd");
+}
+
+int32_t p3d_bn_eval_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* running_mean,
+                        const float* running_var, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
+                        int32_t HW, float eps, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_bwd_common(dy, x, y, gamma, running_mean, running_var, 1, eps, dx, dres, dgamma, dbeta, N, C, HW, relu, 0, workspace,
+                         workspace_bytes, stream);
+}
+
+int32_t p3d_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    P3D_REQUIRE(x && y && n > 0, "relu_fwd: bad argument");
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n);
+    return check_launch("relu_fwd");
+}
+
+int32_t p3d_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    P3D_REQUIRE(dy && y && dx && n > 0, "relu_bwd: bad argument");
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (size_t)n);
+    return check_launch("relu_bwd");
+}
+
+}  // extern "C"

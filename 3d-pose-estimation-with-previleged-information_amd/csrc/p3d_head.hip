@@ -1,0 +1,259 @@
+// Max-pool 3x3/s2/p1, volumetric soft-argmax pose head and the pose loss, fp32, gfx950.
+//
+//   nn.MaxPool2d(3, 2, 1)            depthnet.py:140,192; partial_depthnet.py:219-220
+//   utils.to_heatmap + utils.decode  utils.py:154-194
+//   loss block of vanilla_train      depth_train.py:397-405 (train.py:166-174 with loss_div = 1)
+#include "p3d_common.h"
+
+namespace p3d {
+
+// ---------------------------------------------------------------------------------------------
+// max pool: one thread per output pixel (wo fastest -> coalesced stores, stride-2 window reads served by L1/L2)
+// First maximum in row-major window order wins (torch CPU kernel: strict '>'), NaN propagates like torch.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int NC, int H, int W, int Ho, int Wo) {
+    const size_t total = (size_t)NC * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo);
+        const int ho = (int)((i / Wo) % Ho);
+        const size_t nc = i / ((size_t)Wo * Ho);
+        const float* src = x + nc * H * W;
+        float best = -INFINITY;
+        int bi = 0;
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float v = src[hi * W + wi];
+                if (first || v > best || v != v) { best = v; bi = r * 3 + s; first = false; }
+            }
+        }
+        y[i] = best;
+        if (idx) idx[i] = (uint8_t)bi;
+    }
+}
+
+// one thread per input pixel: gather from the (at most 2x2) windows that cover it -> no atomics, deterministic
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                          int NC, int H, int W, int Ho, int Wo) {
+    const size_t total = (size_t)NC * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wi = (int)(i % W);
+        const int hi = (int)((i / W) % H);
+        const size_t nc = i / ((size_t)W * H);
+        const float* g = dy + nc * Ho * Wo;
+        const uint8_t* ix = idx + nc * Ho * Wo;
+        float acc = 0.f;
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
+        const int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            const int r = hi - (2 * ho - 1);
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const int s = wi - (2 * wo - 1);
+                if (ix[ho * Wo + wo] == r * 3 + s) acc += g[ho * Wo + wo];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// soft-argmax head: one 256-thread block per (b, j).  Logit (h, w, d) of joint j lives at
+// z[((b*D*J + d*J + j)*H + h)*W + w]: for fixed d the H*W plane is contiguous -> coalesced reads.
+// torch.linspace(0, 2, n) in fp32: start + i*step for the lower half, end - (n-1-i)*step for the upper half.
+__device__ __forceinline__ float grid_at(int i, int n) {
+    if (n == 1) return 0.f;
+    const float step = 2.f / (float)(n - 1);
+    return (i < n / 2) ? (float)i * step : 2.f - (float)(n - 1 - i) * step;
+}
+
+struct HeadStats { float mx; double sum, sx, sy, sz; };
+
+__device__ HeadStats head_stats(const float* __restrict__ zb, int D, int J, int H, int W, double* red /*[16]*/, float* redf /*[4]*/) {
+    const int HW = H * W, total = D * HW;
+    const int t = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = t; i < total; i += 256) {
+        const int d = i / HW, hw = i - d * HW;
+        mx = fmaxf(mx, zb[(size_t)d * J * HW + hw]);
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) redf[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    __syncthreads();
+    double s = 0, sx = 0, sy = 0, sz = 0;
+    for (int i = t; i < total; i += 256) {
+        const int d = i / HW, hw = i - d * HW;
+        const int h = hw / W, w = hw - h * W;
+        const float e = expf(zb[(size_t)d * J * HW + hw] - mx);
+        s += e;
+        sx += (double)(e * grid_at(w, W));
+        sy += (double)(e * grid_at(h, H));
+        sz += (double)(e * grid_at(d, D));
+    }
+    s = wave_sum(s); sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+    if ((t & 63) == 0) { const int w = t >> 6; red[w] = s; red[4 + w] = sx; red[8 + w] = sy; red[12 + w] = sz; }
+    __syncthreads();
+    HeadStats r;
+    r.mx = mx;
+    r.sum = red[0] + red[1] + red[2] + red[3];
+    r.sx = red[4] + red[5] + red[6] + red[7];
+    r.sy = red[8] + red[9] + red[10] + red[11];
+    r.sz = red[12] + red[13] + red[14] + red[15];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void softargmax3d_fwd_kernel(const float* __restrict__ z, float* __restrict__ coords, int D, int J, int H, int W,
+                                                               float depth_range) {
+    __shared__ double red[16];
+    __shared__ float redf[4];
+    const int b = blockIdx.x / J, j = blockIdx.x % J;
+    const float* zb = z + ((size_t)b * D * J + j) * H * W;
+    const HeadStats st = head_stats(zb, D, J, H, W, red, redf);
+    if (threadIdx.x == 0) {
+        float* o = coords + ((size_t)b * J + j) * 3;
+        o[0] = (float)(st.sx / st.sum) * depth_range;
+        o[1] = (float)(st.sy / st.sum) * depth_range;
+        o[2] = (float)(st.sz / st.sum) * depth_range;
+    }
+}
+
+// dL/dl_i = p_i * range * sum_a dc_a (g_a(i) - E_a)
+__global__ __launch_bounds__(256) void softargmax3d_bwd_kernel(const float* __restrict__ dcoords, const float* __restrict__ z, float* __restrict__ dz,
+                                                               int D, int J, int H, int W, float depth_range) {
+    __shared__ double red[16];
+    __shared__ float redf[4];
+    const int b = blockIdx.x / J, j = blockIdx.x % J;
+    const size_t zoff = ((size_t)b * D * J + j) * H * W;
+    const float* zb = z + zoff;
+    float* dzb = dz + zoff;
+    const HeadStats st = head_stats(zb, D, J, H, W, red, redf);
+    const float inv = (float)(1.0 / st.sum);
+    const float ex = (float)(st.sx / st.sum), ey = (float)(st.sy / st.sum), ez = (float)(st.sz / st.sum);
+    const float* dc = dcoords + ((size_t)b * J + j) * 3;
+    const float gx = dc[0] * depth_range, gy = dc[1] * depth_range, gz = dc[2] * depth_range;
+    const int HW = H * W, total = D * HW;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int d = i / HW, hw = i - d * HW;
+        const int h = hw / W, w = hw - h * W;
+        const size_t a = (size_t)d * J * HW + hw;
+        const float p = expf(zb[a] - st.mx) * inv;
+        dzb[a] = p * (gx * (grid_at(w, W) - ex) + gy * (grid_at(h, H) - ey) + gz * (grid_at(d, D) - ez));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss block: a single 256-thread block (B*J*3 scalars: 3264 at B = 64)
+__global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict__ relat, const float* __restrict__ true_cam,
+                                                        const uint8_t* __restrict__ true_val, float* __restrict__ loss, float* __restrict__ spec_cam,
+                                                        float* __restrict__ drelat, int B, int J, int key, float loss_div, int criterion,
+                                                        float loss_scale, const float* __restrict__ count_override) {
+    __shared__ double red[8];
+    const int t = threadIdx.x;
+    const int BJ = B * J;
+    double cnt = 0.0, acc = 0.0;
+    for (int i = t; i < BJ; i += 256) cnt += true_val[i] ? 3.0 : 0.0;
+    cnt = wave_sum(cnt);
+    if ((t & 63) == 0) red[t >> 6] = cnt;
+    __syncthreads();
+    cnt = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float denom = (count_override != nullptr && count_override[0] > 0.f) ? count_override[0] : (float)(cnt > 0.0 ? cnt : 1.0);
+    // pass 1: spec, per-element loss, d loss / d spec (stored in drelat)
+    for (int i = t; i < BJ * 3; i += 256) {
+        const int bj = i / 3, a = i - bj * 3;
+        const int b = bj / J;
+        const size_t ko = ((size_t)b * J + key) * 3 + a;
+        const float spec = relat[i] - relat[ko] + true_cam[ko];
+        spec_cam[i] = spec;
+        float per = 0.f, dper = 0.f;
+        if (true_val[bj]) {
+            const float diff = spec / loss_div - true_cam[i] / loss_div;
+            const float ad = fabsf(diff);
+            if (criterion == 0) {           // SmoothL1, beta = 1
+                if (ad < 1.f) { per = 0.5f * diff * diff; dper = diff; }
+                else { per = ad - 0.5f; dper = diff > 0.f ? 1.f : -1.f; }
+            } else if (criterion == 1) {    // L1
+                per = ad; dper = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            } else {                        // MSE
+                per = diff * diff; dper = 2.f * diff;
+            }
+        }
+        acc += per;
+        drelat[i] = dper * loss_scale / (loss_div * denom);
+    }
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / denom);
+    // pass 2: the key joint receives minus the sum of every joint's gradient of its image (own term included)
+    __syncthreads();
+    for (int i = t; i < B * 3; i += 256) {
+        const int b = i / 3, a = i - b * 3;
+        float s = 0.f;
+        for (int j = 0; j < J; ++j) s += drelat[((size_t)b * J + j) * 3 + a];
+        const size_t ko = ((size_t)b * J + key) * 3 + a;
+        // written after all reads of this (b, a) column by this same thread -> no race
+        drelat[ko] -= s;
+    }
+}
+
+}  // namespace p3d
+
+using namespace p3d;
+
+extern "C" {
+
+int32_t p3d_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int32_t NC, int32_t H, int32_t W, void* stream) {
+    P3D_REQUIRE(x && y && NC > 0 && H > 0 && W > 0, "maxpool_fwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)NC * Ho * Wo;
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, idx, NC, H, W, Ho, Wo);
+    return check_launch("maxpool_fwd");
+}
+
+int32_t p3d_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t NC, int32_t H, int32_t W, void* stream) {
+    P3D_REQUIRE(dy && idx && dx && NC > 0 && H > 0 && W > 0, "maxpool_bwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)NC * H * W;
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, NC, H, W, Ho, Wo);
+    return check_launch("maxpool_bwd");
+}
+
+int32_t p3d_softargmax3d_fwd(const float* z, float* coords, int32_t B, int32_t D, int32_t J, int32_t H, int32_t W,
+                             float depth_range, void* stream) {
+    P3D_REQUIRE(z && coords && B > 0 && D > 0 && J > 0 && H > 0 && W > 0, "softargmax3d_fwd: bad argument");
+    hipLaunchKernelGGL(softargmax3d_fwd_kernel, dim3(B * J), dim3(256), 0, (hipStream_t)stream, z, coords, D, J, H, W, depth_range);
+    return check_launch("softargmax3d_fwd");
+}
+
+int32_t p3d_softargmax3d_bwd(const float* dcoords, const float* z, float* dz, int32_t B, int32_t D, int32_t J, int32_t H,
+                             int32_t W, float depth_range, void* stream) {
+    P3D_REQUIRE(dcoords && z && dz && B > 0 && D > 0 && J > 0 && H > 0 && W > 0, "softargmax3d_bwd: bad argument");
+    hipLaunchKernelGGL(softargmax3d_bwd_kernel, dim3(B * J), dim3(256), 0, (hipStream_t)stream, dcoords, z, dz, D, J, H, W, depth_range);
+    return check_launch("softargmax3d_bwd");
+}
+
+int32_t p3d_pose_loss_fwd_bwd(const float* relat, const float* true_cam, const uint8_t* true_val, float* loss, float* spec_cam,
+                              float* drelat, int32_t B, int32_t J, int32_t key_index, float loss_div, int32_t criterion,
+                              float loss_scale, const float* count_override, void* stream) {
+    P3D_REQUIRE(relat && true_cam && true_val && loss && spec_cam && drelat, "pose_loss: null tensor");
+    P3D_REQUIRE(B > 0 && J > 0 && key_index >= 0 && key_index < J, "pose_loss: bad shape B=%d J=%d key=%d", B, J, key_index);
+    P3D_REQUIRE(criterion >= 0 && criterion <= 2 && loss_div != 0.f, "pose_loss: bad criterion/loss_div");
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, relat, true_cam, true_val, loss, spec_cam, drelat, B, J,
+                       key_index, loss_div, criterion, loss_scale, count_override);
+    return check_launch("pose_loss");
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// Global-norm gradient clipping + Adam on flat fp32 buffers, and the on-GPU colour/eraser augmentation.
+//
+//   nn.utils.clip_grad_norm_(params, 5.0) + optim.Adam(lr, weight_decay=4e-5).step()   depth_train.py:455-456, :83
+//   augment_colour.random_color   augment_colour.py:48-67      augment_occluder.random_erase   augment_occluder.py:84-105
+//
+// All HBM-bound streaming kernels: 16-B per lane, grid-stride over <= 2048 blocks.  Adam touches 28 B per
+// parameter (read p,g,m,v; write p,m,v); the clip coefficient is read from device memory so the step needs
+// no host round trip between the norm and the update.
+#include "p3d_common.h"
+
+namespace p3d {
+
+__global__ __launch_bounds__(256) void l2norm_sq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ accum) {
+    double s = 0.0;
+    const size_t n4 = n / 4;
+    const float4* v = reinterpret_cast<const float4*>(g);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 q = v[i];
+        s += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const double q = g[n4 * 4 + threadIdx.x];
+        s += q * q;
+    }
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(accum, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void l2norm_sq_scalar_kernel(const float* __restrict__ g, size_t n, double* __restrict__ accum) {
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (double)g[i] * g[i];
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(accum, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, max_norm, grad_scale;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
+    g = fmaf(a.weight_decay, p, g * coef);
+    m = m + (g - m) * (1.f - a.beta1);                     // exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(v, a.beta2, (1.f - a.beta2) * g * g);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    p = p - a.lr_over_bc1 * (m / denom);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   size_t n, AdamArgs a, const double* __restrict__ norm_sq) {
+    float coef = a.grad_scale;
+    if (norm_sq != nullptr && a.max_norm > 0.f) {
+        const float total = (float)sqrt(*norm_sq) * a.grad_scale;      // norm of the scaled gradient
+        coef = fminf(a.max_norm / (total + 1e-6f), 1.f) * a.grad_scale;
+    }
+    if constexpr (VEC) {
+        const size_t n4 = n / 4;
+        float4* pv = reinterpret_cast<float4*>(p);
+        const float4* gv = reinterpret_cast<const float4*>(g);
+        float4* mv = reinterpret_cast<float4*>(m);
+        float4* vv = reinterpret_cast<float4*>(v);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 P = pv[i], M = mv[i], V = vv[i];
+            const float4 G = gv[i];
+            adam_one(P.x, G.x, M.x, V.x, a, coef);
+            adam_one(P.y, G.y, M.y, V.y, a, coef);
+            adam_one(P.z, G.z, M.z, V.z, a, coef);
+            adam_one(P.w, G.w, M.w, V.w, a, coef);
+            pv[i] = P; mv[i] = M; vv[i] = V;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const size_t i = n4 * 4 + threadIdx.x;
+            adam_one(p[i], g[i], m[i], v[i], a, coef);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+            adam_one(p[i], g[i], m[i], v[i], a, coef);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// colour augmentation on planar float images holding 0..255 values (the reference works on HWC uint8).
+// OpenCV float conventions: H in [0,360), S and V in [0,1].
+__device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
+__global__ __launch_bounds__(256) void augment_colour_kernel(float* __restrict__ img, const float* __restrict__ params, int HW) {
+    const int b = blockIdx.y;
+    const float bright = params[b * 4 + 0], contrast = params[b * 4 + 1], hue = params[b * 4 + 2], sat = params[b * 4 + 3];
+    float* pr = img + (size_t)b * 3 * HW;
+    float* pg = pr + HW;
+    float* pb = pg + HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float r = pr[i] / 255.0f, g = pg[i] / 255.0f, bl = pb[i] / 255.0f;
+        // augment_colour.py:6-12 brightness, :15-24 contrast
+        r = clip01(r + bright); g = clip01(g + bright); bl = clip01(bl + bright);
+        r = clip01((r - 0.5f) * contrast + 0.5f); g = clip01((g - 0.5f) * contrast + 0.5f); bl = clip01((bl - 0.5f) * contrast + 0.5f);
+        // RGB -> HSV
+        const float vmax = fmaxf(r, fmaxf(g, bl)), vmin = fminf(r, fminf(g, bl));
+        const float diff = vmax - vmin;
+        float s = vmax > 1.1920929e-07f ? diff / vmax : 0.f;
+        float h = 0.f;
+        if (diff > 1.1920929e-07f) {
+            const float sc = 60.f / diff;
+            if (vmax == r) h = (g - bl) * sc;
+            else if (vmax == g) h = (bl - r) * sc + 120.f;
+            else h = (r - g) * sc + 240.f;
+            if (h < 0.f) h += 360.f;
+        }
+        // augment_colour.py:27-36 hue, :39-45 saturation
+        h += hue;
+        if (h < 0.f) h += 360.f;
+        if (h >= 360.f) h -= 360.f;
+        s = clip01(s * sat);
+        // HSV -> RGB (sector form)
+        const float hh = h / 60.f;
+        int sector = (int)floorf(hh);
+        const float f = hh - (float)sector;
+        sector = ((sector % 6) + 6) % 6;
+        const float v = vmax;
+        const float p0 = v * (1.f - s), q0 = v * (1.f - s * f), t0 = v * (1.f - s * (1.f - f));
+        switch (sector) {
+            case 0: r = v; g = t0; bl = p0; break;
+            case 1: r = q0; g = v; bl = p0; break;
+            case 2: r = p0; g = v; bl = t0; break;
+            case 3: r = p0; g = q0; bl = v; break;
+            case 4: r = t0; g = p0; bl = v; break;
+            default: r = v; g = p0; bl = q0; break;
+        }
+        // (dest * 255).astype(np.uint8): truncation, augment_colour.py:67
+        pr[i] = floorf(fminf(fmaxf(r * 255.f, 0.f), 255.f));
+        pg[i] = floorf(fminf(fmaxf(g * 255.f, 0.f), 255.f));
+        pb[i] = floorf(fminf(fmaxf(bl * 255.f, 0.f), 255.f));
+    }
+}
+
+__global__ __launch_bounds__(256) void augment_erase_kernel(float* __restrict__ img, const int32_t* __restrict__ rects, const float* __restrict__ colour,
+                                                            int C, int H, int W) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int x0 = max(rects[b * 4 + 0], 0), y0 = max(rects[b * 4 + 1], 0);
+    const int x1 = min(rects[b * 4 + 2], W), y1 = min(rects[b * 4 + 3], H);
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (rw <= 0 || rh <= 0) return;
+    float* dst = img + ((size_t)b * C + c) * H * W;
+    const float col = colour[b * C + c];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rw * rh; i += gridDim.x * blockDim.x) {
+        const int yy = i / rw, xx = i - yy * rw;
+        dst[(y0 + yy) * W + x0 + xx] = col;
+    }
+}
+
+}  // namespace p3d
+
+using namespace p3d;
+
+extern "C" {
+
+int32_t p3d_l2norm_sq_accum(const float* g, int64_t n, double* accum, void* stream) {
+    P3D_REQUIRE(g && accum && n > 0, "l2norm_sq_accum: bad argument");
+    const unsigned blocks = (unsigned)(ceil_div(n, 1024) < 2048 ? ceil_div(n, 1024) : 2048);
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0)
+        hipLaunchKernelGGL(l2norm_sq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (size_t)n, accum);
+    else
+        hipLaunchKernelGGL(l2norm_sq_scalar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (size_t)n, accum);
+    return check_launch("l2norm_sq_accum");
+}
+
+int32_t p3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, float max_norm, const double* norm_sq, float grad_scale, void* stream) {
+    P3D_REQUIRE(p && g && m && v && n > 0, "adam_step: bad argument");
+    P3D_REQUIRE(step >= 1, "adam_step: step must be >= 1 (got %d)", step);
+    AdamArgs a;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.max_norm = max_norm; a.grad_scale = grad_scale;
+    const unsigned blocks = (unsigned)(ceil_div(n, 1024) < 2048 ? ceil_div(n, 1024) : 2048);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, a, norm_sq);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, a, norm_sq);
+    return check_launch("adam_step");
+}
+
+int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream) {
+    P3D_REQUIRE(img && params && B > 0 && H > 0 && W > 0, "augment_colour: bad argument");
+    const int HW = H * W;
+    const unsigned bx = (unsigned)(ceil_div(HW, 256) < 64 ? ceil_div(HW, 256) : 64);
+    hipLaunchKernelGGL(augment_colour_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, img, params, HW);
+    return check_launch("augment_colour");
+}
+
+int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C, int32_t H, int32_t W,
+                          void* stream) {
+    P3D_REQUIRE(img && rects && colour && B > 0 && C > 0 && H > 0 && W > 0, "augment_erase: bad argument");
+    hipLaunchKernelGGL(augment_erase_kernel, dim3(16, C, B), dim3(256), 0, (hipStream_t)stream, img, rects, colour, C, H, W);
+    return check_launch("augment_erase");
+}
+
+}  // extern "C"

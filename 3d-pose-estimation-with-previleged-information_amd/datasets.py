@@ -1,0 +1,43 @@
+"""RGB-only loader API of the legacy entry point (datasets.py:22-27,141-146):
+    data_loader(args, phase, data_info) -> torch.utils.data.DataLoader
+yielding (color[B,3,S,S] f32, cam[B,J,3] f32, valid[B,J] bool[, back_rotate[B,3,3]]) (datasets.py:141-146).
+
+The real datasets need cv2 / cameralib crop re-projection and site files (out of scope).
+With `-synthetic N` the loader serves N deterministic synthetic batches per epoch (synth.make_batch rules),
+which is what the parity tests, smoke() and bench.py use.
+"""
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from . import synth
+
+
+def data_loader(args, phase, data_info):
+    dataset = Dataset(args, phase, data_info)
+    return data.DataLoader(dataset, args.batch_size, shuffle=(args.shuffle and phase == 'train'), num_workers=args.workers,
+                           pin_memory=True)
+
+
+class Dataset(data.Dataset):
+
+    def __init__(self, args, phase, data_info):
+        assert phase in ('train', 'valid', 'test')
+        if not getattr(args, 'synthetic', 0):
+            raise NotImplementedError('only -synthetic N data is available: the dataset readers (cv2 + cameralib crop '
+                                      're-projection, depth_datasets.py:153-237) are outside the hot-path scope')
+        self.phase = phase
+        self.side_in = args.side_in
+        self.num_joints = args.num_joints
+        self.count = args.synthetic * args.batch_size
+        self.at_test = phase != 'train'
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, index):
+        color, depth, cam, val = synth.make_batch(1, side=self.side_in, num_joints=self.num_joints, rank=0, step=index)
+        items = [torch.from_numpy(color[0]), torch.from_numpy(cam[0]), torch.from_numpy(val[0])]
+        if self.at_test:
+            items.append(torch.eye(3))
+        return tuple(items)

@@ -1,0 +1,63 @@
+"""Entry point with the reference's factories (depth_main.py:14-164):
+    get_info() -> JointInfo          create_model(args) -> (model, state)          main()
+Run as  python -m "3d-pose-estimation-with-previleged-information_amd.depth_main" -model resnet50 ... -synthetic 10
+(single GPU) or under torchrun for one process per GPU (replaces nn.DataParallel / -n_cudas, depth_main.py:72).
+"""
+import importlib
+import os
+
+import torch
+
+from . import depth_train, dist as p3d_dist
+from .utils import get_info   # noqa: F401  (depth_main.get_info, depth_main.py:14-33)
+
+
+def create_model(args):
+    """depth_main.py:36-74: pick {partial_}{depth|fusion}net by flags, build args.model, optionally resume."""
+    name = ('partial_' if args.partial_conv else '') + ('fusion' if args.do_fusion else 'depth') + 'net'
+    module = importlib.import_module('.' + name, package=__package__)
+    assert hasattr(module, args.model)
+    model = getattr(module, args.model)(args, args.pretrain)
+    state = None
+    if args.test_only or args.val_only:
+        save_path = os.path.join(args.save_path, args.model + '-' + args.suffix)
+        assert os.path.exists(save_path)
+        checkpoint = os.path.join(save_path, 'model_{}.pth'.format(args.n_epochs))
+        print('=> Loads checkpoint from ' + checkpoint)
+        checkpoint = torch.load(checkpoint, map_location='cpu')['model']
+        assert len(set(model.state_dict().keys()).difference(set(checkpoint.keys()))) == 0     # depth_main.py:57-60
+        model.load_state_dict(checkpoint)
+    if args.resume:
+        print('=> Loads checkpoint from ' + args.model_path)
+        checkpoint = torch.load(args.model_path, map_location='cpu')
+        model.load_state_dict(checkpoint['model'])
+        state = checkpoint['state']
+    return model, state
+
+
+def main(argv=None):
+    from . import opts
+    args = opts.parse(argv)
+    assert not (args.do_teach and args.do_fusion and args.depth_only)
+    rank, world, local_rank = p3d_dist.init_from_env()
+    torch.cuda.set_device(local_rank)
+    model, state = create_model(args)
+    model = model.cuda()
+    data_info = get_info()
+    loader_mod = importlib.import_module('.depth_datasets', package=__package__)
+    train_loader = loader_mod.data_loader(args, 'train', data_info)
+    trainer = depth_train.Trainer(args, model, data_info)
+    trainer.verbose = rank == 0
+    start = state['epoch'] + 1 if state else 1
+    for epoch in range(start, args.n_epochs + 1):
+        record = trainer.train(epoch, train_loader)
+        if rank == 0 and args.save_record:
+            save_dir = os.path.join(args.save_path, args.model + '-' + args.suffix)
+            os.makedirs(save_dir, exist_ok=True)
+            torch.save(dict(state=dict(epoch=epoch), model=model.state_dict()), os.path.join(save_dir, 'model_%d.pth' % epoch))   # log.py:32-40
+        if rank == 0:
+            print(record)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,177 @@
+"""Training driver with the reference's Trainer interface (depth_train.py:40-691), on the HIP hot path.
+
+    Trainer(args, model, data_info)
+    .train(epoch, loader) -> dict(cam_train_loss=...)      vanilla_train / fusion_train  (depth_train.py:376-462, 286-373)
+    .adapt_learn_rate(epoch)                                (depth_train.py:621-638)
+    .vanilla_infer / .fusion_infer                          (depth_train.py:650-679)
+
+One step = forward (conv/BN/pool kernels) -> fused soft-argmax head -> fused loss (value + gradient) ->
+backward -> [RCCL all-reduce of the flat gradient, overlapped] -> global-norm clip + Adam (2 launches).
+Differences from the reference, all documented in DESIGN.md: one process per GPU instead of
+nn.DataParallel; `-half_acc`, distillation (`-do_teach`) and the evaluation path are "next" rows of the scope
+table and raise NotImplementedError; metadata.json is optional (only `no_depth` / `thresholds` are read).
+"""
+import json
+import os
+
+import torch
+
+from . import dist as p3d_dist
+from . import ops, utils
+from .optim import FlatAdam
+
+root_me = os.path.join(os.sep, 'globalwork', 'liu')      # depth_train.py:12; override with -metadata / $P3D_METADATA
+
+
+def _load_metadata(args):
+    path = getattr(args, 'metadata', None) or os.environ.get('P3D_METADATA') or os.path.join(root_me, 'metadata.json')
+    if os.path.exists(path):
+        with open(path) as file:
+            return json.load(file)
+    return None
+
+
+def wrap_by_name(names, params):
+    """depth_train.py:22-25 (the two groups get identical hyper-parameters; kept for interface parity)."""
+    group_a = [param for name, param in zip(names, params) if 'bn' in name]
+    group_b = [param for name, param in zip(names, params) if 'bn' not in name]
+    return [dict(params=group_a), dict(params=group_b)]
+
+
+class Trainer:
+
+    def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
+        if args.half_acc:
+            raise NotImplementedError('-half_acc (fp16 master-copy path, depth_train.py:73-83,413-449) is a "next" row; fp32 is the parity path')
+        if args.do_teach or args.semi_teach:
+            raise NotImplementedError('distillation (-do_teach / -semi_teach, depth_train.py:161-283) is a "next" row')
+        self.model = model
+        self.data_info = data_info
+        self.list_names = [name for name, param in model.named_parameters()]
+        self.list_params = [param for name, param in model.named_parameters()]
+
+        self.half_acc = False
+        self.depth_only = args.depth_only
+        self.do_fusion = args.do_fusion
+        self.do_teach = False
+
+        metadata = _load_metadata(args)
+        self.no_depth = metadata['no_depth'][args.data_name] if metadata else False
+        self.thresh = metadata['thresholds'][args.data_name] if metadata else None
+
+        self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
+        self.reducer = p3d_dist.GradReducer(self.optimizer, reducer_bucket_bytes)
+        self.world = self.reducer.world
+
+        self.depth = args.depth
+        self.num_joints = args.num_joints
+        self.side_in = args.side_in
+        self.stride = args.stride
+        self.depth_range = args.depth_range
+        self.warmup = args.warmup
+        self.learn_rate = args.learn_rate
+        self.learn_decay = args.learn_decay
+        self.num_epochs = args.n_epochs
+        self.warmup_factor = args.warmup_factor
+        self.grad_norm = args.grad_norm
+        self.loss_div = args.loss_div
+        self.criterion = args.criterion                     # name; the loss kernel implements SmoothL1 / L1 / MSE
+        if self.criterion not in ops.CRITERIA:
+            raise ValueError('criterion %r is not one of %s' % (self.criterion, sorted(ops.CRITERIA)))
+        self.verbose = True
+        self.sync_every = 1                                 # read the loss back every k iterations (reference: every one)
+        self.last_spec_cam = None
+
+    # ---- schedules ---------------------------------------------------------------------------
+    def adapt_learn_rate(self, epoch):
+        if epoch - 1 < self.warmup:
+            learn_rate = self.learn_rate * self.warmup_factor
+        elif epoch - 1 < 15:
+            learn_rate = self.learn_rate
+        elif epoch - 1 < 20:
+            learn_rate = self.learn_rate * self.learn_decay
+        elif epoch - 1 < 25:
+            learn_rate = self.learn_rate * self.learn_decay ** 2
+        else:
+            learn_rate = self.learn_rate * self.learn_decay ** 3
+        for group in self.optimizer.param_groups:
+            group['lr'] = learn_rate
+
+    # ---- forward helpers ---------------------------------------------------------------------
+    def to(self, image, device):
+        return image.to(device, non_blocking=True)
+
+    def vanilla_infer(self, in_image, i_batch=0, ret_last=False):
+        cam_feat, last_feat = self.model(in_image)
+        return (cam_feat, last_feat) if ret_last else cam_feat
+
+    def fusion_infer(self, color_image, depth_image, i_batch=0, ret_last=False):
+        cam_feat, last_feat = self.model(color_image, depth_image)
+        return (cam_feat, last_feat) if ret_last else cam_feat
+
+    # ---- the hot loop --------------------------------------------------------------------------
+    def train_step(self, color_image, depth_image, true_cam, true_val):
+        """One optimisation step on device tensors; returns the loss as a 0-d device tensor (no host sync)."""
+        side_out = (self.side_in - 1) // self.stride + 1
+        if self.do_fusion:
+            cam_feat = self.fusion_infer(color_image, depth_image)
+        else:
+            cam_feat = self.vanilla_infer(depth_image if self.depth_only else color_image)
+        heat_cam = utils.to_heatmap(cam_feat, self.depth, self.num_joints, side_out, side_out)
+        relat_cam = utils.decode(heat_cam, self.depth_range)
+        # mean over the valid joints of the GLOBAL batch: per-rank divisor = 3 * global count / world (device side)
+        count = p3d_dist.global_valid_divisor(true_val) if self.world > 1 else None
+        loss, spec_cam = ops.pose_loss(relat_cam, true_cam, true_val, self.data_info.key_index, self.loss_div,
+                                       self.criterion, count_override=count)
+        self.last_spec_cam = spec_cam
+        self.optimizer.zero_grad()
+        loss.backward()
+        scale = self.reducer.finish()
+        self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
+        return loss.detach()
+
+    def _run_epoch(self, epoch, data_loader, device):
+        n_batches = len(data_loader)
+        loss_avg = 0.0
+        total = 0
+        pending = []
+        for i_batch, (color_image, depth_image, true_cam, true_val) in enumerate(data_loader):
+            color_image = self.to(color_image, device) if (self.do_fusion or not self.depth_only) else None
+            depth_image = self.to(depth_image, device) if (self.do_fusion or self.depth_only) else None
+            true_cam = true_cam.to(device, non_blocking=True)
+            true_val = true_val.to(device, non_blocking=True)
+            batch = true_cam.size(0)
+            loss = self.train_step(color_image, depth_image, true_cam, true_val)
+            pending.append((i_batch, batch, loss))
+            if len(pending) >= self.sync_every or i_batch == n_batches - 1:
+                for ib, b, l in pending:
+                    value = l.item()
+                    if self.verbose:
+                        print('| train Epoch[%d] [%d/%d]  Loss %1.4f' % (epoch, ib, n_batches, value), flush=True)
+                    loss_avg += value * b
+                    total += b
+                pending = []
+        loss_avg /= max(total, 1)
+        if self.verbose:
+            print('\n=> train Epoch[%d]  Cam Loss: %1.4f\n' % (epoch, loss_avg))
+        return dict(cam_train_loss=loss_avg)
+
+    def vanilla_train(self, epoch, data_loader, device):
+        return self._run_epoch(epoch, data_loader, device)
+
+    def fusion_train(self, epoch, data_loader, device):
+        return self._run_epoch(epoch, data_loader, device)
+
+    def train(self, epoch, data_loader):
+        self.model.train()
+        self.adapt_learn_rate(epoch)
+        device = self.list_params[0].device
+        if self.do_fusion:
+            return self.fusion_train(epoch, data_loader, device)
+        return self.vanilla_train(epoch, data_loader, device)
+
+    def test(self, epoch, test_loader):
+        raise NotImplementedError('evaluation (vanilla_test / fusion_test, depth_train.py:477-607) is the first "next" row')
+
+    def set_teacher(self, teacher):
+        raise NotImplementedError('distillation is a "next" row')

@@ -1,0 +1,60 @@
+"""Layer modules with torch.nn's constructor signatures, parameter names and initialisers, whose
+forward runs the hand-written HIP kernels (ops.py) instead of ATen.
+
+They subclass the torch.nn classes only to inherit parameter/buffer registration, state_dict
+layout and `isinstance` behaviour (the reference's init loops and freeze_batchnorm test
+`isinstance(m, nn.Conv2d)` / `nn.BatchNorm2d`: depthnet.py:148-154,158-161).  No ATen compute
+kernel is reachable from their forward.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _one(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2 or v[0] != v[1]:
+            raise ops.P3DError('only square kernels / symmetric stride, padding, dilation are supported (got %r)' % (v,))
+        return int(v[0])
+    return int(v)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (groups = 1, zero padding)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or self.padding_mode != 'zeros' or isinstance(self.padding, str):
+            raise ops.P3DError('Conv2d: groups != 1 / non-zero padding modes are not on the hot path')
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation))
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d; forward(x, res=None, relu=False) fuses the residual add and the ReLU that the
+    reference applies right after it (depthnet.py:42-56,98-116)."""
+
+    def forward(self, x, res=None, relu=False):
+        if not (self.affine and self.track_running_stats):
+            raise ops.P3DError('BatchNorm2d: only affine=True, track_running_stats=True is on the hot path')
+        training = self.training
+        momentum = 0.1 if self.momentum is None else self.momentum
+        if training:
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training,
+                                  momentum, self.eps)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) -- the only geometry the reference uses."""
+
+    def forward(self, x):
+        if (_one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)) != (3, 2, 1, 1) or self.ceil_mode:
+            raise ops.P3DError('MaxPool2d: only kernel 3, stride 2, padding 1 is on the hot path')
+        return ops.maxpool3x3s2(x)
+
+
+class Sequential(nn.Sequential):
+    pass

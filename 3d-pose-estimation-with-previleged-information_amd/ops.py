@@ -1,0 +1,408 @@
+"""torch.autograd.Function wrappers over the C ABI (include/p3d_hip.h).
+
+Each Function replaces the torch operator the reference calls at the cited line; arithmetic
+happens only in the hand-written HIP kernels.  Tensors must be fp32 on a HIP device -- there is
+no CPU or eager-PyTorch fallback: anything else raises P3DError.
+"""
+import ctypes
+
+import torch
+
+from ._lib import ConvDesc, P3DError, check, lib
+
+CRITERIA = {'SmoothL1': 0, 'L1': 1, 'MSE': 2}
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise P3DError('p3d ops run only on a HIP device (got a %s tensor); there is no CPU fallback' % t.device)
+        if t.dtype != torch.float32:
+            raise P3DError('p3d ops are fp32 only (got %s)' % t.dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_workspaces = {}
+
+# When a list, every conv launch is bracketed by a pair of events on the launch stream and
+# (kind, algorithmic_flops, start, end) is appended: bench.py's live per-kernel timing.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, d):
+        self.kind = kind
+        self.flops = 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.R * d.S
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.end.record()
+            PROFILE.append((self.kind, self.flops, self.start, self.end))
+        return False
+
+
+
+def workspace(device, nbytes):
+    """Grow-only scratch buffer per device; ops on one stream are ordered, so it can be shared."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def conv_out(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _desc(x_shape, w_shape, stride, pad, dil, c_offset=0, c_total=None, accumulate=0):
+    n, c, h, w = x_shape
+    k, cw, r, s = w_shape
+    d = ConvDesc()
+    d.N, d.C, d.H, d.W = n, c, h, w
+    d.K, d.R, d.S = k, r, s
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.Ho, d.Wo = conv_out(h, r, stride, pad, dil), conv_out(w, s, stride, pad, dil)
+    d.c_total = cw if c_total is None else c_total
+    d.c_offset = c_offset
+    d.accumulate = accumulate
+    return d
+
+
+# --------------------------------------------------------------------------------------------
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (depthnet.py:16-33,65-89,138,156) and, with mask_in/mult, PartialConv's masked,
+    renormalised convolution (partial_conv.py:45-53)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mask_in, mult, stride, pad, dil):
+        _need_gpu(x, w, bias, mask_in, mult)
+        x, w = x.contiguous(), w.contiguous()
+        d = _desc(x.shape, w.shape, stride, pad, dil)
+        if x.shape[1] != w.shape[1]:
+            raise P3DError('conv2d: input has %d channels, weight expects %d' % (x.shape[1], w.shape[1]))
+        y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        with _Timed('fwd', d):
+            check(lib().p3d_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(mask_in), _p(mult), _p(y), _stream()), 'p3d_conv2d_fwd')
+        ctx.save_for_backward(x, w, mask_in, mult)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mask_in, mult = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        d = _desc(x.shape, w.shape, stride, pad, dil)
+        L = lib()
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with _Timed('dgrad', d):
+                check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), st), 'p3d_conv2d_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            nbytes = L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            ws = workspace(x.device, nbytes)
+            with _Timed('wgrad', d):
+                check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(d.K, dtype=torch.float32, device=x.device)
+            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), st), 'p3d_conv2d_bgrad')
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, mask_in=None, mult=None):
+    return Conv2dFn.apply(x, w, bias, mask_in, mult, stride, pad, dil)
+
+
+class ConvCat1x1Fn(torch.autograd.Function):
+    """conv(cat([x, y], 1), w) without materialising the concat (fusionnet.py:138-139):
+    two passes over disjoint input-channel windows of w, the second accumulating."""
+
+    @staticmethod
+    def forward(ctx, x, y, w):
+        _need_gpu(x, y, w)
+        x, y, w = x.contiguous(), y.contiguous(), w.contiguous()
+        c1, c2 = x.shape[1], y.shape[1]
+        if w.shape[1] != c1 + c2 or x.shape[0] != y.shape[0] or x.shape[2:] != y.shape[2:]:
+            raise P3DError('conv_cat: shapes %s %s do not match weight %s' % (tuple(x.shape), tuple(y.shape), tuple(w.shape)))
+        L, st = lib(), _stream()
+        d1 = _desc(x.shape, w.shape, 1, 0, 1, c_offset=0, c_total=c1 + c2)
+        d2 = _desc(y.shape, w.shape, 1, 0, 1, c_offset=c1, c_total=c1 + c2, accumulate=1)
+        out = torch.empty((d1.N, d1.K, d1.Ho, d1.Wo), dtype=torch.float32, device=x.device)
+        check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
+        check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
+        ctx.save_for_backward(x, y, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        c1, c2 = x.shape[1], y.shape[1]
+        L, st = lib(), _stream()
+        d1 = _desc(x.shape, w.shape, 1, 0, 1, c_offset=0, c_total=c1 + c2)
+        d2 = _desc(y.shape, w.shape, 1, 0, 1, c_offset=c1, c_total=c1 + c2)
+        dx = dyy = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d1), _p(dy), _p(w), None, None, _p(dx), st), 'p3d_conv2d_dgrad')
+        if ctx.needs_input_grad[1]:
+            dyy = torch.empty_like(y)
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), st), 'p3d_conv2d_dgrad')
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            for d, inp in ((d1, x), (d2, y)):
+                ws = workspace(x.device, L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+                check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(inp), None, None, _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
+        return dx, dyy, dw
+
+
+def conv_cat1x1(x, y, w):
+    return ConvCat1x1Fn.apply(x, y, w)
+
+
+def mask_count(mask, kernel, stride, pad, dil):
+    """partial_conv.py:35-43 (no_grad): mask [N,1,H,W] -> (mult, mask_out) [N,1,Ho,Wo]."""
+    _need_gpu(mask)
+    mask = mask.contiguous()
+    n, one, h, w = mask.shape
+    d = _desc((n, 1, h, w), (1, 1, kernel, kernel), stride, pad, dil)
+    mult = torch.empty((n, 1, d.Ho, d.Wo), dtype=torch.float32, device=mask.device)
+    mask_out = torch.empty_like(mult)
+    check(lib().p3d_mask_count_fwd(ctypes.byref(d), _p(mask), _p(mult), _p(mask_out), _stream()), 'p3d_mask_count_fwd')
+    return mult, mask_out
+
+
+def nonzero_mask(x):
+    """(x != 0).float()  (partial_depthnet.py:215)"""
+    _need_gpu(x)
+    x = x.contiguous()
+    m = torch.empty_like(x)
+    check(lib().p3d_nonzero_mask(_p(x), _p(m), x.numel(), _stream()), 'p3d_nonzero_mask')
+    return m
+
+
+# --------------------------------------------------------------------------------------------
+class BatchNormActFn(torch.autograd.Function):
+    """act(bn(x) + res): nn.BatchNorm2d + optional residual add + optional F.relu
+    (depthnet.py:42-56,98-116).  running_mean/running_var are updated in place in training."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps):
+        _need_gpu(x, gamma, beta, running_mean, running_var, res)
+        x = x.contiguous()
+        res = None if res is None else res.contiguous()
+        n, c, h, w = x.shape
+        L, st = lib(), _stream()
+        y = torch.empty_like(x)
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
+            check(L.p3d_bn_train_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
+                                     n, c, h * w, momentum, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_train_fwd')
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        else:
+            check(L.p3d_bn_eval_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y),
+                                    n, c, h * w, eps, int(relu), st), 'p3d_bn_eval_fwd')
+            ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var)
+        ctx.cfg = (bool(relu), bool(training), eps, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, s1, s2 = ctx.saved_tensors
+        relu, training, eps, has_res = ctx.cfg
+        dy = dy.contiguous()
+        n, c, h, w = x.shape
+        L, st = lib(), _stream()
+        dx = torch.empty_like(x)
+        dres = None
+        if has_res and ctx.needs_input_grad[5]:
+            dres = torch.empty_like(x) if relu else dy      # without ReLU the residual gradient is dy itself
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
+        dres_ptr = _p(dres) if (dres is not None and relu) else None
+        if training:
+            check(L.p3d_bn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
+                                     n, c, h * w, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_train_bwd')
+        else:
+            check(L.p3d_bn_eval_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
+                                    n, c, h * w, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_eval_bwd')
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
+    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps)
+
+
+class ReluFn(torch.autograd.Function):
+    """standalone F.relu (depthnet.py:197-198 skip_relu variants)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().p3d_relu_fwd(_p(x), _p(y), x.numel(), _stream()), 'p3d_relu_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().p3d_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), 'p3d_relu_bwd')
+        return dx
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+class MaxPool3x3S2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (depthnet.py:140,192)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        ho, wo = conv_out(h, 3, 2, 1, 1), conv_out(w, 3, 2, 1, 1)
+        y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+        need_idx = ctx.needs_input_grad[0]
+        idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=x.device) if need_idx else None
+        check(lib().p3d_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n * c, h, w, _stream()), 'p3d_maxpool3x3s2_fwd')
+        ctx.save_for_backward(idx)
+        ctx.in_shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.in_shape
+        dy = dy.contiguous()
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+        check(lib().p3d_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n * c, h, w, _stream()), 'p3d_maxpool3x3s2_bwd')
+        return dx
+
+
+def maxpool3x3s2(x):
+    return MaxPool3x3S2Fn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+class SoftArgmax3dFn(torch.autograd.Function):
+    """utils.to_heatmap followed by utils.decode (utils.py:154-194), fused."""
+
+    @staticmethod
+    def forward(ctx, z, depth, num_joints, height, width, depth_range):
+        _need_gpu(z)
+        z = z.contiguous()
+        b = z.shape[0]
+        if tuple(z.shape[1:]) != (depth * num_joints, height, width):
+            raise P3DError('softargmax3d: z %s is not [B, %d*%d, %d, %d]' % (tuple(z.shape), depth, num_joints, height, width))
+        coords = torch.empty((b, num_joints, 3), dtype=torch.float32, device=z.device)
+        check(lib().p3d_softargmax3d_fwd(_p(z), _p(coords), b, depth, num_joints, height, width, depth_range, _stream()), 'p3d_softargmax3d_fwd')
+        ctx.save_for_backward(z)
+        ctx.cfg = (depth, num_joints, height, width, depth_range)
+        return coords
+
+    @staticmethod
+    def backward(ctx, dcoords):
+        (z,) = ctx.saved_tensors
+        depth, num_joints, height, width, depth_range = ctx.cfg
+        dcoords = dcoords.contiguous()
+        dz = torch.empty_like(z)
+        check(lib().p3d_softargmax3d_bwd(_p(dcoords), _p(z), _p(dz), z.shape[0], depth, num_joints, height, width, depth_range, _stream()),
+              'p3d_softargmax3d_bwd')
+        return dz, None, None, None, None, None
+
+
+def softargmax3d(z, depth, num_joints, height, width, depth_range):
+    return SoftArgmax3dFn.apply(z, depth, num_joints, height, width, float(depth_range))
+
+
+class PoseLossFn(torch.autograd.Function):
+    """Loss block of Trainer.vanilla_train (depth_train.py:397-405): returns (loss, spec_cam)."""
+
+    @staticmethod
+    def forward(ctx, relat, true_cam, true_val, key_index, loss_div, criterion, count_override):
+        _need_gpu(relat, true_cam)
+        relat, true_cam = relat.contiguous(), true_cam.contiguous()
+        if not true_val.is_cuda:
+            raise P3DError('pose_loss: true_val must be on the HIP device')
+        val = true_val.contiguous().view(torch.uint8) if true_val.dtype == torch.bool else true_val.contiguous()
+        if val.dtype != torch.uint8:
+            raise P3DError('pose_loss: true_val must be bool or uint8')
+        b, j, _ = relat.shape
+        loss = torch.empty(1, dtype=torch.float32, device=relat.device)
+        spec = torch.empty_like(relat)
+        drelat = torch.empty_like(relat)
+        check(lib().p3d_pose_loss_fwd_bwd(_p(relat), _p(true_cam), _p(val), _p(loss), _p(spec), _p(drelat), b, j, key_index,
+                                          loss_div, CRITERIA[criterion], 1.0, _p(count_override), _stream()), 'p3d_pose_loss_fwd_bwd')
+        ctx.save_for_backward(drelat)
+        ctx.mark_non_differentiable(spec)
+        return loss.view(()), spec
+
+    @staticmethod
+    def backward(ctx, dloss, dspec):
+        (drelat,) = ctx.saved_tensors
+        return drelat * dloss, None, None, None, None, None, None
+
+
+def pose_loss(relat, true_cam, true_val, key_index, loss_div, criterion='SmoothL1', count_override=None):
+    """count_override: optional 1-element fp32 device tensor replacing 3*n_valid as the mean's divisor."""
+    return PoseLossFn.apply(relat, true_cam, true_val, int(key_index), float(loss_div), criterion, count_override)
+
+
+# --------------------------------------------------------------------------------------------
+def l2norm_sq_accum(flat, accum):
+    check(lib().p3d_l2norm_sq_accum(_p(flat), flat.numel(), _p(accum), _stream()), 'p3d_l2norm_sq_accum')
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, norm_sq=None, grad_scale=1.0):
+    check(lib().p3d_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step), float(max_norm),
+                              _p(norm_sq), float(grad_scale), _stream()), 'p3d_adam_step')
+
+
+def augment_colour_(img, params):
+    """In place on img [B,3,H,W] holding 0..255 values; params [B,4] (augment_colour.py:48-67)."""
+    _need_gpu(img, params)
+    b, c, h, w = img.shape
+    if c != 3 or not img.is_contiguous():
+        raise P3DError('augment_colour: need a contiguous [B,3,H,W] image')
+    check(lib().p3d_augment_colour(_p(img), _p(params.contiguous()), b, h, w, _stream()), 'p3d_augment_colour')
+    return img
+
+
+def augment_erase_(img, rects, colour):
+    """In place: fill rects [B,4] int32 (x0,y0,x1,y1) with colour [B,C] (augment_occluder.py:84-105)."""
+    _need_gpu(img, colour)
+    b, c, h, w = img.shape
+    if rects.dtype != torch.int32 or not img.is_contiguous():
+        raise P3DError('augment_erase: rects must be int32 and img contiguous')
+    check(lib().p3d_augment_erase(_p(img), _p(rects.contiguous()), _p(colour.contiguous()), b, c, h, w, _stream()), 'p3d_augment_erase')
+    return img

@@ -1,0 +1,90 @@
+"""FlatAdam: nn.utils.clip_grad_norm_ + optim.Adam(weight_decay) of the reference trainer
+(depth_train.py:83,455-456) as two kernel launches over flat HBM buffers.
+
+All parameters are re-homed into ONE contiguous fp32 buffer (each tensor a view at a 16-B aligned
+offset), and so are their gradients and the Adam moments.  Consequences:
+  * the global L2 norm is one streaming reduction and the update one streaming kernel (28 B/param),
+    instead of 161 tensors x ~10 ATen launches for ResNet-50;
+  * the clip coefficient is consumed on the device (no .item() between norm and step);
+  * the gradient buffer is what the RCCL all-reduce sends, bucket by bucket, with no packing copy.
+The reference's two param groups carry identical hyper-parameters (wrap_by_name, depth_train.py:22-25,
+weight decay on BN and bias included), so one flat group reproduces it; `param_groups` keeps two dicts
+because adapt_learn_rate writes both (depth_train.py:637-638).
+"""
+import torch
+
+from . import ops
+
+ALIGN = 4   # floats (16 B)
+
+
+def plan_layout(numels, align=ALIGN):
+    """Offsets of each tensor in the flat buffer and the padded total (pure host logic)."""
+    offsets, total = [], 0
+    for n in numels:
+        offsets.append(total)
+        total += (n + align - 1) // align * align
+    return offsets, total
+
+
+class FlatAdam:
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        named_params = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named_params:
+            raise ValueError('FlatAdam: no trainable parameter')
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        device = self.params[0].device
+        if any(p.device != device or p.dtype != torch.float32 for p in self.params):
+            raise ValueError('FlatAdam: parameters must all be fp32 on one device')
+        self.offsets, self.total = plan_layout([p.numel() for p in self.params])
+        self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat_p[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.param_groups = [dict(lr=lr), dict(lr=lr)]
+        self.step_count = 0
+        self.norm_sq = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def slices(self):
+        """(name, offset, numel) per parameter, in registration order."""
+        return [(n, off, p.numel()) for n, p, off in zip(self.names, self.params, self.offsets)]
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, off in zip(self.params, self.offsets):        # re-attach if someone dropped a .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+
+    def clip_and_step(self, max_norm, grad_scale=1.0):
+        """clip_grad_norm_(params, max_norm) followed by Adam.step(); grad_scale (1/world_size) is applied first."""
+        self.norm_sq.zero_()
+        if max_norm and max_norm > 0:
+            ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
+        self.step_count += 1
+        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay, self.step_count, max_norm or 0.0,
+                      self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
+
+    def step(self):
+        self.clip_and_step(0.0)
+
+    def total_norm(self, grad_scale=1.0):
+        """Host value of the last global gradient norm (synchronises; for logging/tests only)."""
+        return float(self.norm_sq.item()) ** 0.5 * grad_scale
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names, offsets=self.offsets)
+
+    def load_state_dict(self, state):
+        self.step_count = int(state['step'])
+        self.exp_avg.copy_(state['exp_avg'])
+        self.exp_avg_sq.copy_(state['exp_avg_sq'])

@@ -1,0 +1,35 @@
+"""PartialConv: mask-renormalised convolution (reference partial_conv.py:6-57), on the HIP kernels.
+
+Same constructor and call contract as the reference class: PartialConv(*conv2d_args, multi_channel=False,
+return_mask=True); forward(input, mask_in) -> (output, mask_out).  Only multi_channel=False (a 1-channel
+mask, slide_winsize = kh*kw) exists on the hot path.  The reference does three extra passes per conv
+(a 1-channel box-sum conv, `input*mask`, `raw*multiplier`); here the mask multiply rides in the conv's
+operand gather and the renormalisation in its epilogue, so only the tiny box-sum kernel remains.
+"""
+import torch
+
+from . import ops
+from .nn import Conv2d, _one
+
+
+class PartialConv(Conv2d):
+
+    def __init__(self, *args, **kwargs):
+        self.multi_channel = kwargs.pop('multi_channel', False)
+        self.return_mask = kwargs.pop('return_mask', True)
+        if self.multi_channel:
+            raise ops.P3DError('PartialConv(multi_channel=True) is not used by the reference networks and not implemented')
+        super().__init__(*args, **kwargs)
+        self.slide_winsize = self.kernel_size[0] * self.kernel_size[1]      # partial_conv.py:28
+
+    def forward(self, input, mask_in):
+        assert len(input.shape) == 4                                          # partial_conv.py:33
+        k, stride, pad, dil = _one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)
+        with torch.no_grad():
+            mult, mask_out = ops.mask_count(mask_in, k, stride, pad, dil)    # partial_conv.py:35-43
+        if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled():
+            raise ops.P3DError('PartialConv with a trainable bias: backward is not implemented (no reference network uses it)')
+        output = ops.conv2d(input, self.weight, self.bias, stride, pad, dil, mask_in=mask_in, mult=mult)
+        if self.return_mask:
+            return output, mask_out
+        return output

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- crops/sec of the full training step of the hot path on N MI355X GPUs of one node.
+
+Workload (BASELINE.json configs[1], the one the metric is quoted on): depthnet ResNet-50 RGB pose head,
+synthetic 256x256x3 crops, batch 64 per GPU, fp32: forward -> soft-argmax head -> SmoothL1 -> backward ->
+[RCCL gradient all-reduce, overlapped] -> global-norm clip -> Adam.  Inputs are resident in HBM before the
+timed region.  One process per GPU; for N > 1 launch with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line (contract in the task statement; `roofline` and `cpu_baseline` described in DESIGN.md).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG_NAME = '3d-pose-estimation-with-previleged-information_amd'
+
+R50_FWD_BWD_GFLOP_PER_CROP = 56.03      # conv MACs*2, fwd + dgrad + wgrad (no stem dgrad)
+FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FLAGS = ['-suffix', 'bench', '-data_name', 'h36m', '-save_path', '/tmp/p3d_bench', '-criterion', 'SmoothL1', '-num_joints', '17',
+         '-side_in', '256', '-stride', '16', '-depth', '16', '-depth_range', '1000', '-loss_div', '10', '-learn_rate', '5e-5',
+         '-weight_decay', '4e-5', '-grad_norm', '5']
+
+
+def cpu_baseline(pkg, model_name, batch, steps):
+    """The oracle's PyTorch-CPU port of the same step, timed on this box's host cores (bounded sample)."""
+    import torch
+    from oracle.torch_port import TorchPort
+    torch.manual_seed(0)
+    args = pkg.opts.parse(['-model', model_name] + FLAGS)
+    shapes = {k: tuple(v.shape) for k, v in pkg.depth_main.create_model(args)[0].state_dict().items()}
+    port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family='depthnet', model=model_name)
+    cores = torch.get_num_threads()
+    batches = [pkg.synth.make_batch(batch, side=256, rank=0, step=i) for i in range(2)]
+    port.train_step(*batches[0], lr=1e-5)                          # warm-up
+    t0 = time.perf_counter()
+    for i in range(steps):
+        port.train_step(*batches[i % 2], lr=1e-5)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit='crops/s', cores=cores, kind='port',
+                sample='%s 256x256 bs=%d, %d timed steps after 1 warm-up (oracle/torch_port.py, fp32)' % (model_name, batch, steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='crops per GPU')
+    ap.add_argument('--model', default='resnet50')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    opt = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module(PKG_NAME)
+    ops = pkg.ops
+    rank, world, local_rank = pkg.dist.init_from_env()
+    if world != opt.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 under torch.distributed.run)' % (opt.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    args = pkg.opts.parse(['-model', opt.model] + FLAGS)
+    torch.manual_seed(0)                                  # identical random-init weights on every rank
+    model, _ = pkg.depth_main.create_model(args)
+    model = model.to(device).train()
+    trainer = pkg.depth_train.Trainer(args, model, pkg.utils.get_info())
+    trainer.verbose = False
+    trainer.adapt_learn_rate(1)
+
+    nbuf = 3
+    batches = []
+    for i in range(nbuf):
+        c, d, tc, tv = pkg.synth.make_batch(opt.batch, side=256, rank=rank, step=i)
+        batches.append((torch.from_numpy(c).to(device), None, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(opt.warmup):
+        trainer.train_step(*batches[i % nbuf])
+    sync()
+    ops.PROFILE = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for i in range(opt.steps):
+        loss = trainer.train_step(*batches[i % nbuf])
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_value = float(loss)
+
+    if rank == 0:
+        crops = opt.batch * world * opt.steps
+        value = crops / elapsed
+        conv_ms = {}
+        conv_flops = 0.0
+        for kind, flops, start, end in prof:
+            conv_ms[kind] = conv_ms.get(kind, 0.0) + start.elapsed_time(end)
+            conv_flops += flops
+        conv_total_ms = sum(conv_ms.values())
+        launches = len(prof)
+        gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if opt.model == 'resnet50' else conv_flops / 1e9 / (opt.batch * opt.steps)
+        achieved = gflop_crop * opt.batch * opt.steps / conv_total_ms          # GFLOP/ms == TFLOP/s
+        out = {
+            'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
+            'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
+            'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'depthnet %s RGB pose head, 256x256x3 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
+                                   'RCCL grad all-reduce + clip + Adam' % (opt.model, opt.batch),
+                       'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
+            'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
+                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'launches_per_step': launches // max(opt.steps, 1),
+                         'avg_launch_ms': round(conv_total_ms / max(launches, 1), 4),
+                         'conv_ms_per_step': {k: round(v / opt.steps, 3) for k, v in conv_ms.items()},
+                         'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1)},
+        }
+        if world == 1 and not opt.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

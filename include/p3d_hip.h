@@ -1,0 +1,168 @@
+/*
+ * libp3d_hip.so -- C ABI of the MI355X (gfx950) hot path of
+ * 3D-Pose-Estimation-with-Previleged-Information.
+ *
+ * The reference has no FFI of its own: its hot path is eager PyTorch modules.  Each entry
+ * point below replaces the torch operator call(s) named in its comment (reference file:line);
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, NCHW, contiguous, in device (HBM) memory, owned by the caller
+ *   - no hidden allocation, no hidden synchronisation: scratch comes in through `workspace`,
+ *     sized by the matching *_workspace_bytes() query; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*, NULL = default stream)
+ *   - return 0 on success, a negative P3D_E* code on error; p3d_last_error() gives the text
+ *     (thread local).  Nothing throws across the boundary.
+ *   - thread safe for distinct streams.
+ */
+#ifndef P3D_HIP_H
+#define P3D_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_OK 0
+#define P3D_EINVAL (-1)      /* bad shape / null pointer / unsupported argument */
+#define P3D_EWORKSPACE (-2)  /* workspace missing or too small */
+#define P3D_ELAUNCH (-3)     /* HIP reported a launch error */
+
+#define P3D_VERSION 100
+
+int32_t p3d_version(void);
+const char* p3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution: nn.Conv2d forward / input gradient / weight gradient
+ *   depthnet.py:16-33,65-89,138,156,167-173  resnet.py:142,160-172  fusionnet.py:135,164-165
+ * and, through the optional mask pointers, partial_conv.PartialConv (partial_conv.py:32-57).
+ *
+ * x [N,C,H,W], w [K,c_total,R,S] of which this call uses input channels [c_offset, c_offset+C)
+ * (c_total == C, c_offset == 0 for an ordinary conv; the fusion 1x1 conv over cat([x,y]) is two
+ * calls, one per stream, the second with accumulate = 1: fusionnet.py:138-139), y [N,K,Ho,Wo].
+ * Ho = (H + 2*pad - dil*(R-1) - 1)/stride + 1, same for Wo; the library re-derives and checks.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct p3d_conv_desc {
+    int32_t N, C, H, W;
+    int32_t K, R, S;
+    int32_t stride, pad, dil;
+    int32_t Ho, Wo;
+    int32_t c_total, c_offset;
+    int32_t accumulate;   /* fwd: y += result; dgrad: dx += result; wgrad: dw += result */
+    int32_t reserved;
+} p3d_conv_desc;
+
+/* y = conv(x * mask_in) * mult + bias.  bias [K] or NULL.  mask_in [N,1,H,W] or NULL (prologue,
+ * partial_conv.py:45).  mult [N,1,Ho,Wo] or NULL (epilogue, partial_conv.py:53).  With both bias and
+ * mult the result is ((raw-b)*mult + b)*mask_out with mask_out = (mult > 0)  (partial_conv.py:48-51). */
+int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
+                       const float* mask_in, const float* mult, float* y, void* stream);
+
+/* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x). */
+int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
+                         const float* mask_in, float* dx, void* stream);
+
+/* dw[:, c_offset:c_offset+C] = wgrad(dy * mult, x * mask_in); deterministic two-stage split-K
+ * reduction through `workspace`. */
+size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
+int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x, const float* mult,
+                         const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* db[k] = sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
+int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, void* stream);
+
+/* partial_conv.py:35-43: cnt = boxsum(mask); mult = R*S/(cnt+1e-6)*clamp(cnt,0,1); mask_out = clamp(cnt,0,1).
+ * mask [N,1,H,W] -> mult, mask_out [N,1,Ho,Wo]. */
+int32_t p3d_mask_count_fwd(const p3d_conv_desc* d, const float* mask, float* mult, float* mask_out, void* stream);
+
+/* veil = (x != 0).float()  (partial_depthnet.py:215) */
+int32_t p3d_nonzero_mask(const float* x, float* mask, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ fused residual add and ReLU): nn.BatchNorm2d, F.relu, out + res
+ *   depthnet.py:42-56,98-116,139,189-190  fusionnet.py:140
+ * train:  y = act( (x-mean)*invstd*gamma + beta + res ), batch statistics (biased var for the
+ *         normalisation, unbiased for running_var, momentum 0.1 by default, eps 1e-5)
+ * res may be NULL; relu in {0,1}.  save_mean / save_invstd [C] are outputs kept for backward.
+ * running_mean / running_var may be NULL (no update).
+ * ------------------------------------------------------------------------------------------ */
+size_t p3d_bn_workspace_bytes(int32_t N, int32_t C, int32_t HW);
+int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd,
+                         int32_t N, int32_t C, int32_t HW, float momentum, float eps, int32_t relu,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the above.  y is the forward output (its sign is the ReLU mask; ignored when relu == 0).
+ * dres (may be NULL) receives the gradient of the residual input = masked dy. */
+int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                         const float* save_mean, const float* save_invstd, float* dx, float* dres,
+                         float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* eval / frozen statistics (model.eval() depth_train.py:611; freeze_batchnorm depthnet.py:158-161) */
+int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                        const float* running_mean, const float* running_var, float* y,
+                        int32_t N, int32_t C, int32_t HW, float eps, int32_t relu, void* stream);
+int32_t p3d_bn_eval_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                        const float* running_mean, const float* running_var, float* dx, float* dres,
+                        float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, float eps, int32_t relu,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* standalone F.relu (skip_relu variants, depthnet.py:197-198) */
+int32_t p3d_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int32_t p3d_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  depthnet.py:140,192; partial_depthnet.py:219-220
+ * x [NC,H,W] -> y [NC,Ho,Wo]; idx (uint8 tap 0..8 of the first maximum, may be NULL) feeds backward.
+ * ------------------------------------------------------------------------------------------ */
+int32_t p3d_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int32_t NC, int32_t H, int32_t W, void* stream);
+int32_t p3d_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t NC, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Volumetric soft-argmax head: utils.to_heatmap + utils.decode  (utils.py:154-194)
+ * z [B, D*J, H, W] (channel = d*J + j) -> coords [B, J, 3] = (x, y, z) * depth_range.
+ * ------------------------------------------------------------------------------------------ */
+int32_t p3d_softargmax3d_fwd(const float* z, float* coords, int32_t B, int32_t D, int32_t J, int32_t H, int32_t W,
+                             float depth_range, void* stream);
+int32_t p3d_softargmax3d_bwd(const float* dcoords, const float* z, float* dz, int32_t B, int32_t D, int32_t J,
+                             int32_t H, int32_t W, float depth_range, void* stream);
+
+/* Loss block of Trainer.vanilla_train (depth_train.py:397-405):
+ *   spec = relat - relat[:,key] + true_cam[:,key]
+ *   loss = criterion(spec[valid]/loss_div, true_cam[valid]/loss_div), reduction 'mean'
+ * criterion: 0 SmoothL1 (beta 1), 1 L1, 2 MSE.  true_val is uint8 [B,J].
+ * Outputs: loss[1], spec_cam [B,J,3], drelat [B,J,3] = loss_scale * dloss/drelat.
+ * count_override (device pointer to one float, may be NULL): when > 0 it replaces 3*n_valid as the divisor of the mean
+ * (global count / world_size under data parallelism, read on the device so no host sync is needed). */
+int32_t p3d_pose_loss_fwd_bwd(const float* relat, const float* true_cam, const uint8_t* true_val, float* loss,
+                              float* spec_cam, float* drelat, int32_t B, int32_t J, int32_t key_index,
+                              float loss_div, int32_t criterion, float loss_scale, const float* count_override, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.utils.clip_grad_norm_ + optim.Adam(weight_decay) on flat buffers (depth_train.py:455-456, :83)
+ * ------------------------------------------------------------------------------------------ */
+/* accum[0] (double) += sum(g[i]^2).  Caller zeroes accum before the first call of a step. */
+int32_t p3d_l2norm_sq_accum(const float* g, int64_t n, double* accum, void* stream);
+/* coef = min(max_norm / (sqrt(*norm_sq) * norm_scale + 1e-6), 1) * norm_scale is applied to g on the fly
+ * (norm_sq NULL or max_norm <= 0: coef = grad_scale only); then torch.optim.Adam's update with coupled L2
+ * weight decay.  step is the 1-based step count.  grad_scale multiplies g before anything else (1/world_size). */
+int32_t p3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int32_t step, float max_norm, const double* norm_sq,
+                      float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * On-GPU augmentation (config 5): augment_colour.random_color (augment_colour.py:48-67) and
+ * augment_occluder.random_erase (augment_occluder.py:84-105) on float images [B,3,H,W] in [0,1].
+ * params [B,4]: brightness delta, contrast factor, hue shift (deg), saturation factor.
+ * rects  [B,4] int32: x0, y0, x1, y1 (exclusive); colour [B,3].
+ * ------------------------------------------------------------------------------------------ */
+int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream);
+int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C,
+                          int32_t H, int32_t W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the numpy oracle and the golden vectors
+that came from the real reference.  Needs an MI355X: run with `-m gpu`."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_path
+from oracle import np_ops as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+CONV_CASES = [
+    # name,      N, C,  H,  W,  K, k, s, p, d, bias
+    ('1x1',      2, 64, 16, 16, 128, 1, 1, 0, 1, False),
+    ('1x1s2',    2, 48, 17, 15, 40, 1, 2, 0, 1, False),
+    ('3x3',      2, 32, 20, 20, 64, 3, 1, 1, 1, False),
+    ('3x3s2',    3, 24, 33, 31, 70, 3, 2, 1, 1, False),
+    ('3x3d2',    2, 16, 16, 16, 272, 3, 1, 2, 2, False),
+    ('3x3bias',  2, 40, 17, 17, 51, 3, 1, 1, 1, True),
+    ('7x7s2',    2, 3, 64, 64, 64, 7, 2, 3, 1, False),
+    ('7x7s2c1',  1, 1, 65, 63, 64, 7, 2, 3, 1, False),
+    ('5x5',      1, 5, 12, 13, 9, 5, 1, 2, 1, True),
+    ('big',      4, 256, 16, 16, 256, 3, 1, 1, 1, False),
+    ('wideN',    2, 16, 64, 64, 64, 3, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, pkg):
+    ops = pkg.ops
+    name, n, c, h, w, k, ks, st, pad, dil, bias = case
+    rng = np.random.default_rng(hash(name) % 2 ** 31)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((k, c, ks, ks)) / np.sqrt(c * ks * ks)).astype(np.float32)
+    b = rng.standard_normal(k).astype(np.float32) if bias else None
+    y_ref = ref.conv2d_fwd(x, wt, b, st, pad, dil)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    wtt = dev(wt).requires_grad_(True)
+    bt = dev(b).requires_grad_(True) if bias else None
+    y = ops.conv2d(xt, wtt, bt, st, pad, dil)
+    y.backward(dev(dy))
+    # fp32 MFMA is an exact fmaf chain: only the summation order differs from the float64 oracle
+    assert relerr(host(y), y_ref) < 5e-6
+    assert relerr(host(xt.grad), ref.conv2d_dgrad(dy, wt, x.shape, st, pad, dil)) < 5e-6
+    assert relerr(host(wtt.grad), ref.conv2d_wgrad(dy, x, wt.shape, st, pad, dil)) < 2e-5
+    if bias:
+        assert relerr(host(bt.grad), ref.conv2d_bgrad(dy)) < 5e-6
+
+
+def test_partial_conv_matches_reference_golden(pkg):
+    """PartialConv module vs vectors produced by the reference's own class (partial_conv.py:32-57)."""
+    g = np.load(golden_path('partial_conv.npz'))
+    for m in json.loads(str(g['meta'])):
+        n = m['name']
+        wt = g[n + '.w']
+        conv = pkg.partial_conv.PartialConv(wt.shape[1], wt.shape[0], kernel_size=m['k'], stride=m['stride'], padding=m['pad'],
+                                            dilation=m['dil'], bias=m['bias']).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(dev(wt))
+            if m['bias']:
+                conv.bias.copy_(dev(g[n + '.b']))
+                conv.bias.requires_grad_(False)
+        x = dev(g[n + '.x']).requires_grad_(True)
+        y, mo = conv(x, dev(g[n + '.mask']))
+        assert np.array_equal(host(mo), g[n + '.mask_out']), n
+        assert np.abs(host(y) - g[n + '.y']).max() < 1e-5 * max(np.abs(g[n + '.y']).max(), 1.0), n
+        if not m['bias']:
+            y.backward(dev(g[n + '.dy']))
+            assert np.abs(host(x.grad) - g[n + '.dx']).max() < 1e-5 * max(np.abs(g[n + '.dx']).max(), 1.0), n
+            assert np.abs(host(conv.weight.grad) - g[n + '.dw']).max() < 1e-5 * max(np.abs(g[n + '.dw']).max(), 1.0), n
+
+
+def test_conv_cat_equals_conv_of_concat(pkg):
+    ops = pkg.ops
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 24, 9, 9)).astype(np.float32)
+    y = rng.standard_normal((2, 40, 9, 9)).astype(np.float32)
+    wt = (rng.standard_normal((32, 64, 1, 1)) * 0.1).astype(np.float32)
+    out_ref = ref.conv2d_fwd(np.concatenate([x, y], 1), wt)
+    dy = rng.standard_normal(out_ref.shape).astype(np.float32)
+    xt, yt, wtt = dev(x).requires_grad_(True), dev(y).requires_grad_(True), dev(wt).requires_grad_(True)
+    out = ops.conv_cat1x1(xt, yt, wtt)
+    out.backward(dev(dy))
+    dcat = ref.conv2d_dgrad(dy, wt, (2, 64, 9, 9))
+    assert relerr(host(out), out_ref) < 5e-6
+    assert relerr(host(xt.grad), dcat[:, :24]) < 5e-6
+    assert relerr(host(yt.grad), dcat[:, 24:]) < 5e-6
+    assert relerr(host(wtt.grad), ref.conv2d_wgrad(dy, np.concatenate([x, y], 1), wt.shape)) < 2e-5
+
+
+BN_CASES = [(4, 64, 16, 16, True, True), (3, 10, 17, 17, True, False), (2, 130, 8, 8, False, True), (5, 7, 5, 3, False, False),
+            (64, 16, 32, 32, True, True)]
+
+
+@pytest.mark.parametrize('n,c,h,w,relu,with_res', BN_CASES)
+def test_bn_train_fwd_bwd(n, c, h, w, relu, with_res, pkg):
+    ops = pkg.ops
+    rng = np.random.default_rng(n * 1000 + c)
+    x = (rng.standard_normal((n, c, h, w)) * 2 + 3).astype(np.float32)
+    res = rng.standard_normal((n, c, h, w)).astype(np.float32) if with_res else None
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(c)).astype(np.float32)
+    rm = rng.standard_normal(c).astype(np.float32)
+    rv = (1 + rng.random(c)).astype(np.float32)
+    y_ref, mean, invstd, nrm, nrv = ref.bn_train_fwd(x, gamma, beta, rm, rv)
+    pre = y_ref + (res if with_res else 0)
+    out_ref = np.maximum(pre, 0) if relu else pre
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    g = dy * (out_ref > 0) if relu else dy
+    dx_ref, dg_ref, db_ref = ref.bn_train_bwd(g.astype(np.float32), x, mean, invstd, gamma)
+
+    xt, gt, bt = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    rt = dev(res).requires_grad_(True) if with_res else None
+    rmt, rvt = dev(rm), dev(rv)
+    out = ops.batch_norm_act(xt, gt, bt, rmt, rvt, rt, relu, True, 0.1, 1e-5)
+    out.backward(dev(dy))
+    assert np.abs(host(out) - out_ref).max() < 2e-5
+    assert relerr(host(rmt), nrm) < 1e-6 and relerr(host(rvt), nrv) < 1e-5
+    assert relerr(host(xt.grad), dx_ref) < 5e-5
+    assert relerr(host(gt.grad), dg_ref) < 2e-5 and relerr(host(bt.grad), db_ref) < 2e-5
+    if with_res:
+        assert np.array_equal(host(rt.grad), g.astype(np.float32))
+
+
+def test_bn_eval_fwd_bwd(pkg):
+    ops = pkg.ops
+    rng = np.random.default_rng(11)
+    n, c, h, w = 3, 20, 9, 9
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    gamma, beta = rng.standard_normal(c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    rm, rv = rng.standard_normal(c).astype(np.float32), (0.5 + rng.random(c)).astype(np.float32)
+    y_ref = np.maximum(ref.bn_eval_fwd(x, gamma, beta, rm, rv), 0)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    dx_ref, dg_ref, db_ref = ref.bn_eval_bwd((dy * (y_ref > 0)).astype(np.float32), x, gamma, beta, rm, rv)
+    xt, gt, bt = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    rmt, rvt = dev(rm), dev(rv)
+    out = ops.batch_norm_act(xt, gt, bt, rmt, rvt, None, True, False, 0.1, 1e-5)
+    out.backward(dev(dy))
+    assert np.abs(host(out) - y_ref).max() < 1e-5
+    assert np.array_equal(host(rmt), rm) and np.array_equal(host(rvt), rv)      # eval mode leaves the running stats alone
+    assert relerr(host(xt.grad), dx_ref) < 1e-5
+    assert relerr(host(gt.grad), dg_ref) < 1e-5 and relerr(host(bt.grad), db_ref) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 16, 16), (1, 3, 17, 15), (3, 2, 7, 9), (2, 64, 128, 128)])
+def test_maxpool_fwd_bwd_with_ties(shape, pkg):
+    ops = pkg.ops
+    rng = np.random.default_rng(sum(shape))
+    x = np.maximum(rng.standard_normal(shape), 0).astype(np.float32)          # post-ReLU input: many exact ties at 0
+    y_ref, idx = ref.maxpool3x3s2_fwd(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = ops.maxpool3x3s2(xt)
+    y.backward(dev(dy))
+    assert np.array_equal(host(y), y_ref)
+    assert np.abs(host(xt.grad) - ref.maxpool3x3s2_bwd(dy, idx, x.shape)).max() < 1e-6
+
+
+def test_relu(pkg):
+    ops = pkg.ops
+    x = np.random.default_rng(0).standard_normal((3, 4, 5, 7)).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = ops.relu(xt)
+    y.backward(torch.ones_like(y))
+    assert np.array_equal(host(y), np.maximum(x, 0))
+    assert np.array_equal(host(xt.grad), (x > 0).astype(np.float32))
+
+
+def test_head_matches_reference_golden(pkg):
+    """utils.to_heatmap + utils.decode vs the reference's own outputs and autograd gradients."""
+    g = np.load(golden_path('head.npz'))
+    for m in json.loads(str(g['meta'])):
+        n = m['name']
+        z = dev(g[n + '.z']).requires_grad_(True)
+        heat = pkg.utils.to_heatmap(z, m['depth'], m['num_joints'], m['height'], m['width'])
+        coords = pkg.utils.decode(heat, m['depth_range'])
+        coords.backward(dev(g[n + '.dc']))
+        assert relerr(host(coords), g[n + '.coords']) < 2e-6, n
+        assert relerr(host(z.grad), g[n + '.dz']) < 5e-5, n
+
+
+@pytest.mark.parametrize('criterion', ['SmoothL1', 'L1', 'MSE'])
+@pytest.mark.parametrize('invalid', [0.0, 0.3])
+def test_pose_loss(criterion, invalid, pkg):
+    ops = pkg.ops
+    rng = np.random.default_rng(5)
+    b, j = 6, 17
+    relat = (rng.standard_normal((b, j, 3)) * 8 + 1000).astype(np.float32)     # mixes |diff|<1 and >1 after /loss_div
+    cam = (rng.standard_normal((b, j, 3)) * 8).astype(np.float32)
+    val = rng.random((b, j)) >= invalid
+    val[:, 16] = True
+    loss_ref, spec_ref, drelat_ref = ref.pose_loss_fwd_bwd(relat, cam, val, 16, 10.0, criterion)
+    rt = dev(relat).requires_grad_(True)
+    loss, spec = ops.pose_loss(rt, dev(cam), torch.from_numpy(val).cuda(), 16, 10.0, criterion)
+    loss.backward()
+    assert abs(float(loss) - loss_ref) < 1e-5 * max(abs(loss_ref), 1)
+    assert relerr(host(spec), spec_ref) < 1e-6
+    assert relerr(host(rt.grad), drelat_ref) < 1e-5
+
+
+def test_clip_and_adam_two_steps(pkg):
+    """FlatAdam (l2norm + adam kernels) vs the oracle restatement of clip_grad_norm_ + optim.Adam, clip active and inactive."""
+    rng = np.random.default_rng(9)
+    shapes = [(7, 3, 3, 3), (7,), (5, 7, 1, 1), (13,)]
+    ps = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    params = [torch.nn.Parameter(dev(p.copy())) for p in ps]
+    opt = pkg.optim.FlatAdam([('p%d' % i, p) for i, p in enumerate(params)], lr=1e-3, weight_decay=4e-5)
+    ms = [np.zeros_like(p) for p in ps]
+    vs = [np.zeros_like(p) for p in ps]
+    for step, gscale in ((1, 10.0), (2, 0.01)):          # first step clips (norm >> 5), second does not
+        gs = [(rng.standard_normal(s) * gscale).astype(np.float32) for s in shapes]
+        opt.zero_grad()
+        for p, g in zip(params, gs):
+            p.grad.copy_(dev(g))
+        opt.clip_and_step(5.0)
+        total, coef = ref.clip_grad_norm(gs, 5.0)
+        assert abs(opt.total_norm() - total) < 1e-5 * total
+        for i in range(len(ps)):
+            ps[i], ms[i], vs[i] = ref.adam_step(ps[i], gs[i], ms[i], vs[i], step, 1e-3, weight_decay=4e-5, grad_scale=coef)
+            assert np.abs(host(params[i]) - ps[i]).max() < 2e-6, (step, i)
+
+
+def test_ops_refuse_cpu_tensors(pkg):
+    with pytest.raises(pkg._lib.P3DError):
+        pkg.ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))

@@ -91,3 +91,25 @@ def test_learn_rate_schedule():
     assert ops.adapt_learn_rate(16, 5e-5) == pytest.approx(1e-5)
     assert ops.adapt_learn_rate(21, 5e-5) == pytest.approx(2e-6)
     assert ops.adapt_learn_rate(26, 5e-5) == pytest.approx(4e-7)
+
+
+@pytest.mark.parametrize('case', ['depth_r18_b2', 'fusion_r18_b2', 'partial_r18_b2', 'depth_r50_b2'])
+def test_torch_port_matches_reference(case, synth):
+    """oracle/torch_port.py (the cpu_baseline of bench.py) against the same reference vectors."""
+    from oracle.torch_port import TorchPort
+    g = np.load(golden_path('step_%s.npz' % case))
+    meta = json.loads(str(g['meta']))
+    with open(golden_path('state_keys.json')) as f:
+        inv = json.load(f)
+    tag = meta['family'] + ('_depth_only' if (meta['family'] == 'depthnet' and '-depth_only' in meta['extra']) else '')
+    sd = synth.det_state_dict(inv[tag + '.' + meta['model']]['state'], 0)
+    port = TorchPort(sd, family=meta['family'], model=meta['model'])
+    for it in range(meta['iters']):
+        c, d, tc, tv = synth.make_batch(meta['batch'], side=meta['side'], rank=0, step=it, invalid_frac=meta['invalid_frac'])
+        out = port.train_step(c, d, tc, tv, depth_only='-depth_only' in meta['extra'], lr=meta['lr'])
+        assert abs(out['loss'] - g['losses'][it]) < 1e-4 * abs(g['losses'][it])
+        assert abs(out['clip_total'] - g['clip_total'][it]) < 1e-3 * g['clip_total'][it]
+        assert rel(out['spec_cam'].reshape(-1, 3)[tv.reshape(-1)], g['spec_sel_%d' % it]) < 1e-4
+    st = port.state()
+    ps = np.array([st[n].reshape(-1)[g['sample_idx'][i]] for i, n in enumerate(meta['names'])])
+    assert np.abs(ps - g['param_samples']).max() < 3e-5
