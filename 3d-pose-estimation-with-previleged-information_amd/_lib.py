@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libp3d_hip.so')
+LIB_PATH = os.environ.get('P3D_LIB') or os.path.join(_HERE, 'csrc', 'libp3d_hip.so')   # P3D_LIB: A/B a tuning build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'p3d_hip.h')
 
 
@@ -31,10 +31,11 @@ SIGNATURES = {
     'p3d_version': (_i32, []),
     'p3d_last_error': (ctypes.c_char_p, []),
     'p3d_conv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    'p3d_conv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_conv2d_dgrad_workspace_bytes': (_sz, [_desc]),
+    'p3d_conv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_wgrad_workspace_bytes': (_sz, [_desc]),
     'p3d_conv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
-    'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr]),
+    'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
     'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
     'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),

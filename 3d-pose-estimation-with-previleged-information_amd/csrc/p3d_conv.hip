@@ -6,24 +6,40 @@
 // fmaf chain), so parity with the reference's fp32 CPU path is limited only by summation order.
 //
 // GEMM view (C[M x Ncols] = A[M x Kd] * B[Kd x Ncols]), NCHW kept end to end:
-//   FWD   : M = K (out ch)  Ncols = N*Ho*Wo  Kd = C*R*S    A = w          B = im2col(x) (gathered)
-//   DGRAD : M = C (in ch)   Ncols = N*H*W    Kd = K*R*S    A = w^T       B = dy gathered at (hi+pad-r*dil)/stride
-//   WGRAD : M = K           Ncols = C*R*S    Kd = N*Ho*Wo  A = dy         B = im2col(x)^T ; split over Kd into slabs
+//   FWD   : M = K (out ch)  Ncols = N*Ho*Wo  Kd = R*S*C    A = w          B = im2col(x) (gathered)
+//   DGRAD : M = C (in ch)   Ncols = N*H*W    Kd = R*S*K    A = w^T       B = dy gathered at (hi+pad-r*dil)/stride
+//   WGRAD : M = K           Ncols = R*S*C    Kd = N*Ho*Wo  A = dy         B = im2col(x)^T ; split over Kd into slabs
 // In every mode the pixel index is the contiguous one in HBM (NCHW), so global reads of B (FWD/DGRAD)
 // run along wo and the stores of C run along the pixel index: 128-B segments per 32 lanes.
 //
-// Tile: block = 256 threads = 4 waves, each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators
-// (64 acc VGPRs).  Block tile 128x128 (2x2 waves) or 64x256 (1x4 waves), BK = 16, LDS double buffered
-// ([BK][BM+1] and [BK][BN+1] floats: 33-41 KB, >= 3 blocks/CU), one barrier per K-step; the next K-step's
-// global loads are issued into registers before the MFMAs of the current one.
+// Tap-major reduction order ("TAPM"): the reduction index runs (r,s) outer, channel inner, with the channel
+// count padded to the K-step.  A K-step then lies inside ONE filter tap, so the tap's (r,s), the bounds
+// test of the gathered pixel and its address are computed once per K-step and thread; the per-element work
+// of the gather is one multiply-add.  (Stem convolutions with C < 16 use the generic order instead.)
+//
+// Strided DGRAD is decomposed into stride^2 parity classes of input pixels (blockIdx.y); each class is a dense
+// GEMM over only the filter taps that reach it (an arithmetic progression of taps), stored class-major into a
+// staging buffer with full-line stores and interleaved into dx by one streaming pass.
+//
+// Block = 256 threads = 4 waves; a wave owns TM x TN accumulators of the 32x32x2 MFMA.  Tile shapes
+// (BM x BN x BK, wave grid): 128x128x16 (2x2), 64x256x16 (1x4), 96x128x16 (1x4), 64x128x16 (2x2),
+// 128x64x16 (2x2), 64x64x32 (2x2); the host picks the one with the least padded + tail-quantised work.
+// LDS holds [BK][BM+1] and [BK][BN+1] floats, double buffered (33-41 KB -> >= 3 blocks per CU); one barrier
+// per K-step; the next K-step's operands are fetched into registers before the MFMAs of the current one.
+// Operand fetches are buffer loads against a wave-uniform resource whose range check returns 0 for the
+// padding / out-of-tile elements (offset 0x80000000), so the gather has no branches.
+// blockIdx.x is remapped so that blocks sharing an activation (B) tile land on one XCD and reuse its L2.
 #include "p3d_common.h"
+#include <stdlib.h>
 
 namespace p3d {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-constexpr int BK = 16;
+constexpr int OOB = (int)0x80000000;          // byte offset that every resource below rejects (returns 0)
+constexpr unsigned MAX_RECORDS = 0x80000000u;
+constexpr int MAX_STRIDE = 4;
 
 struct IgemmParams {
     const float* A;
@@ -39,31 +55,37 @@ struct IgemmParams {
     int kchunk;             // WGRAD: K extent per split (multiple of BK)
     int accumulate;
     int tiles_m;
+    int cpad;               // TAPM: reduction channels (C for FWD/WGRAD, K for DGRAD) rounded up to BK
+    // DGRAD parity classes (index = parity along the axis): first tap, tap step, tap count, and ho = i + off0 - ir*offstep
+    int ncls;
+    int staged;             // 1: write the class-major staging buffer (strided dgrad), 0: write dx directly
+    size_t cls_stride;      // floats between the staging buffers of two classes
+    int r0[MAX_STRIDE], rstep[MAX_STRIDE], nr[MAX_STRIDE], offr0[MAX_STRIDE], offrstep[MAX_STRIDE];
+    int s0[MAX_STRIDE], sstep[MAX_STRIDE], ns[MAX_STRIDE], offs0[MAX_STRIDE], offsstep[MAX_STRIDE];
 };
 
-template <int KSZ>
-__device__ __forceinline__ void split_k(int kk, int RS, int S, int& q, int& r, int& s) {
-    if constexpr (KSZ == 1) {
-        q = kk; r = 0; s = 0;
-    } else if constexpr (KSZ == 9) {
-        q = kk / 9; int rs = kk - q * 9; r = rs / 3; s = rs - r * 3;
-    } else if constexpr (KSZ == 49) {
-        q = kk / 49; int rs = kk - q * 49; r = rs / 7; s = rs - r * 7;
-    } else {
-        q = kk / RS; int rs = kk - q * RS; r = rs / S; s = rs - r * S;
-    }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
+    const unsigned n = bytes < (size_t)MAX_RECORDS ? (unsigned)bytes : MAX_RECORDS;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
-template <int MODE, int BM, int BN, int KSZ>
+template <int MODE, int BM, int BN, int WM, int WN, int BK, bool TAPM, bool MASKED>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-    constexpr int WN_WAVES = BN / 64;
-    constexpr int WM_WAVES = BM / 64;
-    static_assert(WN_WAVES * WM_WAVES == 4, "4 waves per block");
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(MODE != MODE_DGRAD || TAPM, "dgrad always runs tap-major");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM * WM * 32 == BM && TN * WN * 32 == BN, "tile must split into 32x32 MFMA tiles");
     constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr bool A_KFAST = !(MODE == MODE_DGRAD && KSZ == 1);
+    constexpr bool A_MFAST = (MODE == MODE_DGRAD);        // lanes along m (weights are [k][c][rs]: c is the near-contiguous index)
     constexpr bool B_KFAST = (MODE == MODE_WGRAD);
     constexpr int A_PER = BM * BK / 256;
     constexpr int B_PER = BN * BK / 256;
+    constexpr int K_ROWS = 256 / BK;            // rows (m or j) covered per pass of the k-fast mappings
+    static_assert(A_PER * 256 == BM * BK && B_PER * 256 == BN * BK, "tile must be a multiple of the block");
+    static_assert(256 % BN == 0 || B_KFAST, "column-fast B mapping needs BN | 256");
 
     __shared__ float smem[2 * BK * (LDA + LDB)];
     float* As = smem;
@@ -71,132 +93,232 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
-    const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware remap (bijective): blocks b, b+8, ... share an XCD; give each XCD a contiguous run of logical ids
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RS = p.R * p.S;
     const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
 
-    int k_begin = 0, k_end = p.Kd;
+    // ---- reduction range ----
+    int k_begin = 0, k_end = p.Kd, nk;
+    int ph = 0, pw = 0, Hc = p.H, Wc = p.W, ncols = p.Ncols, cls_ns = 1;
     if constexpr (MODE == MODE_WGRAD) {
         k_begin = blockIdx.y * p.kchunk;
         k_end = min(p.Kd, k_begin + p.kchunk);
+        nk = (k_end - k_begin + BK - 1) / BK;
+    } else if constexpr (MODE == MODE_DGRAD) {
+        // parity class of this block (uniform): pixels hi = ph + stride*i, wi = pw + stride*j
+        const int cls = blockIdx.y;
+        ph = cls / p.stride; pw = cls - ph * p.stride;
+        Hc = (p.H - ph + p.stride - 1) / p.stride;
+        Wc = (p.W - pw + p.stride - 1) / p.stride;
+        ncols = p.N * Hc * Wc;
+        cls_ns = p.ns[pw];
+        nk = p.nr[ph] * cls_ns * (p.cpad / BK);
+        if (n0 >= ncols || nk == 0) return;        // a class no tap reaches stays zero: the interleave pass writes it
+    } else {
+        nk = TAPM ? RS * (p.cpad / BK) : (p.Kd + BK - 1) / BK;
     }
-    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    // ---- wave-uniform buffer resources: w whole; x / dy from the first image this block touches ----
+    int nfirst;
+    if constexpr (MODE == MODE_FWD) nfirst = n0 / HoWo;
+    else if constexpr (MODE == MODE_DGRAD) nfirst = n0 / (Hc * Wc);
+    else nfirst = k_begin / HoWo;
+    __amdgpu_buffer_rsrc_t rA, rB, rM;
+    if constexpr (MODE == MODE_FWD) {
+        rA = make_rsrc(p.A, (size_t)p.K * p.ldw * 4);
+        rB = make_rsrc(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
+        rM = make_rsrc(MASKED && p.mask_in ? p.mask_in + (size_t)nfirst * HW : nullptr, MASKED && p.mask_in ? (size_t)(p.N - nfirst) * HW * 4 : 0);
+    } else if constexpr (MODE == MODE_DGRAD) {
+        rA = make_rsrc(p.A, (size_t)p.K * p.ldw * 4);
+        rB = make_rsrc(p.B + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
+        rM = make_rsrc(MASKED && p.mult ? p.mult + (size_t)nfirst * HoWo : nullptr, MASKED && p.mult ? (size_t)(p.N - nfirst) * HoWo * 4 : 0);
+    } else {
+        rA = make_rsrc(p.A + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
+        rB = make_rsrc(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
+        rM = make_rsrc(nullptr, 0);
+    }
+    const bool use_mask = MASKED && (MODE == MODE_FWD ? p.mask_in != nullptr : (MODE == MODE_DGRAD ? p.mult != nullptr : false));
 
     // ---- per-thread invariants of the B gather (FWD/DGRAD: one fixed GEMM column per thread) ----
     int cb_n = 0, cb_a = 0, cb_b = 0;
     bool col_ok = false;
     if constexpr (!B_KFAST) {
         const int col = n0 + (t % BN);
-        col_ok = col < p.Ncols;
+        col_ok = col < ncols;
         if constexpr (MODE == MODE_FWD) {
             const int n = col / HoWo, pp = col - n * HoWo;
             const int ho = pp / p.Wo, wo = pp - ho * p.Wo;
-            cb_n = n; cb_a = ho * p.stride - p.pad; cb_b = wo * p.stride - p.pad;
+            cb_n = n - nfirst; cb_a = ho * p.stride - p.pad; cb_b = wo * p.stride - p.pad;
         } else {
-            const int n = col / HW, pix = col - n * HW;
-            const int hi = pix / p.W, wi = pix - hi * p.W;
-            cb_n = n; cb_a = hi + p.pad; cb_b = wi + p.pad;
+            const int hw = Hc * Wc;
+            const int n = col / hw, pix = col - n * hw;
+            const int i = pix / Wc;
+            cb_n = n - nfirst; cb_a = i; cb_b = pix - i * Wc;
         }
+    }
+    // WGRAD tap-major: the block's columns lie inside one tap (host guarantees C % BN == 0)
+    int wg_r = 0, wg_s = 0, wg_c0 = 0;
+    if constexpr (MODE == MODE_WGRAD && TAPM) {
+        const int tp = n0 / p.C;
+        wg_c0 = n0 - tp * p.C;
+        wg_r = tp / p.S; wg_s = tp - wg_r * p.S;
     }
 
     float ra[A_PER], rb[B_PER];
+    int ld_tp = 0, ld_c0 = 0;         // tap and channel base of the next K-step to fetch (TAPM, FWD/DGRAD)
+
+    // Every fetch is  buffer_load(rsrc, voffset | invalid, soffset):  voffset = the per-thread part, fixed over the K loop
+    // (or recomputed once per K-step), soffset = the wave-uniform part (channel base, tap, row step) kept in SGPRs, and
+    // `invalid` = 0x80000000 on lanes whose element is padding, which the resource's range check turns into 0.
+    // So a K-step's gather costs a handful of VALU instructions per thread, not a handful per element.
+    const bool chan_pad = TAPM && (MODE != MODE_WGRAD) && (p.cpad != (MODE == MODE_FWD ? p.C : p.K));
+    const int chan_lim = (MODE == MODE_FWD) ? p.C : p.K;
+    int a_voff[A_PER];                // A: per-thread, per-row offsets (bytes) or OOB for rows beyond M
+    int b_base = 0;                   // B: per-thread offset of this thread's column / row, tap part added per K-step
+    if constexpr (MODE == MODE_FWD && TAPM) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int m = m0 + t / BK + K_ROWS * i;
+            a_voff[i] = m < p.M ? (m * p.ldw + (t % BK) * RS) * 4 : OOB;
+        }
+        b_base = ((cb_n * p.C + t / BN) * HW) * 4;
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = t + 256 * i;
+            const int m = m0 + e % BM;
+            a_voff[i] = m < p.M ? ((e / BM) * p.ldw + m * RS) * 4 : OOB;
+        }
+        b_base = ((cb_n * p.K + t / BN) * HoWo) * 4;
+    }
+    if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) a_voff[i] = (m0 + t / BK + K_ROWS * i) < p.M ? 0 : OOB;      // only the validity bit
+    }
 
     auto load_tiles = [&](int kt) {
-        const int kbase = k_begin + kt * BK;
-        // ---------------- A ----------------
-        if constexpr (MODE == MODE_WGRAD) {
-            const int kk = kbase + (t & 15);
-            const bool kok = kk < k_end;
-            const int n = kk / HoWo, pp = kk - n * HoWo;
-            const float sc = (kok && p.mult) ? p.mult[(size_t)n * HoWo + pp] : 1.f;
-            const float* src = p.A + (size_t)n * p.K * HoWo + pp;
+        // ================= FWD =================
+        if constexpr (MODE == MODE_FWD) {
+            if constexpr (TAPM) {
+                const int r = ld_tp / p.S, s = ld_tp - r * p.S;
+                const int a_soff = (p.woff + ld_c0 * RS + ld_tp) * 4;
+                const int a_bad = (chan_pad && ld_c0 + t % BK >= chan_lim) ? OOB : 0;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int m = m0 + (t >> 4) + 16 * i;
-                ra[i] = (kok && m < p.M) ? src[(size_t)m * HoWo] * sc : 0.f;
-            }
-        } else {
+                for (int i = 0; i < A_PER; ++i)
+                    ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | a_bad, a_soff, 0));
+                const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
+                const bool okp = col_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const int pix = hi * p.W + wi;
+                const int voff = (b_base + pix * 4) | (okp ? 0 : OOB);
+                float mk = 1.f;
+                if constexpr (MASKED) { if (use_mask) mk = bload(rM, okp ? (cb_n * HW + pix) * 4 : OOB); }
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                int kk_l, m_l;
-                if constexpr (A_KFAST) { kk_l = t & 15; m_l = (t >> 4) + 16 * i; }
-                else { m_l = t % BM; kk_l = t / BM + (256 / BM) * i; }
-                const int m = m0 + m_l, kk = kbase + kk_l;
-                float v = 0.f;
-                if (m < p.M && kk < k_end) {
-                    if constexpr (MODE == MODE_FWD) {
-                        v = p.A[(size_t)m * p.ldw + p.woff + kk];
-                    } else {
-                        int q, r, s;
-                        split_k<KSZ>(kk, RS, p.S, q, r, s);
-                        v = p.A[(size_t)q * p.ldw + p.woff + m * RS + (kk - q * RS)];
-                    }
+                for (int i = 0; i < B_PER; ++i) {
+                    const int crow = ld_c0 + (256 / BN) * i;                      // uniform; this thread reads channel crow + t/BN
+                    const int bad = (chan_pad && crow + t / BN >= chan_lim) ? OOB : 0;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff | bad, crow * HW * 4, 0));
+                    rb[i] = MASKED ? v * mk : v;
                 }
-                ra[i] = v;
+            } else {
+                const int kbase = kt * BK;
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) {
+                    const int m = m0 + t / BK + K_ROWS * i, kk = kbase + t % BK;
+                    ra[i] = bload(rA, (m < p.M && kk < k_end) ? (m * p.ldw + p.woff + kk) * 4 : OOB);
+                }
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int kk = kbase + t / BN + (256 / BN) * i;
+                    const int c = kk / RS, rs = kk - c * RS;
+                    const int r = rs / p.S, s = rs - r * p.S;
+                    const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
+                    const bool ok = col_ok && kk < k_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    float v = bload(rB, ok ? ((cb_n * p.C + c) * HW + hi * p.W + wi) * 4 : OOB);
+                    if constexpr (MASKED) { if (use_mask) v *= bload(rM, ok ? (cb_n * HW + hi * p.W + wi) * 4 : OOB); }
+                    rb[i] = v;
+                }
             }
         }
-        // ---------------- B ----------------
-        if constexpr (MODE == MODE_FWD) {
-            const float* xb = p.B + (size_t)cb_n * p.C * HW;
-            const float* mb = p.mask_in ? p.mask_in + (size_t)cb_n * HW : nullptr;
+        // ================= DGRAD (always tap-major over the taps of this parity class) =================
+        if constexpr (MODE == MODE_DGRAD) {
+            const int ir = ld_tp / cls_ns, is = ld_tp - ir * cls_ns;
+            const int r = p.r0[ph] + p.rstep[ph] * ir, s = p.s0[pw] + p.sstep[pw] * is;
+            const int ho = cb_a + p.offr0[ph] - ir * p.offrstep[ph], wo = cb_b + p.offs0[pw] - is * p.offsstep[pw];
+            const int a_soff = (ld_c0 * p.ldw + p.woff + r * p.S + s) * 4;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int bad = (chan_pad && ld_c0 + (t + 256 * i) / BM >= chan_lim) ? OOB : 0;
+                ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | bad, a_soff, 0));
+            }
+            const bool okp = col_ok && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            const int pix = ho * p.Wo + wo;
+            const int voff = (b_base + pix * 4) | (okp ? 0 : OOB);
+            float mk = 1.f;
+            if constexpr (MASKED) { if (use_mask) mk = bload(rM, okp ? (cb_n * HoWo + pix) * 4 : OOB); }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
-                const int kk = kbase + t / BN + (256 / BN) * i;
-                int c, r, s;
-                split_k<KSZ>(kk, RS, p.S, c, r, s);
-                const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
-                float v = 0.f;
-                if (col_ok && kk < k_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                    v = xb[(size_t)c * HW + hi * p.W + wi];
-                    if (mb) v *= mb[hi * p.W + wi];
-                }
-                rb[i] = v;
+                const int qrow = ld_c0 + (256 / BN) * i;
+                const int bad = (chan_pad && qrow + t / BN >= chan_lim) ? OOB : 0;
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff | bad, qrow * HoWo * 4, 0));
+                rb[i] = MASKED ? v * mk : v;
             }
-        } else if constexpr (MODE == MODE_DGRAD) {
-            const float* db = p.B + (size_t)cb_n * p.K * HoWo;
-            const float* mb = p.mult ? p.mult + (size_t)cb_n * HoWo : nullptr;
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int kk = kbase + t / BN + (256 / BN) * i;
-                int q, r, s;
-                split_k<KSZ>(kk, RS, p.S, q, r, s);
-                int th = cb_a - r * p.dil, tw = cb_b - s * p.dil;
-                bool ok = col_ok && kk < k_end && th >= 0 && tw >= 0;
-                int ho = th, wo = tw;
-                if (p.stride != 1) {
-                    ho = th / p.stride; wo = tw / p.stride;
-                    ok = ok && (ho * p.stride == th) && (wo * p.stride == tw);
-                }
-                ok = ok && ho < p.Ho && wo < p.Wo;
-                float v = 0.f;
-                if (ok) {
-                    v = db[(size_t)q * HoWo + ho * p.Wo + wo];
-                    if (mb) v *= mb[ho * p.Wo + wo];
-                }
-                rb[i] = v;
-            }
-        } else {
-            const int kk = kbase + (t & 15);
+        }
+        if constexpr (MODE != MODE_WGRAD && TAPM) {
+            ld_c0 += BK;
+            if (ld_c0 >= p.cpad) { ld_c0 = 0; ++ld_tp; }
+        }
+        // ================= WGRAD =================
+        if constexpr (MODE == MODE_WGRAD) {
+            const int kk = k_begin + kt * BK + (t % BK);
             const bool kok = kk < k_end;
             const int n = kk / HoWo, pp = kk - n * HoWo;
+            {
+                const int voff = ((((n - nfirst) * p.K + m0 + t / BK) * HoWo + pp) * 4) | (kok ? 0 : OOB);
+                float sc = 1.f;
+                if constexpr (MASKED) { if (p.mult) sc = kok ? p.mult[(size_t)n * HoWo + pp] : 0.f; }
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff | a_voff[i], K_ROWS * i * HoWo * 4, 0));
+                    ra[i] = MASKED ? v * sc : v;
+                }
+            }
             const int ho = pp / p.Wo, wo = pp - ho * p.Wo;
             const int hb = ho * p.stride - p.pad, wb = wo * p.stride - p.pad;
-            const float* xb = p.B + (size_t)n * p.C * HW;
-            const float* mb = p.mask_in ? p.mask_in + (size_t)n * HW : nullptr;
+            const int nb = (n - nfirst) * p.C;
+            if constexpr (TAPM) {
+                const int hi = hb + wg_r * p.dil, wi = wb + wg_s * p.dil;
+                const bool okp = kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const int pix = hi * p.W + wi;
+                const int voff = (((nb + wg_c0 + t / BK) * HW + pix) * 4) | (okp ? 0 : OOB);
+                float mk = 1.f;
+                if constexpr (MASKED) { if (p.mask_in) mk = okp ? p.mask_in[(size_t)n * HW + pix] : 0.f; }
 #pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int j = n0 + (t >> 4) + 16 * i;
-                int c, r, s;
-                split_k<KSZ>(j, RS, p.S, c, r, s);
-                const int hi = hb + r * p.dil, wi = wb + s * p.dil;
-                float v = 0.f;
-                if (kok && j < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                    v = xb[(size_t)c * HW + hi * p.W + wi];
-                    if (mb) v *= mb[hi * p.W + wi];
+                for (int i = 0; i < B_PER; ++i) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, K_ROWS * i * HW * 4, 0));
+                    rb[i] = MASKED ? v * mk : v;
                 }
-                rb[i] = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int j = n0 + t / BK + K_ROWS * i;
+                    const int c = j / RS, rs = j - c * RS;
+                    const int r = rs / p.S, s = rs - r * p.S;
+                    const int hi = hb + r * p.dil, wi = wb + s * p.dil;
+                    const bool ok = kok && j < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    float v = bload(rB, ok ? ((nb + c) * HW + hi * p.W + wi) * 4 : OOB);
+                    if constexpr (MASKED) { if (p.mask_in) v *= ok ? p.mask_in[(size_t)n * HW + hi * p.W + wi] : 0.f; }
+                    rb[i] = v;
+                }
             }
         }
     };
@@ -205,24 +327,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int kk_l, m_l;
-            if constexpr (A_KFAST) { kk_l = t & 15; m_l = (t >> 4) + 16 * i; }
-            else { m_l = t % BM; kk_l = t / BM + (256 / BM) * i; }
+            if constexpr (A_MFAST) { const int e = t + 256 * i; m_l = e % BM; kk_l = e / BM; }
+            else { kk_l = t % BK; m_l = t / BK + K_ROWS * i; }
             As[(buf * BK + kk_l) * LDA + m_l] = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             int kk_l, c_l;
-            if constexpr (B_KFAST) { kk_l = t & 15; c_l = (t >> 4) + 16 * i; }
+            if constexpr (B_KFAST) { kk_l = t % BK; c_l = t / BK + K_ROWS * i; }
             else { c_l = t % BN; kk_l = t / BN + (256 / BN) * i; }
             Bs[(buf * BK + kk_l) * LDB + c_l] = rb[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -236,16 +358,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);
-        const float* a_base = As + (buf * BK + kh) * LDA + wm * 64 + li;
-        const float* b_base = Bs + (buf * BK + kh) * LDB + wn * 64 + li;
+        const float* a_base = As + (buf * BK + kh) * LDA + wm * (TM * 32) + li;
+        const float* b_base = Bs + (buf * BK + kh) * LDB + wn * (TN * 32) + li;
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) av[0][a] = a_base[32 * a];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bv[0][b] = b_base[32 * b];
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
-            const float a0 = a_base[2 * kp * LDA], a1 = a_base[2 * kp * LDA + 32];
-            const float b0 = b_base[2 * kp * LDB], b1 = b_base[2 * kp * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (kp + 1 < BK / 2) {           // operands of the next k-pair are in flight while this one's MFMAs issue
+#pragma unroll
+                for (int a = 0; a < TM; ++a) av[(kp + 1) & 1][a] = a_base[2 * (kp + 1) * LDA + 32 * a];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[(kp + 1) & 1][b] = b_base[2 * (kp + 1) * LDB + 32 * b];
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][a], bv[kp & 1][b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
@@ -253,9 +385,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + li;
-        if (col >= p.Ncols) continue;
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = n0 + wn * (TN * 32) + ni * 32 + li;
+        if (col >= ncols) continue;
         size_t base;
         size_t rstride;
         float scale = 1.f;
@@ -263,27 +395,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int n = col / HoWo, pp = col - n * HoWo;
             base = (size_t)n * p.K * HoWo + pp;
             rstride = HoWo;
-            if (p.mult) scale = p.mult[(size_t)n * HoWo + pp];
+            if constexpr (MASKED) { if (p.mult) scale = p.mult[(size_t)n * HoWo + pp]; }
         } else if constexpr (MODE == MODE_DGRAD) {
-            const int n = col / HW, pix = col - n * HW;
-            base = (size_t)n * p.C * HW + pix;
-            rstride = HW;
-            if (p.mask_in) scale = p.mask_in[(size_t)n * HW + pix];
+            const int hw = Hc * Wc;
+            const int n = col / hw, pix = col - n * hw;
+            if (p.staged) {      // class-major staging buffer [cls][N][C][Hc][Wc]: full-line stores; interleaved into dx afterwards
+                base = (size_t)blockIdx.y * p.cls_stride + (size_t)n * p.C * hw + pix;
+                rstride = hw;
+            } else {
+                base = (size_t)n * p.C * HW + pix;
+                rstride = HW;
+                if constexpr (MASKED) { if (p.mask_in) scale = p.mask_in[(size_t)n * HW + pix]; }
+            }
         } else {
             base = (size_t)blockIdx.y * p.M * p.Ncols + col;
             rstride = p.Ncols;
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const int row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
                 if (row < p.M) {
-                    float v = acc[mi][ni][reg] * scale;
+                    float v = acc[mi][ni][reg];
+                    if constexpr (MASKED) v *= scale;
                     const size_t idx = base + (size_t)row * rstride;
                     if constexpr (MODE == MODE_FWD) {
                         // with a partial-conv multiplier: ((raw - b)*mult + b)*mask_out, mask_out == (mult > 0)  (partial_conv.py:48-51)
-                        if (p.bias) v = (p.mult && !(scale > 0.f)) ? 0.f : v + p.bias[row];
+                        if (p.bias) v = (MASKED && p.mult && !(scale > 0.f)) ? 0.f : v + p.bias[row];
                     }
                     if constexpr (MODE != MODE_WGRAD) {
                         if (p.accumulate) v += p.Cout[idx];
@@ -295,7 +434,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-// dw[k][woff + j] (=|+=) sum_z slab[z][k][j]
+// dx[n][c][hi][wi] (=|+=) stage[cls(hi,wi)][n][c][hi/s][wi/s] * mask_in ; classes no tap reaches contribute 0
+__global__ __launch_bounds__(256) void dgrad_interleave_kernel(const float* __restrict__ stage, float* __restrict__ dx, const float* __restrict__ mask_in,
+                                                               int NC, int C, int H, int W, int stride, size_t cls_stride, int live_mask, int accumulate) {
+    const size_t total = (size_t)NC * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wi = (int)(i % W);
+        const int hi = (int)((i / W) % H);
+        const size_t nc = i / ((size_t)W * H);
+        const int ih = hi / stride, iw = wi / stride;
+        const int ph = hi - ih * stride, pw = wi - iw * stride, cls = ph * stride + pw;
+        float v = 0.f;
+        if ((live_mask >> cls) & 1) {
+            const int hc = (H - ph + stride - 1) / stride, wc = (W - pw + stride - 1) / stride;
+            v = stage[(size_t)cls * cls_stride + (nc * hc + ih) * wc + iw];
+        }
+        if (mask_in) v *= mask_in[(nc / C) * H * W + (size_t)hi * W + wi];
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// dw[k][woff + j] (=|+=) sum_z slab[z][k][j]   (generic column order j = c*RS + rs)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int Ncols,
                                                            int splits, int ldw, int woff, int accumulate) {
     const size_t total = (size_t)M * Ncols;
@@ -308,8 +467,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// tap-major slabs: column j' = rs*C + c.  One block per (filter k, 64-channel chunk): sums the splits with coalesced reads along c,
+// transposes (rs, c) -> (c, rs) through LDS, and writes the 64*RS contiguous floats of dw[k][c0:c0+64][:][:].
+constexpr int REDUCE_CH = 64;
+__global__ __launch_bounds__(256) void wgrad_reduce_tapm_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int C, int RS,
+                                                                int splits, int ldw, int woff, int accumulate) {
+    extern __shared__ float tile[];                     // [REDUCE_CH][RS]
+    const int k = blockIdx.x, c0 = blockIdx.y * REDUCE_CH;
+    const size_t total = (size_t)M * RS * C;
+    const int n = RS * REDUCE_CH;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int rs = e / REDUCE_CH, cl = e - rs * REDUCE_CH;
+        const size_t src = (size_t)k * RS * C + (size_t)rs * C + c0 + cl;
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + src];
+        tile[cl * RS + rs] = s;
+    }
+    __syncthreads();
+    float* dst = dw + (size_t)k * ldw + woff + (size_t)c0 * RS;
+    for (int e = threadIdx.x; e < n; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
+}
+
 // db[k] = sum over n, hw of dy[n][k][hw]; one block per channel
-__global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int K, int HW) {
+__global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int K, int HW, int accumulate) {
     const int k = blockIdx.x;
     double s = 0.0;
     for (int n = 0; n < N; ++n) {
@@ -320,7 +500,10 @@ __global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) db[k] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float v = (float)(red[0] + red[1] + red[2] + red[3]);
+        db[k] = accumulate ? db[k] + v : v;
+    }
 }
 
 // partial_conv.py:35-43 on a 1-channel mask
@@ -358,16 +541,20 @@ static int32_t validate(const p3d_conv_desc* d) {
     P3D_REQUIRE(d != nullptr, "conv: null descriptor");
     P3D_REQUIRE(d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->K > 0 && d->R > 0 && d->S > 0,
                 "conv: non-positive dimension N=%d C=%d H=%d W=%d K=%d R=%d S=%d", d->N, d->C, d->H, d->W, d->K, d->R, d->S);
-    P3D_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "conv: bad stride/dil/pad %d/%d/%d", d->stride, d->dil, d->pad);
+    P3D_REQUIRE(d->stride >= 1 && d->stride <= MAX_STRIDE && d->dil >= 1 && d->pad >= 0, "conv: bad stride/dil/pad %d/%d/%d (stride <= %d)",
+                d->stride, d->dil, d->pad, MAX_STRIDE);
     const int ho = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     P3D_REQUIRE(ho == d->Ho && wo == d->Wo && ho > 0 && wo > 0, "conv: Ho/Wo %d/%d do not match derived %d/%d", d->Ho, d->Wo, ho, wo);
     P3D_REQUIRE(d->c_total >= d->C && d->c_offset >= 0 && d->c_offset + d->C <= d->c_total,
                 "conv: channel window [%d,%d) outside c_total=%d", d->c_offset, d->c_offset + d->C, d->c_total);
-    P3D_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31) &&
-                    (int64_t)d->C * d->H * d->W < (1ll << 31) && (int64_t)d->K * d->Ho * d->Wo < (1ll << 31) &&
-                    (int64_t)d->K * d->c_total * d->R * d->S < (1ll << 31),
-                "conv: extent exceeds 32-bit pixel indexing");
+    // 32-bit GEMM indices, and every per-block buffer window (a few images of x / dy, or all of w) below 2 GiB
+    const int64_t lim = 1ll << 31;
+    const int64_t img_x = (int64_t)d->C * d->H * d->W * 4, img_y = (int64_t)d->K * d->Ho * d->Wo * 4;
+    const int64_t span_f = 256 / ((int64_t)d->Ho * d->Wo) + 2, span_d = 256 * 16 / ((int64_t)d->H * d->W) + 2;
+    P3D_REQUIRE((int64_t)d->N * d->Ho * d->Wo < lim && (int64_t)d->N * d->H * d->W < lim && (int64_t)d->K * d->c_total * d->R * d->S * 4 < lim &&
+                    img_x * span_f < lim && img_y * span_d < lim,
+                "conv: extent exceeds the 32-bit / 2 GiB-window indexing of the kernel");
     return P3D_OK;
 }
 
@@ -381,56 +568,115 @@ static IgemmParams base_params(const p3d_conv_desc* d) {
     return p;
 }
 
-static int ksz_of(const p3d_conv_desc* d) {
-    if (d->R == 1 && d->S == 1) return 1;
-    if (d->R == 3 && d->S == 3) return 9;
-    if (d->R == 7 && d->S == 7) return 49;
-    return 0;
+// ---- tile configurations --------------------------------------------------------------------------------
+struct TileCfg { int bm, bn, bk; double eff; };
+//                               128x128           64x256            96x128            64x128            128x64            64x64
+static const TileCfg kCfgs[6] = {{128, 128, 16, 1.0}, {64, 256, 16, 0.95}, {96, 128, 16, 0.95}, {64, 128, 16, 0.85}, {128, 64, 16, 0.85}, {64, 64, 32, 0.7}};
+constexpr int kSlots = 512;   // blocks resident at once (2 per CU) used to price the tail of a launch
+
+// cost ~ rounds of resident blocks x tile area / efficiency; `zmult` = extra grid factor (classes)
+static int forced_cfg() {      // tuning aid: P3D_FORCE_CFG=0..5 pins the tile shape (tools/conv_bench.py --sweep)
+    static const int v = [] { const char* e = getenv("P3D_FORCE_CFG"); return e ? atoi(e) : -1; }();
+    return v;
 }
 
-// pick the block tile with the least padded work; ties go to 128x128
-static bool use_wide_tile(int M, int Ncols) {
-    const int64_t c128 = ceil_div(M, 128) * 128 * ceil_div(Ncols, 128) * 128;
-    const int64_t c64 = ceil_div(M, 64) * 64 * ceil_div(Ncols, 256) * 256;
-    return c64 < c128;
-}
-
-template <int MODE, int BM, int BN>
-static void launch_ksz(int ksz, dim3 grid, hipStream_t st, const IgemmParams& p) {
-    switch (ksz) {
-        case 1: hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, 1>), grid, dim3(256), 0, st, p); break;
-        case 9: hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, 9>), grid, dim3(256), 0, st, p); break;
-        case 49: hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, 49>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, 0>), grid, dim3(256), 0, st, p); break;
+static int pick_cfg(int M, int Ncols, int64_t zmult) {
+    if (forced_cfg() >= 0 && forced_cfg() < 6) return forced_cfg();
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        const int64_t blocks = ceil_div(M, kCfgs[i].bm) * ceil_div(Ncols, kCfgs[i].bn) * zmult;
+        const double rounds = blocks <= kSlots ? (double)ceil_div(blocks, 256) * 0.5 : (double)blocks / kSlots;
+        const double cost = rounds * kCfgs[i].bm * kCfgs[i].bn / kCfgs[i].eff;
+        if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
     }
+    return best;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int BK>
+static void launch_variant(bool tapm, bool masked, dim3 grid, hipStream_t st, const IgemmParams& p) {
+    constexpr bool ALLOW_MASK = (BM == 128 && BN == 128) || (BM == 64 && BN == 256);
+    if constexpr (ALLOW_MASK) {
+        if (masked) {
+            if constexpr (MODE != MODE_DGRAD) {
+                if (!tapm) { hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, true>), grid, dim3(256), 0, st, p); return; }
+            }
+            hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, true>), grid, dim3(256), 0, st, p);
+            return;
+        }
+    }
+    if constexpr (MODE != MODE_DGRAD) {
+        if (!tapm) { hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, false>), grid, dim3(256), 0, st, p); return; }
+    }
+    hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, false>), grid, dim3(256), 0, st, p);
+}
+
+static int mask_cfg(int cfg, bool masked) {   // masked variants exist for the two largest shapes only
+    if (masked && cfg != 0 && cfg != 1) return (kCfgs[cfg].bm == 64) ? 1 : 0;
+    return cfg;
 }
 
 template <int MODE>
-static void launch_igemm(int ksz, IgemmParams& p, int splits, hipStream_t st) {
-    if (use_wide_tile(p.M, p.Ncols)) {
-        p.tiles_m = (int)ceil_div(p.M, 64);
-        dim3 grid((unsigned)(p.tiles_m * ceil_div(p.Ncols, 256)), (unsigned)splits);
-        launch_ksz<MODE, 64, 256>(ksz, grid, st, p);
-    } else {
-        p.tiles_m = (int)ceil_div(p.M, 128);
-        dim3 grid((unsigned)(p.tiles_m * ceil_div(p.Ncols, 128)), (unsigned)splits);
-        launch_ksz<MODE, 128, 128>(ksz, grid, st, p);
+static void launch_igemm(int cfg, bool tapm, bool masked, IgemmParams& p, int ny, hipStream_t st) {
+    p.tiles_m = (int)ceil_div(p.M, kCfgs[cfg].bm);
+    dim3 grid((unsigned)(p.tiles_m * ceil_div(p.Ncols, kCfgs[cfg].bn)), (unsigned)ny);
+    switch (cfg) {
+        case 0: launch_variant<MODE, 128, 128, 2, 2, 16>(tapm, masked, grid, st, p); break;
+        case 1: launch_variant<MODE, 64, 256, 1, 4, 16>(tapm, masked, grid, st, p); break;
+        case 2: launch_variant<MODE, 96, 128, 1, 4, 16>(tapm, masked, grid, st, p); break;
+        case 3: launch_variant<MODE, 64, 128, 2, 2, 16>(tapm, masked, grid, st, p); break;
+        case 4: launch_variant<MODE, 128, 64, 2, 2, 16>(tapm, masked, grid, st, p); break;
+        default: launch_variant<MODE, 64, 64, 2, 2, 32>(tapm, masked, grid, st, p); break;
     }
 }
 
-struct WgradPlan { int splits; int kchunk; };
+struct WgradPlan { int cfg; bool tapm; int splits; int kchunk; };
 
-static WgradPlan plan_wgrad(const p3d_conv_desc* d) {
+static WgradPlan plan_wgrad(const p3d_conv_desc* d, bool masked) {
     const int M = d->K, Ncols = d->C * d->R * d->S;
     const int64_t Kd = (int64_t)d->N * d->Ho * d->Wo;
-    const int64_t tiles = use_wide_tile(M, Ncols) ? ceil_div(M, 64) * ceil_div(Ncols, 256) : ceil_div(M, 128) * ceil_div(Ncols, 128);
-    int64_t splits = ceil_div(1024, tiles);                 // ~4 blocks per CU over the chip
-    const int64_t max_splits = ceil_div(Kd, 8 * BK);        // at least 8 K-steps per block
+    // choose the tile for a fully split problem (tail-free), then the split count that fills ~4 blocks per CU.
+    // Tap-major columns need every block inside one tap: C % BN == 0.
+    int cfg = -1;
+    bool tapm = false;
+    double best = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        if (masked && i > 1) break;
+        if (forced_cfg() >= 0 && forced_cfg() < 6 && i != forced_cfg() && !masked) continue;
+        const bool tm = d->C % kCfgs[i].bn == 0;
+        double cost = (double)ceil_div(M, kCfgs[i].bm) * kCfgs[i].bm * ceil_div(Ncols, kCfgs[i].bn) * kCfgs[i].bn / kCfgs[i].eff;
+        if (!tm && d->R * d->S > 1) cost *= 1.3;          // generic per-element tap decode is slower
+        if (cost < best * 0.999) { best = cost; cfg = i; tapm = tm; }
+    }
+    const int bk = kCfgs[cfg].bk;
+    const int64_t tiles = ceil_div(M, kCfgs[cfg].bm) * ceil_div(Ncols, kCfgs[cfg].bn);
+    int64_t splits = ceil_div(1024, tiles);
+    const int64_t max_splits = ceil_div(Kd, 8 * bk);        // at least 8 K-steps per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    int64_t kchunk = ceil_div(ceil_div(Kd, splits), BK) * BK;
+    int64_t kchunk = ceil_div(ceil_div(Kd, splits), bk) * bk;
     splits = ceil_div(Kd, kchunk);
-    return {(int)splits, (int)kchunk};
+    return {cfg, tapm, (int)splits, (int)kchunk};
+}
+
+// Taps r in [0,R) with (par + pad - r*dil) % stride == 0 form an arithmetic progression r0 + step*ir; the output
+// coordinate they read is ho = i + off0 - ir*offstep for the class-grid row i (hi = par + stride*i).
+static void fill_class(int par, int R, int stride, int pad, int dil, int* r0, int* step, int* n, int* off0, int* offstep) {
+    *r0 = 0; *step = 1; *n = 0; *off0 = 0; *offstep = 0;
+    int first = -1, second = -1;
+    for (int r = 0; r < R; ++r) {
+        const int t = par + pad - r * dil;
+        if (((t % stride) + stride) % stride != 0) continue;
+        if (first < 0) first = r;
+        else if (second < 0) second = r;
+        ++*n;
+    }
+    if (first < 0) return;
+    *r0 = first;
+    *step = second < 0 ? 1 : second - first;
+    const int t0 = par + pad - first * dil;                 // divisible by stride
+    *off0 = t0 >= 0 ? t0 / stride : -((-t0) / stride);
+    *offstep = (*step * dil) / stride;                        // (step*dil) is a multiple of stride by construction
 }
 
 }  // namespace p3d
@@ -446,53 +692,113 @@ int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, c
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
     p.M = d->K; p.Ncols = d->N * d->Ho * d->Wo; p.Kd = d->C * d->R * d->S;
-    launch_igemm<MODE_FWD>(ksz_of(d), p, 1, (hipStream_t)stream);
+    const bool masked = mask_in || mult;
+    const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, 1), masked);
+    const bool tapm = d->C >= 16;
+    p.cpad = (int)ceil_div(d->C, kCfgs[cfg].bk) * kCfgs[cfg].bk;
+    launch_igemm<MODE_FWD>(cfg, tapm, masked, p, 1, (hipStream_t)stream);
     return check_launch("conv2d_fwd");
 }
 
+size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
+    if (validate(d) || d->stride == 1) return 0;
+    const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
+    return (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
+}
+
 int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
-                         const float* mask_in, float* dx, void* stream) {
+                         const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && w && dx, "conv2d_dgrad: null tensor");
     IgemmParams p = base_params(d);
     p.A = w; p.B = dy; p.Cout = dx; p.mask_in = mask_in; p.mult = mult;
-    p.M = d->C; p.Ncols = d->N * d->H * d->W; p.Kd = d->K * d->R * d->S;
-    launch_igemm<MODE_DGRAD>(ksz_of(d), p, 1, (hipStream_t)stream);
-    return check_launch("conv2d_dgrad");
+    p.M = d->C; p.Kd = d->K * d->R * d->S;
+    const bool masked = mask_in || mult;
+    const int st = d->stride;
+    p.ncls = st * st;
+    int live = 0;
+    for (int par = 0; par < st; ++par) {
+        fill_class(par, d->R, st, d->pad, d->dil, &p.r0[par], &p.rstep[par], &p.nr[par], &p.offr0[par], &p.offrstep[par]);
+        fill_class(par, d->S, st, d->pad, d->dil, &p.s0[par], &p.sstep[par], &p.ns[par], &p.offs0[par], &p.offsstep[par]);
+    }
+    for (int c = 0; c < p.ncls; ++c)
+        if (p.nr[c / st] * p.ns[c % st] > 0) live |= 1 << c;
+    const int hc = (int)ceil_div(d->H, st), wc = (int)ceil_div(d->W, st);
+    p.Ncols = d->N * hc * wc;                    // the largest class (0,0) sizes the grid
+    const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, p.ncls), masked);
+    p.cpad = (int)ceil_div(d->K, kCfgs[cfg].bk) * kCfgs[cfg].bk;
+    if (st == 1) {
+        launch_igemm<MODE_DGRAD>(cfg, true, masked, p, 1, (hipStream_t)stream);
+        return check_launch("conv2d_dgrad");
+    }
+    // stride > 1: parity classes of input pixels, each a dense GEMM over the taps that reach it, written class-major to the
+    // staging buffer with full-line stores, then interleaved into dx (mask and accumulate applied there) in one streaming pass
+    const size_t need = p3d_conv2d_dgrad_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) {
+        set_error("conv2d_dgrad: strided path needs a %zu B workspace (got %zu)", need, workspace_bytes);
+        return P3D_EWORKSPACE;
+    }
+    p.staged = 1;
+    p.cls_stride = (size_t)d->N * d->C * hc * wc;
+    p.Cout = (float*)workspace;
+    p.mask_in = nullptr;
+    p.accumulate = 0;
+    launch_igemm<MODE_DGRAD>(cfg, true, masked && mult != nullptr, p, p.ncls, (hipStream_t)stream);
+    if (int32_t e = check_launch("conv2d_dgrad")) return e;
+    const int64_t total = (int64_t)d->N * d->C * d->H * d->W;
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(dgrad_interleave_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dx, mask_in,
+                       d->N * d->C, d->C, d->H, d->W, st, p.cls_stride, live, d->accumulate);
+    return check_launch("conv2d_dgrad interleave");
 }
 
 size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
-    const WgradPlan pl = plan_wgrad(d);
-    return (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
+    // the larger of the masked / unmasked plans, so one query serves both
+    const WgradPlan a = plan_wgrad(d, false), b = plan_wgrad(d, true);
+    const int splits = a.splits > b.splits ? a.splits : b.splits;
+    return (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
 int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x, const float* mult,
                          const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && x && dw, "conv2d_wgrad: null tensor");
-    const WgradPlan pl = plan_wgrad(d);
+    const bool masked = mask_in || mult;
+    const WgradPlan pl = plan_wgrad(d, masked);
     const size_t need = (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
     if (!workspace || workspace_bytes < need) {
         set_error("conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
         return P3D_EWORKSPACE;
     }
+    {
+        const int64_t span = pl.kchunk / ((int64_t)d->Ho * d->Wo) + 2;
+        const int64_t img = (int64_t)4 * (d->C * d->H * d->W > d->K * d->Ho * d->Wo ? d->C * d->H * d->W : d->K * d->Ho * d->Wo);
+        P3D_REQUIRE((span < d->N ? span : d->N) * img < (1ll << 31), "conv2d_wgrad: per-block window exceeds 2 GiB");
+    }
     IgemmParams p = base_params(d);
     p.A = dy; p.B = x; p.Cout = (float*)workspace; p.mask_in = mask_in; p.mult = mult;
     p.M = d->K; p.Ncols = d->C * d->R * d->S; p.Kd = d->N * d->Ho * d->Wo;
     p.kchunk = pl.kchunk;
-    launch_igemm<MODE_WGRAD>(ksz_of(d), p, pl.splits, (hipStream_t)stream);
+    p.cpad = d->C;
+    launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
-    const size_t total = (size_t)p.M * p.Ncols;
-    const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 2048 ? ceil_div((int64_t)total, 256) : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                       p.M, p.Ncols, pl.splits, p.ldw, p.woff, d->accumulate);
+    if (pl.tapm) {
+        const int RS = d->R * d->S;
+        hipLaunchKernelGGL(wgrad_reduce_tapm_kernel, dim3(d->K, d->C / REDUCE_CH), dim3(256), RS * REDUCE_CH * sizeof(float), (hipStream_t)stream,
+                           (const float*)workspace, dw, p.M, d->C, RS, pl.splits, p.ldw, p.woff, d->accumulate);
+    } else {
+        const size_t total = (size_t)p.M * p.Ncols;
+        const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 2048 ? ceil_div((int64_t)total, 256) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                           p.M, p.Ncols, pl.splits, p.ldw, p.woff, d->accumulate);
+    }
     return check_launch("conv2d_wgrad reduce");
 }
 
-int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, void* stream) {
+int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream) {
     P3D_REQUIRE(dy && db && N > 0 && K > 0 && HW > 0, "conv2d_bgrad: bad argument");
-    hipLaunchKernelGGL(bgrad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, db, N, K, HW);
+    hipLaunchKernelGGL(bgrad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, db, N, K, HW, accumulate);
     return check_launch("conv2d_bgrad");
 }
 

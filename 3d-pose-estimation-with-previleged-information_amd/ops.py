@@ -115,8 +115,9 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            ws = workspace(x.device, L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
             with _Timed('dgrad', d):
-                check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), st), 'p3d_conv2d_dgrad')
+                check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), _p(ws), ws.numel(), st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             nbytes = L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
@@ -125,7 +126,7 @@ class Conv2dFn(torch.autograd.Function):
                 check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(d.K, dtype=torch.float32, device=x.device)
-            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), st), 'p3d_conv2d_bgrad')
+            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), 0, st), 'p3d_conv2d_bgrad')
         return dx, dw, db, None, None, None, None, None
 
 
@@ -164,10 +165,10 @@ class ConvCat1x1Fn(torch.autograd.Function):
         dx = dyy = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.p3d_conv2d_dgrad(ctypes.byref(d1), _p(dy), _p(w), None, None, _p(dx), st), 'p3d_conv2d_dgrad')
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d1), _p(dy), _p(w), None, None, _p(dx), None, 0, st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[1]:
             dyy = torch.empty_like(y)
-            check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), st), 'p3d_conv2d_dgrad')
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), None, 0, st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[2]:
             dw = torch.empty_like(w)
             for d, inp in ((d1, x), (d2, y)):

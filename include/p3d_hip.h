@@ -61,9 +61,11 @@ typedef struct p3d_conv_desc {
 int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
                        const float* mask_in, const float* mult, float* y, void* stream);
 
-/* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x). */
+/* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x).  Stride-2 convolutions are
+ * computed as four dense parity-class GEMMs staged in `workspace` (query the size; 0 for stride 1). */
+size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d);
 int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
-                         const float* mask_in, float* dx, void* stream);
+                         const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[:, c_offset:c_offset+C] = wgrad(dy * mult, x * mask_in); deterministic two-stage split-K
  * reduction through `workspace`. */
@@ -71,8 +73,8 @@ size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x, const float* mult,
                          const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
-/* db[k] = sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
-int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, void* stream);
+/* db[k] (=|+=) sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
+int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream);
 
 /* partial_conv.py:35-43: cnt = boxsum(mask); mult = R*S/(cnt+1e-6)*clamp(cnt,0,1); mask_out = clamp(cnt,0,1).
  * mask [N,1,H,W] -> mult, mask_out [N,1,Ho,Wo]. */
