@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ stat2, int stat2_is_var, float eps,
                                                            const double* __restrict__ partial, int nsplit, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* dgamma, float* dbeta, int N, int C, int HW,
-                                                           int relu, int train) {
+                                                           int relu, int train, int accumulate) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < nsplit; ++i) {
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         s2 += partial[((size_t)c * nsplit + i) * 2 + 1];
     }
     if (s == 0 && threadIdx.x == 0) {
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     }
     const float mu = mean[c];
     const float is = stat2_is_var ? 1.f / sqrtf(stat2[c] + eps) : stat2[c];
@@ -303,7 +303,7 @@ int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, c
 
 static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* stat2,
                              int stat2_is_var, float eps, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
-                             int32_t HW, int32_t relu, int train, void* workspace, size_t workspace_bytes, void* stream) {
+                             int32_t HW, int32_t relu, int train, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     P3D_REQUIRE(dy && x && gamma && mean && stat2 && dx && dgamma && dbeta, "bn_bwd: null tensor");
     P3D_REQUIRE(!relu || y, "bn_bwd: relu backward needs the forward output");
     P3D_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd: bad shape %d %d %d", N, C, HW);
@@ -319,19 +319,19 @@ static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, co
     if (vec_ok(HW, dy, x, yy, dx, dres)) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
-                           dx, dres, dgamma, dbeta, N, C, HW, relu, train);
+                           dx, dres, dgamma, dbeta, N, C, HW, relu, train, accumulate);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
-                           dx, dres, dgamma, dbeta, N, C, HW, relu, train);
+                           dx, dres, dgamma, dbeta, N, C, HW, relu, train, accumulate);
     }
     return check_launch("bn_bwd");
 }
 
 int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                          const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
-                         int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
-    return bn_bwd_common(dy, x, y, gamma, save_mean, save_invstd, 0, 0.f, dx, dres, dgamma, dbeta, N, C, HW, relu, 1, workspace,
+                         int32_t HW, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_bwd_common(dy, x, y, gamma, save_mean, save_invstd, 0, 0.f, dx, dres, dgamma, dbeta, N, C, HW, relu, 1, accumulate, workspace,
                          workspace_bytes, stream);
 }
 
@@ -350,8 +350,8 @@ int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, co
 
 int32_t p3d_bn_eval_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* running_mean,
                         const float* running_var, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
-                        int32_t HW, float eps, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
-    return bn_bwd_common(dy, x, y, gamma, running_mean, running_var, 1, eps, dx, dres, dgamma, dbeta, N, C, HW, relu, 0, workspace,
+                        int32_t HW, float eps, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_bwd_common(dy, x, y, gamma, running_mean, running_var, 1, eps, dx, dres, dgamma, dbeta, N, C, HW, relu, 0, accumulate, workspace,
                          workspace_bytes, stream);
 }
 

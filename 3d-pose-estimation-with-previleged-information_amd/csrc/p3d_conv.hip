@@ -458,6 +458,19 @@ __global__ __launch_bounds__(256) void dgrad_interleave_kernel(const float* __re
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int Ncols,
                                                            int splits, int ldw, int woff, int accumulate) {
     const size_t total = (size_t)M * Ncols;
+    if (ldw == Ncols && woff == 0 && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(slab)) & 15) == 0) {
+        // contiguous destination: 16-B per lane
+        const float4* s4 = reinterpret_cast<const float4*>(slab);
+        float4* d4 = reinterpret_cast<float4*>(dw);
+        const size_t n4 = total >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 a = s4[i];
+            for (int z = 1; z < splits; ++z) { const float4 b = s4[(size_t)z * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (accumulate) { const float4 o = d4[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+            d4[i] = a;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
@@ -783,7 +796,7 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     p.cpad = d->C;
     launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
-    if (pl.tapm) {
+    if (pl.tapm && d->R * d->S > 1) {
         const int RS = d->R * d->S;
         hipLaunchKernelGGL(wgrad_reduce_tapm_kernel, dim3(d->K, d->C / REDUCE_CH), dim3(256), RS * REDUCE_CH * sizeof(float), (hipStream_t)stream,
                            (const float*)workspace, dw, p.M, d->C, RS, pl.splits, p.ldw, p.woff, d->accumulate);

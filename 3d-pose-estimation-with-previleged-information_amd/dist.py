@@ -71,7 +71,9 @@ class GradReducer:
         self._hooks = []
         if self.world > 1:
             for idx, p in enumerate(optimizer.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+                hook = self._make_hook(idx)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))       # gradients that arrive through autograd
+                p._p3d_grad_ready = (lambda h=hook, q=p: h(q))                        # gradients the HIP kernels wrote in place (ops._grad_done)
         self.reset()
 
     def reset(self):
@@ -108,6 +110,9 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.opt.params:
+            if hasattr(p, '_p3d_grad_ready'):
+                del p._p3d_grad_ready
 
 
 def global_valid_divisor(true_val, group=None):

@@ -67,6 +67,21 @@ def workspace(device, nbytes):
     return ws
 
 
+def _grad_sink(param):
+    """The preallocated .grad of a parameter owned by FlatAdam (flagged _p3d_direct_grad), or None.
+    Backward kernels accumulate straight into it (the buffer is zeroed once per step), so autograd's own
+    per-parameter add kernel and its temporary are skipped; the Function then returns None for that input."""
+    if param is not None and getattr(param, '_p3d_direct_grad', False) and param.grad is not None:
+        return param.grad
+    return None
+
+
+def _grad_done(param):
+    ready = getattr(param, '_p3d_grad_ready', None)       # set by dist.GradReducer: counts the bucket down
+    if ready is not None:
+        ready()
+
+
 def conv_out(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -102,6 +117,7 @@ class Conv2dFn(torch.autograd.Function):
             check(lib().p3d_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(mask_in), _p(mult), _p(y), _stream()), 'p3d_conv2d_fwd')
         ctx.save_for_backward(x, w, mask_in, mult)
         ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.params = (w, bias)
         return y
 
     @staticmethod
@@ -118,15 +134,25 @@ class Conv2dFn(torch.autograd.Function):
             ws = workspace(x.device, L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
             with _Timed('dgrad', d):
                 check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), _p(ws), ws.numel(), st), 'p3d_conv2d_dgrad')
+        w_param, b_param = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            sink = _grad_sink(w_param)
+            dw = torch.empty_like(w) if sink is None else sink
+            d.accumulate = 0 if sink is None else 1
             nbytes = L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
             ws = workspace(x.device, nbytes)
             with _Timed('wgrad', d):
                 check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
+            if sink is not None:
+                dw = None
+                _grad_done(w_param)
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(d.K, dtype=torch.float32, device=x.device)
-            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), 0, st), 'p3d_conv2d_bgrad')
+            sink = _grad_sink(b_param)
+            db = torch.empty(d.K, dtype=torch.float32, device=x.device) if sink is None else sink
+            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), 0 if sink is None else 1, st), 'p3d_conv2d_bgrad')
+            if sink is not None:
+                db = None
+                _grad_done(b_param)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -152,6 +178,7 @@ class ConvCat1x1Fn(torch.autograd.Function):
         check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
         check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
         ctx.save_for_backward(x, y, w)
+        ctx.w_param = w
         return out
 
     @staticmethod
@@ -170,10 +197,15 @@ class ConvCat1x1Fn(torch.autograd.Function):
             dyy = torch.empty_like(y)
             check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), None, 0, st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
+            sink = _grad_sink(ctx.w_param)
+            dw = torch.empty_like(w) if sink is None else sink
             for d, inp in ((d1, x), (d2, y)):
+                d.accumulate = 0 if sink is None else 1
                 ws = workspace(x.device, L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
                 check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(inp), None, None, _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
+            if sink is not None:
+                dw = None
+                _grad_done(ctx.w_param)
         return dx, dyy, dw
 
 
@@ -227,6 +259,7 @@ class BatchNormActFn(torch.autograd.Function):
                                     n, c, h * w, eps, int(relu), st), 'p3d_bn_eval_fwd')
             ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var)
         ctx.cfg = (bool(relu), bool(training), eps, res is not None)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -240,16 +273,23 @@ class BatchNormActFn(torch.autograd.Function):
         dres = None
         if has_res and ctx.needs_input_grad[5]:
             dres = torch.empty_like(x) if relu else dy      # without ReLU the residual gradient is dy itself
-        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty_like(dgamma)
+        g_param, b_param = ctx.params
+        g_sink, b_sink = _grad_sink(g_param), _grad_sink(b_param)
+        direct = g_sink is not None and b_sink is not None
+        dgamma = g_sink if direct else torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = b_sink if direct else torch.empty_like(dgamma)
         ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
         dres_ptr = _p(dres) if (dres is not None and relu) else None
         if training:
             check(L.p3d_bn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
-                                     n, c, h * w, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_train_bwd')
+                                     n, c, h * w, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_bn_train_bwd')
         else:
             check(L.p3d_bn_eval_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
-                                    n, c, h * w, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_eval_bwd')
+                                    n, c, h * w, eps, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_bn_eval_bwd')
+        if direct:
+            dgamma = dbeta = None
+            _grad_done(g_param)
+            _grad_done(b_param)
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 

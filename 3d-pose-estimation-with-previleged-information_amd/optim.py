@@ -49,6 +49,7 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+                p._p3d_direct_grad = True        # ops.py backward kernels accumulate straight into this buffer
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.param_groups = [dict(lr=lr), dict(lr=lr)]
         self.step_count = 0

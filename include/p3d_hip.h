@@ -97,10 +97,11 @@ int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, c
                          int32_t N, int32_t C, int32_t HW, float momentum, float eps, int32_t relu,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the above.  y is the forward output (its sign is the ReLU mask; ignored when relu == 0).
- * dres (may be NULL) receives the gradient of the residual input = masked dy. */
+ * dres (may be NULL) receives the gradient of the residual input = masked dy.
+ * accumulate != 0: dgamma / dbeta are added to (the caller's .grad buffers) instead of overwritten. */
 int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres,
-                         float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                         float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* eval / frozen statistics (model.eval() depth_train.py:611; freeze_batchnorm depthnet.py:158-161) */
 int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, const float* beta,
@@ -108,7 +109,7 @@ int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, co
                         int32_t N, int32_t C, int32_t HW, float eps, int32_t relu, void* stream);
 int32_t p3d_bn_eval_bwd(const float* dy, const float* x, const float* y, const float* gamma,
                         const float* running_mean, const float* running_var, float* dx, float* dres,
-                        float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, float eps, int32_t relu,
+                        float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, float eps, int32_t relu, int32_t accumulate,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* standalone F.relu (skip_relu variants, depthnet.py:197-198) */
