@@ -52,7 +52,7 @@ struct IgemmParams {
     int ldw;                // c_total*R*S : stride between filters in w
     int woff;               // c_offset*R*S
     int M, Ncols, Kd;
-    int kchunk;             // WGRAD: K extent per split (multiple of BK)
+    int kchunk;             // WGRAD: K extent per split (multiple of BK); FWD: K-steps per split (0 = no split)
     int accumulate;
     int tiles_m;
     int cpad;               // TAPM: reduction channels (C for FWD/WGRAD, K for DGRAD) rounded up to BK
@@ -68,11 +68,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
     const unsigned n = bytes < (size_t)MAX_RECORDS ? (unsigned)bytes : MAX_RECORDS;
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)n, 0x00020000);
 }
+// 16-B buffer load.  ROCm 7.2's __builtin_amdgcn_raw_buffer_load_b128 lowers to the *dword* intrinsic (checked in the IR), so the
+// v4f32 intrinsic is bound by name, with the resource as four dwords: {base lo, base hi, num_records, flags}.
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+__device__ f32x4v raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ i32x4 make_rsrc4(const float* base, size_t bytes) {
+    const unsigned n = bytes < (size_t)MAX_RECORDS ? (unsigned)bytes : MAX_RECORDS;
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    i32x4 r;
+    r[0] = (int)(unsigned)a; r[1] = (int)((a >> 32) & 0xffff); r[2] = (int)n; r[3] = 0x00020000;
+    return r;
+}
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int BK, bool TAPM, bool MASKED>
+// WV (WGRAD only): 0 = dword fetches; 1 = dy fetched as 16-B vectors along the pixel index (Ho*Wo % 4 == 0); 2 = x as well
+// (1x1, stride 1, no padding: im2col is the identity).  Low-channel layers (K, C <= 256 at 64x64) are HBM-streaming
+// problems at 32 FLOP/B, where 4x fewer, 4x wider loads matter.
+template <int MODE, int BM, int BN, int WM, int WN, int BK, bool TAPM, bool MASKED, int WV = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(MODE != MODE_DGRAD || TAPM, "dgrad always runs tap-major");
@@ -84,6 +99,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int A_PER = BM * BK / 256;
     constexpr int B_PER = BN * BK / 256;
     constexpr int K_ROWS = 256 / BK;            // rows (m or j) covered per pass of the k-fast mappings
+    constexpr bool VA = (MODE == MODE_WGRAD) && WV >= 1, VB = (MODE == MODE_WGRAD) && WV >= 2;
+    constexpr int KQ = BK / 4;                  // 16-B vectors per row of a K-step
+    constexpr int V_ROWS = 256 / KQ;            // rows covered per pass of the vector mapping
+    constexpr int A_VPER = (BM * KQ + 255) / 256, B_VPER = (BN * KQ + 255) / 256;
+    constexpr int A_PIECES = VA ? A_VPER : A_PER, B_PIECES = VB ? B_VPER : B_PER;
+    static_assert(WV == 0 || (MODE == MODE_WGRAD && !MASKED), "vector fetch is a WGRAD, unmasked variant");
     static_assert(A_PER * 256 == BM * BK && B_PER * 256 == BN * BK, "tile must be a multiple of the block");
     static_assert(256 % BN == 0 || B_KFAST, "column-fast B mapping needs BN | 256");
 
@@ -126,6 +147,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     } else {
         nk = TAPM ? RS * (p.cpad / BK) : (p.Kd + BK - 1) / BK;
     }
+    int kt_first = 0;                 // FWD split-K: this block reduces K-steps [kt_first, kt_first + nk) into slab blockIdx.y
+    if constexpr (MODE == MODE_FWD && TAPM) {
+        if (p.kchunk > 0) {
+            kt_first = blockIdx.y * p.kchunk;
+            nk = min(nk - kt_first, p.kchunk);
+        }
+    }
 
     // ---- wave-uniform buffer resources: w whole; x / dy from the first image this block touches ----
     int nfirst;
@@ -145,6 +173,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         rA = make_rsrc(p.A + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
         rB = make_rsrc(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
         rM = make_rsrc(nullptr, 0);
+    }
+    i32x4 rA4 = {0, 0, 0, 0}, rB4 = {0, 0, 0, 0};
+    if constexpr (MODE == MODE_WGRAD && WV >= 1) {
+        rA4 = make_rsrc4(p.A + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
+        rB4 = make_rsrc4(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
     }
     const bool use_mask = MASKED && (MODE == MODE_FWD ? p.mask_in != nullptr : (MODE == MODE_DGRAD ? p.mult != nullptr : false));
 
@@ -173,8 +206,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         wg_r = tp / p.S; wg_s = tp - wg_r * p.S;
     }
 
-    float ra[A_PER], rb[B_PER];
+    float ra[VA ? 4 * A_VPER : A_PER], rb[VB ? 4 * B_VPER : B_PER];
     int ld_tp = 0, ld_c0 = 0;         // tap and channel base of the next K-step to fetch (TAPM, FWD/DGRAD)
+    if constexpr (MODE == MODE_FWD && TAPM) {
+        ld_tp = (kt_first * BK) / p.cpad;
+        ld_c0 = kt_first * BK - ld_tp * p.cpad;
+    }
 
     // Every fetch is  buffer_load(rsrc, voffset | invalid, soffset):  voffset = the per-thread part, fixed over the K loop
     // (or recomputed once per K-step), soffset = the wave-uniform part (channel base, tap, row step) kept in SGPRs, and
@@ -201,112 +238,102 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
         b_base = ((cb_n * p.K + t / BN) * HoWo) * 4;
     }
+    int b_rowbad[VB ? B_VPER : 1];
     if constexpr (MODE == MODE_WGRAD) {
+        if constexpr (VA) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) a_voff[i] = (m0 + t / BK + K_ROWS * i) < p.M ? 0 : OOB;      // only the validity bit
-    }
-
-    auto load_tiles = [&](int kt) {
-        // ================= FWD =================
-        if constexpr (MODE == MODE_FWD) {
-            if constexpr (TAPM) {
-                const int r = ld_tp / p.S, s = ld_tp - r * p.S;
-                const int a_soff = (p.woff + ld_c0 * RS + ld_tp) * 4;
-                const int a_bad = (chan_pad && ld_c0 + t % BK >= chan_lim) ? OOB : 0;
+            for (int i = 0; i < A_VPER; ++i) {
+                const int row = t / KQ + V_ROWS * i;
+                a_voff[i] = (row < BM && m0 + row < p.M) ? 0 : OOB;
+            }
+        } else {
 #pragma unroll
-                for (int i = 0; i < A_PER; ++i)
-                    ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | a_bad, a_soff, 0));
-                const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
-                const bool okp = col_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const int pix = hi * p.W + wi;
-                const int voff = (b_base + pix * 4) | (okp ? 0 : OOB);
-                float mk = 1.f;
-                if constexpr (MASKED) { if (use_mask) mk = bload(rM, okp ? (cb_n * HW + pix) * 4 : OOB); }
+            for (int i = 0; i < A_PER; ++i) a_voff[i] = (m0 + t / BK + K_ROWS * i) < p.M ? 0 : OOB;      // only the validity bit
+        }
+        if constexpr (VB) {
 #pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int crow = ld_c0 + (256 / BN) * i;                      // uniform; this thread reads channel crow + t/BN
-                    const int bad = (chan_pad && crow + t / BN >= chan_lim) ? OOB : 0;
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff | bad, crow * HW * 4, 0));
-                    rb[i] = MASKED ? v * mk : v;
-                }
-            } else {
-                const int kbase = kt * BK;
-#pragma unroll
-                for (int i = 0; i < A_PER; ++i) {
-                    const int m = m0 + t / BK + K_ROWS * i, kk = kbase + t % BK;
-                    ra[i] = bload(rA, (m < p.M && kk < k_end) ? (m * p.ldw + p.woff + kk) * 4 : OOB);
-                }
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int kk = kbase + t / BN + (256 / BN) * i;
-                    const int c = kk / RS, rs = kk - c * RS;
-                    const int r = rs / p.S, s = rs - r * p.S;
-                    const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
-                    const bool ok = col_ok && kk < k_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                    float v = bload(rB, ok ? ((cb_n * p.C + c) * HW + hi * p.W + wi) * 4 : OOB);
-                    if constexpr (MASKED) { if (use_mask) v *= bload(rM, ok ? (cb_n * HW + hi * p.W + wi) * 4 : OOB); }
-                    rb[i] = v;
-                }
+            for (int i = 0; i < B_VPER; ++i) {
+                const int row = t / KQ + V_ROWS * i;
+                b_rowbad[i] = (row < BN && n0 + row < p.Ncols) ? 0 : OOB;
             }
         }
-        // ================= DGRAD (always tap-major over the taps of this parity class) =================
+    }
+
+    // The fetch of a K-step is cut into a prologue (wave-uniform tap / channel bookkeeping + the per-thread offset of the
+    // step) and A_PER + B_PER single loads, so that the main loop can drop one piece between two MFMAs: the matrix pipe is busy
+    // 64 cycles per MFMA and the wave's VALU / VMEM issue slots in that shadow are otherwise idle.
+    int st_a_soff = 0, st_a_bad = 0, st_b_voff = 0, st_b_soff0 = 0, st_tail = 0;   // st_tail = OOB when there is no next K-step
+    float st_a_scale = 1.f, st_b_scale = 1.f;
+
+    auto ld_prologue = [&](int kt) {
+        if constexpr (MODE == MODE_FWD && TAPM) {
+            const int r = ld_tp / p.S, s = ld_tp - r * p.S;
+            st_a_soff = (p.woff + ld_c0 * RS + ld_tp) * 4;
+            st_a_bad = (chan_pad && ld_c0 + t % BK >= chan_lim) ? OOB : 0;
+            const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
+            const bool okp = col_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int pix = hi * p.W + wi;
+            st_b_voff = (b_base + pix * 4) | (okp ? 0 : OOB);
+            st_b_soff0 = ld_c0;
+            if constexpr (MASKED) { if (use_mask) st_b_scale = bload(rM, okp ? (cb_n * HW + pix) * 4 : OOB); }
+        }
+        if constexpr (MODE == MODE_FWD && !TAPM) {
+            const int kbase = kt * BK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int m = m0 + t / BK + K_ROWS * i, kk = kbase + t % BK;
+                ra[i] = bload(rA, (m < p.M && kk < k_end) ? (m * p.ldw + p.woff + kk) * 4 : OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int kk = kbase + t / BN + (256 / BN) * i;
+                const int c = kk / RS, rs = kk - c * RS;
+                const int r = rs / p.S, s = rs - r * p.S;
+                const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
+                const bool ok = col_ok && kk < k_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                float v = bload(rB, ok ? ((cb_n * p.C + c) * HW + hi * p.W + wi) * 4 : OOB);
+                if constexpr (MASKED) { if (use_mask) v *= bload(rM, ok ? (cb_n * HW + hi * p.W + wi) * 4 : OOB); }
+                rb[i] = v;
+            }
+        }
         if constexpr (MODE == MODE_DGRAD) {
             const int ir = ld_tp / cls_ns, is = ld_tp - ir * cls_ns;
             const int r = p.r0[ph] + p.rstep[ph] * ir, s = p.s0[pw] + p.sstep[pw] * is;
             const int ho = cb_a + p.offr0[ph] - ir * p.offrstep[ph], wo = cb_b + p.offs0[pw] - is * p.offsstep[pw];
-            const int a_soff = (ld_c0 * p.ldw + p.woff + r * p.S + s) * 4;
-#pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int bad = (chan_pad && ld_c0 + (t + 256 * i) / BM >= chan_lim) ? OOB : 0;
-                ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | bad, a_soff, 0));
-            }
+            st_a_soff = (ld_c0 * p.ldw + p.woff + r * p.S + s) * 4;
             const bool okp = col_ok && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
             const int pix = ho * p.Wo + wo;
-            const int voff = (b_base + pix * 4) | (okp ? 0 : OOB);
-            float mk = 1.f;
-            if constexpr (MASKED) { if (use_mask) mk = bload(rM, okp ? (cb_n * HoWo + pix) * 4 : OOB); }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int qrow = ld_c0 + (256 / BN) * i;
-                const int bad = (chan_pad && qrow + t / BN >= chan_lim) ? OOB : 0;
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff | bad, qrow * HoWo * 4, 0));
-                rb[i] = MASKED ? v * mk : v;
-            }
+            st_b_voff = (b_base + pix * 4) | (okp ? 0 : OOB);
+            st_b_soff0 = ld_c0;
+            if constexpr (MASKED) { if (use_mask) st_b_scale = bload(rM, okp ? (cb_n * HoWo + pix) * 4 : OOB); }
         }
         if constexpr (MODE != MODE_WGRAD && TAPM) {
             ld_c0 += BK;
             if (ld_c0 >= p.cpad) { ld_c0 = 0; ++ld_tp; }
         }
-        // ================= WGRAD =================
         if constexpr (MODE == MODE_WGRAD) {
-            const int kk = k_begin + kt * BK + (t % BK);
+            const int kk = k_begin + kt * BK + (VA ? 4 * (t % KQ) : (t % BK));     // VA: first of 4 consecutive pixels (same image)
             const bool kok = kk < k_end;
             const int n = kk / HoWo, pp = kk - n * HoWo;
-            {
-                const int voff = ((((n - nfirst) * p.K + m0 + t / BK) * HoWo + pp) * 4) | (kok ? 0 : OOB);
-                float sc = 1.f;
-                if constexpr (MASKED) { if (p.mult) sc = kok ? p.mult[(size_t)n * HoWo + pp] : 0.f; }
-#pragma unroll
-                for (int i = 0; i < A_PER; ++i) {
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, voff | a_voff[i], K_ROWS * i * HoWo * 4, 0));
-                    ra[i] = MASKED ? v * sc : v;
-                }
-            }
-            const int ho = pp / p.Wo, wo = pp - ho * p.Wo;
-            const int hb = ho * p.stride - p.pad, wb = wo * p.stride - p.pad;
+            st_a_soff = ((((n - nfirst) * p.K + m0 + (VA ? t / KQ : t / BK)) * HoWo + pp) * 4) | (kok ? 0 : OOB);     // a voffset here
+            if constexpr (MASKED) { if (p.mult) st_a_scale = kok ? p.mult[(size_t)n * HoWo + pp] : 0.f; }
             const int nb = (n - nfirst) * p.C;
+            if constexpr (VB) {
+                // 1x1 / stride 1 / no padding: x[n][c][pp], 4 consecutive pixels per lane; with VA the scalar kk mapping is not used
+                st_b_voff = (((nb + (TAPM ? wg_c0 : n0) + t / KQ) * HW + pp) * 4) | (kok ? 0 : OOB);
+            } else {
+            const int kkb = VA ? k_begin + kt * BK + (t % BK) : kk;            // B keeps the dword mapping
+            const bool kokb = kkb < k_end;
+            const int nB = kkb / HoWo, ppB = kkb - nB * HoWo;
+            const int ho = ppB / p.Wo, wo = ppB - ho * p.Wo;
+            const int hb = ho * p.stride - p.pad, wb = wo * p.stride - p.pad;
+            const int nbB = (nB - nfirst) * p.C;
             if constexpr (TAPM) {
                 const int hi = hb + wg_r * p.dil, wi = wb + wg_s * p.dil;
-                const bool okp = kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const bool okp = kokb && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const int pix = hi * p.W + wi;
-                const int voff = (((nb + wg_c0 + t / BK) * HW + pix) * 4) | (okp ? 0 : OOB);
-                float mk = 1.f;
-                if constexpr (MASKED) { if (p.mask_in) mk = okp ? p.mask_in[(size_t)n * HW + pix] : 0.f; }
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, K_ROWS * i * HW * 4, 0));
-                    rb[i] = MASKED ? v * mk : v;
-                }
+                st_b_voff = (((nbB + wg_c0 + t / BK) * HW + pix) * 4) | (okp ? 0 : OOB);
+                if constexpr (MASKED) { if (p.mask_in) st_b_scale = okp ? p.mask_in[(size_t)nB * HW + pix] : 0.f; }
             } else {
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
@@ -314,16 +341,72 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     const int c = j / RS, rs = j - c * RS;
                     const int r = rs / p.S, s = rs - r * p.S;
                     const int hi = hb + r * p.dil, wi = wb + s * p.dil;
-                    const bool ok = kok && j < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                    float v = bload(rB, ok ? ((nb + c) * HW + hi * p.W + wi) * 4 : OOB);
-                    if constexpr (MASKED) { if (p.mask_in) v *= ok ? p.mask_in[(size_t)n * HW + hi * p.W + wi] : 0.f; }
+                    const bool ok = kokb && j < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && st_tail == 0;
+                    float v = bload(rB, ok ? ((nbB + c) * HW + hi * p.W + wi) * 4 : OOB);
+                    if constexpr (MASKED) { if (p.mask_in) v *= ok ? p.mask_in[(size_t)nB * HW + hi * p.W + wi] : 0.f; }
                     rb[i] = v;
                 }
             }
+            }
         }
+    };
+    auto ld_a = [&](int i) {
+        float v;
+        if constexpr (MODE == MODE_FWD) {
+            if constexpr (!TAPM) return;
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | st_a_bad | st_tail, st_a_soff, 0));
+        } else if constexpr (MODE == MODE_DGRAD) {
+            const int bad = (chan_pad && st_b_soff0 + (t + 256 * i) / BM >= chan_lim) ? OOB : 0;
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_voff[i] | bad | st_tail, st_a_soff, 0));
+        } else if constexpr (VA) {
+            const f32x4v q = raw_buffer_load_f32x4(rA4, st_a_soff | a_voff[i] | st_tail, V_ROWS * i * HoWo * 4, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[4 * i + j] = q[j];
+            return;
+        } else {
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, st_a_soff | a_voff[i] | st_tail, K_ROWS * i * HoWo * 4, 0));
+            if constexpr (MASKED) v *= st_a_scale;
+        }
+        ra[i] = v;
+    };
+    auto ld_b = [&](int i) {
+        float v;
+        if constexpr (VB) {
+            const f32x4v q = raw_buffer_load_f32x4(rB4, st_b_voff | b_rowbad[i] | st_tail, V_ROWS * i * HW * 4, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[4 * i + j] = q[j];
+            return;
+        } else if constexpr (MODE == MODE_WGRAD) {
+            if constexpr (!TAPM) return;
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, st_b_voff | st_tail, K_ROWS * i * HW * 4, 0));
+        } else {
+            if constexpr (!TAPM) return;
+            const int crow = st_b_soff0 + (256 / BN) * i;                       // uniform; this thread reads channel crow + t/BN
+            const int bad = (chan_pad && crow + t / BN >= chan_lim) ? OOB : 0;
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, st_b_voff | bad | st_tail, crow * (MODE == MODE_FWD ? HW : HoWo) * 4, 0));
+        }
+        if constexpr (MASKED) v *= st_b_scale;
+        rb[i] = v;
+    };
+    auto load_tiles = [&](int kt) {           // whole fetch at once (prologue of the K loop)
+        ld_prologue(kt);
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) ld_a(i);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) ld_b(i);
     };
 
     auto store_tiles = [&](int buf) {
+        if constexpr (VA) {
+#pragma unroll
+            for (int i = 0; i < A_VPER; ++i) {
+                const int row = t / KQ + V_ROWS * i;
+                if (row < BM) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) As[(buf * BK + 4 * (t % KQ) + j) * LDA + row] = ra[4 * i + j];
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int kk_l, m_l;
@@ -331,6 +414,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             else { kk_l = t % BK; m_l = t / BK + K_ROWS * i; }
             As[(buf * BK + kk_l) * LDA + m_l] = ra[i];
         }
+        if constexpr (VB) {
+#pragma unroll
+            for (int i = 0; i < B_VPER; ++i) {
+                const int row = t / KQ + V_ROWS * i;
+                if (row < BN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Bs[(buf * BK + 4 * (t % KQ) + j) * LDB + row] = rb[4 * i + j];
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             int kk_l, c_l;
@@ -357,7 +450,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+        // no branch on "is there a next K-step": the last iteration fetches with every lane out of range (st_tail), which costs no
+        // memory traffic and keeps the loop body one basic block, so the compiler's vmcnt bookkeeping stays exact
+        constexpr bool PIPELINED = TAPM;          // generic (stem) order: whole fetch up front, as before
+        st_tail = (kt + 1 < nk) ? 0 : OOB;
+        if constexpr (PIPELINED) ld_prologue(kt + 1);
+        else if (kt + 1 < nk) load_tiles(kt + 1);
         const float* a_base = As + (buf * BK + kh) * LDA + wm * (TM * 32) + li;
         const float* b_base = Bs + (buf * BK + kh) * LDB + wn * (TN * 32) + li;
         float av[2][TM], bv[2][TN];
@@ -365,21 +463,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int a = 0; a < TM; ++a) av[0][a] = a_base[32 * a];
 #pragma unroll
         for (int b = 0; b < TN; ++b) bv[0][b] = b_base[32 * b];
+        constexpr int NKP = BK / 2;
 #pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            if (kp + 1 < BK / 2) {           // operands of the next k-pair are in flight while this one's MFMAs issue
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (kp + 1 < NKP) {           // operands of the next k-pair are in flight while this one's MFMAs issue
 #pragma unroll
                 for (int a = 0; a < TM; ++a) av[(kp + 1) & 1][a] = a_base[2 * (kp + 1) * LDA + 32 * a];
 #pragma unroll
                 for (int b = 0; b < TN; ++b) bv[(kp + 1) & 1][b] = b_base[2 * (kp + 1) * LDB + 32 * b];
             }
+            // keep the LDS prefetch ahead of the MFMA group in program order (a wave's MFMAs issue back to back), and feed this
+            // k-pair's share of the next K-step's global fetch into the shadow of the first MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
+                for (int b = 0; b < TN; ++b) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp & 1][a], bv[kp & 1][b], acc[a][b], 0, 0, 0);
+                    if (a == 0 && b == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PIPELINED) {
+#pragma unroll
+                            for (int i = 0; i < A_PIECES; ++i) if (i % NKP == kp) ld_a(i);
+#pragma unroll
+                            for (int i = 0; i < B_PIECES; ++i) if (i % NKP == kp) ld_b(i);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (PIPELINED || kt + 1 < nk) store_tiles(buf ^ 1);      // (after the last K-step this stores zeros nobody reads)
         __syncthreads();
     }
 
@@ -393,7 +507,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         float scale = 1.f;
         if constexpr (MODE == MODE_FWD) {
             const int n = col / HoWo, pp = col - n * HoWo;
-            base = (size_t)n * p.K * HoWo + pp;
+            base = (size_t)n * p.K * HoWo + pp + (size_t)blockIdx.y * p.cls_stride;      // cls_stride = |y| when split-K slabs are in use, else 0
             rstride = HoWo;
             if constexpr (MASKED) { if (p.mult) scale = p.mult[(size_t)n * HoWo + pp]; }
         } else if constexpr (MODE == MODE_DGRAD) {
@@ -451,6 +565,30 @@ __global__ __launch_bounds__(256) void dgrad_interleave_kernel(const float* __re
         }
         if (mask_in) v *= mask_in[(nc / C) * H * W + (size_t)hi * W + wi];
         dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// y[n][k][p] (=|+=) sum_z slab[z][n][k][p] + bias[k]   (split-K forward)
+__global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict__ slab, float* __restrict__ y, const float* __restrict__ bias,
+                                                         size_t total, int K, int HoWo, int splits, int accumulate) {
+    if ((HoWo & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(slab)) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(slab);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        const size_t n4 = total >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 a = s4[i];
+            for (int z = 1; z < splits; ++z) { const float4 b = s4[(size_t)z * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (bias) { const float b = bias[((i << 2) / HoWo) % K]; a.x += b; a.y += b; a.z += b; a.w += b; }
+            if (accumulate) { const float4 o = y4[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+            y4[i] = a;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int z = 0; z < splits; ++z) a += slab[(size_t)z * total + i];
+        if (bias) a += bias[(i / HoWo) % K];
+        y[i] = accumulate ? y[i] + a : a;
     }
 }
 
@@ -584,7 +722,8 @@ static IgemmParams base_params(const p3d_conv_desc* d) {
 // ---- tile configurations --------------------------------------------------------------------------------
 struct TileCfg { int bm, bn, bk; double eff; };
 //                               128x128           64x256            96x128            64x128            128x64            64x64
-static const TileCfg kCfgs[6] = {{128, 128, 16, 1.0}, {64, 256, 16, 0.95}, {96, 128, 16, 0.95}, {64, 128, 16, 0.85}, {128, 64, 16, 0.85}, {64, 64, 32, 0.7}};
+static const TileCfg kCfgs[8] = {{128, 128, 16, 1.0}, {64, 256, 16, 0.95}, {96, 128, 16, 0.95}, {64, 128, 16, 0.85}, {128, 64, 16, 0.85}, {64, 64, 32, 0.7},
+                                 {128, 128, 32, 1.0}, {64, 128, 32, 0.85}};     // 6, 7: experimental BK = 32 shapes (P3D_FORCE_CFG only)
 constexpr int kSlots = 512;   // blocks resident at once (2 per CU) used to price the tail of a launch
 
 // cost ~ rounds of resident blocks x tile area / efficiency; `zmult` = extra grid factor (classes)
@@ -594,7 +733,7 @@ static int forced_cfg() {      // tuning aid: P3D_FORCE_CFG=0..5 pins the tile s
 }
 
 static int pick_cfg(int M, int Ncols, int64_t zmult) {
-    if (forced_cfg() >= 0 && forced_cfg() < 6) return forced_cfg();
+    if (forced_cfg() >= 0 && forced_cfg() < 8) return forced_cfg();
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < 6; ++i) {
@@ -607,8 +746,20 @@ static int pick_cfg(int M, int Ncols, int64_t zmult) {
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int BK>
-static void launch_variant(bool tapm, bool masked, dim3 grid, hipStream_t st, const IgemmParams& p) {
+static void launch_variant(bool tapm, bool masked, int wv, dim3 grid, hipStream_t st, const IgemmParams& p) {
     constexpr bool ALLOW_MASK = (BM == 128 && BN == 128) || (BM == 64 && BN == 256);
+    if constexpr (MODE == MODE_WGRAD) {
+        if (!masked && wv == 2) {
+            if (tapm) hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, false, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, false, 2>), grid, dim3(256), 0, st, p);
+            return;
+        }
+        if (!masked && wv == 1) {
+            if (tapm) hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, false, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, false, 1>), grid, dim3(256), 0, st, p);
+            return;
+        }
+    }
     if constexpr (ALLOW_MASK) {
         if (masked) {
             if constexpr (MODE != MODE_DGRAD) {
@@ -630,16 +781,18 @@ static int mask_cfg(int cfg, bool masked) {   // masked variants exist for the t
 }
 
 template <int MODE>
-static void launch_igemm(int cfg, bool tapm, bool masked, IgemmParams& p, int ny, hipStream_t st) {
+static void launch_igemm(int cfg, bool tapm, bool masked, IgemmParams& p, int ny, hipStream_t st, int wv = 0) {
     p.tiles_m = (int)ceil_div(p.M, kCfgs[cfg].bm);
     dim3 grid((unsigned)(p.tiles_m * ceil_div(p.Ncols, kCfgs[cfg].bn)), (unsigned)ny);
     switch (cfg) {
-        case 0: launch_variant<MODE, 128, 128, 2, 2, 16>(tapm, masked, grid, st, p); break;
-        case 1: launch_variant<MODE, 64, 256, 1, 4, 16>(tapm, masked, grid, st, p); break;
-        case 2: launch_variant<MODE, 96, 128, 1, 4, 16>(tapm, masked, grid, st, p); break;
-        case 3: launch_variant<MODE, 64, 128, 2, 2, 16>(tapm, masked, grid, st, p); break;
-        case 4: launch_variant<MODE, 128, 64, 2, 2, 16>(tapm, masked, grid, st, p); break;
-        default: launch_variant<MODE, 64, 64, 2, 2, 32>(tapm, masked, grid, st, p); break;
+        case 0: launch_variant<MODE, 128, 128, 2, 2, 16>(tapm, masked, wv, grid, st, p); break;
+        case 1: launch_variant<MODE, 64, 256, 1, 4, 16>(tapm, masked, wv, grid, st, p); break;
+        case 2: launch_variant<MODE, 96, 128, 1, 4, 16>(tapm, masked, wv, grid, st, p); break;
+        case 3: launch_variant<MODE, 64, 128, 2, 2, 16>(tapm, masked, wv, grid, st, p); break;
+        case 4: launch_variant<MODE, 128, 64, 2, 2, 16>(tapm, masked, wv, grid, st, p); break;
+        case 6: launch_variant<MODE, 128, 128, 2, 2, 32>(tapm, false, wv, grid, st, p); break;
+        case 7: launch_variant<MODE, 64, 128, 2, 2, 32>(tapm, false, wv, grid, st, p); break;
+        default: launch_variant<MODE, 64, 64, 2, 2, 32>(tapm, masked, wv, grid, st, p); break;
     }
 }
 
@@ -653,9 +806,10 @@ static WgradPlan plan_wgrad(const p3d_conv_desc* d, bool masked) {
     int cfg = -1;
     bool tapm = false;
     double best = 1e300;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 8; ++i) {
         if (masked && i > 1) break;
-        if (forced_cfg() >= 0 && forced_cfg() < 6 && i != forced_cfg() && !masked) continue;
+        if (!masked && forced_cfg() >= 0 && i != forced_cfg()) continue;
+        if (forced_cfg() < 0 && i >= 6) break;            // experimental shapes only when forced
         const bool tm = d->C % kCfgs[i].bn == 0;
         double cost = (double)ceil_div(M, kCfgs[i].bm) * kCfgs[i].bm * ceil_div(Ncols, kCfgs[i].bn) * kCfgs[i].bn / kCfgs[i].eff;
         if (!tm && d->R * d->S > 1) cost *= 1.3;          // generic per-element tap decode is slower
@@ -698,18 +852,69 @@ using namespace p3d;
 
 extern "C" {
 
+// Forward split-K: a launch of <= 400 long-K blocks leaves CUs with 1 or 2 blocks and no tail to even them out (ResNet-50's
+// 2048->272 regressor: 384 blocks x 1152 K-steps).  Splitting the K-steps 2-3 ways gives ~3 equal blocks per CU; the partial
+// outputs go to slabs in the workspace and one streaming pass sums them and adds the bias.
+struct FwdPlan { int cfg; bool tapm; int splits; int kchunk; };
+
+static FwdPlan plan_fwd(const p3d_conv_desc* d, bool masked, bool allow_split) {
+    FwdPlan pl;
+    const int M = d->K, Ncols = d->N * d->Ho * d->Wo;
+    pl.tapm = d->C >= 16;
+    pl.cfg = mask_cfg(pick_cfg(M, Ncols, 1), masked);
+    pl.splits = 1; pl.kchunk = 0;
+    if (!allow_split || masked || !pl.tapm || forced_cfg() >= 0) return pl;
+    // candidate: the tile with the least padded work if the grid had no tail; if that leaves <= 400 long blocks, split K
+    int cfgA = 0;
+    double best = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        const double cost = (double)ceil_div(M, kCfgs[i].bm) * kCfgs[i].bm * ceil_div(Ncols, kCfgs[i].bn) * kCfgs[i].bn / kCfgs[i].eff;
+        if (cost < best * 0.999) { best = cost; cfgA = i; }
+    }
+    const int64_t blocksA = ceil_div(M, kCfgs[cfgA].bm) * ceil_div(Ncols, kCfgs[cfgA].bn);
+    if (blocksA > 400) return pl;
+    const int cpad = (int)ceil_div(d->C, kCfgs[cfgA].bk) * kCfgs[cfgA].bk;
+    const int nk = d->R * d->S * (cpad / kCfgs[cfgA].bk);
+    int64_t splits = ceil_div(768, blocksA);
+    if (splits > nk / 32) splits = nk / 32;
+    if (splits > 8) splits = 8;
+    if (splits < 2) return pl;
+    pl.cfg = cfgA;
+    pl.kchunk = (int)ceil_div(nk, splits);
+    pl.splits = (int)ceil_div(nk, pl.kchunk);
+    if (pl.splits < 2) { pl.splits = 1; pl.kchunk = 0; pl.cfg = mask_cfg(pick_cfg(M, Ncols, 1), masked); }
+    return pl;
+}
+
+size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
+    if (validate(d)) return 0;
+    const FwdPlan pl = plan_fwd(d, false, true);
+    return pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0;
+}
+
 int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
-                       const float* mask_in, const float* mult, float* y, void* stream) {
+                       const float* mask_in, const float* mult, float* y, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
     p.M = d->K; p.Ncols = d->N * d->Ho * d->Wo; p.Kd = d->C * d->R * d->S;
     const bool masked = mask_in || mult;
-    const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, 1), masked);
-    const bool tapm = d->C >= 16;
-    p.cpad = (int)ceil_div(d->C, kCfgs[cfg].bk) * kCfgs[cfg].bk;
-    launch_igemm<MODE_FWD>(cfg, tapm, masked, p, 1, (hipStream_t)stream);
+    FwdPlan pl = plan_fwd(d, masked, true);
+    const size_t ysize = (size_t)d->N * d->K * d->Ho * d->Wo;
+    if (pl.splits > 1 && (!workspace || workspace_bytes < pl.splits * ysize * sizeof(float))) pl = plan_fwd(d, masked, false);   // no scratch: unsplit
+    p.cpad = (int)ceil_div(d->C, kCfgs[pl.cfg].bk) * kCfgs[pl.cfg].bk;
+    if (pl.splits > 1) {
+        p.Cout = (float*)workspace; p.bias = nullptr; p.accumulate = 0;
+        p.kchunk = pl.kchunk; p.cls_stride = ysize;
+        launch_igemm<MODE_FWD>(pl.cfg, true, false, p, pl.splits, (hipStream_t)stream);
+        if (int32_t e = check_launch("conv2d_fwd")) return e;
+        const unsigned blocks = (unsigned)(ceil_div((int64_t)ysize, 1024) < 4096 ? ceil_div((int64_t)ysize, 1024) : 4096);
+        hipLaunchKernelGGL(fwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, y, bias, ysize, d->K,
+                           d->Ho * d->Wo, pl.splits, d->accumulate);
+        return check_launch("conv2d_fwd reduce");
+    }
+    launch_igemm<MODE_FWD>(pl.cfg, pl.tapm, masked, p, 1, (hipStream_t)stream);
     return check_launch("conv2d_fwd");
 }
 
@@ -794,7 +999,13 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     p.M = d->K; p.Ncols = d->C * d->R * d->S; p.Kd = d->N * d->Ho * d->Wo;
     p.kchunk = pl.kchunk;
     p.cpad = d->C;
-    launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream);
+    int wv = 0;
+    if (!masked && (d->Ho * d->Wo) % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+        wv = 1;
+        if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) wv = 2;
+    }
+    { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
+    launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
     if (pl.tapm && d->R * d->S > 1) {
         const int RS = d->R * d->S;

@@ -113,8 +113,12 @@ class Conv2dFn(torch.autograd.Function):
         if x.shape[1] != w.shape[1]:
             raise P3DError('conv2d: input has %d channels, weight expects %d' % (x.shape[1], w.shape[1]))
         y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        L = lib()
+        nbytes = L.p3d_conv2d_fwd_workspace_bytes(ctypes.byref(d))
+        ws = workspace(x.device, nbytes) if nbytes else None
         with _Timed('fwd', d):
-            check(lib().p3d_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(mask_in), _p(mult), _p(y), _stream()), 'p3d_conv2d_fwd')
+            check(L.p3d_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(mask_in), _p(mult), _p(y), _p(ws), ws.numel() if ws is not None else 0,
+                                   _stream()), 'p3d_conv2d_fwd')
         ctx.save_for_backward(x, w, mask_in, mult)
         ctx.cfg = (stride, pad, dil, bias is not None)
         ctx.params = (w, bias)
@@ -175,8 +179,8 @@ class ConvCat1x1Fn(torch.autograd.Function):
         d1 = _desc(x.shape, w.shape, 1, 0, 1, c_offset=0, c_total=c1 + c2)
         d2 = _desc(y.shape, w.shape, 1, 0, 1, c_offset=c1, c_total=c1 + c2, accumulate=1)
         out = torch.empty((d1.N, d1.K, d1.Ho, d1.Wo), dtype=torch.float32, device=x.device)
-        check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
-        check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), st), 'p3d_conv2d_fwd')
+        check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), None, 0, st), 'p3d_conv2d_fwd')
+        check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), None, 0, st), 'p3d_conv2d_fwd')
         ctx.save_for_backward(x, y, w)
         ctx.w_param = w
         return out

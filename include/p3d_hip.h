@@ -59,7 +59,10 @@ typedef struct p3d_conv_desc {
  * partial_conv.py:45).  mult [N,1,Ho,Wo] or NULL (epilogue, partial_conv.py:53).  With both bias and
  * mult the result is ((raw-b)*mult + b)*mask_out with mask_out = (mult > 0)  (partial_conv.py:48-51). */
 int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
-                       const float* mask_in, const float* mult, float* y, void* stream);
+                       const float* mask_in, const float* mult, float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* Scratch for the split-K forward the library uses when a launch would leave most CUs one long block (0 otherwise; the
+ * workspace is optional: with NULL / too small the conv runs unsplit). */
+size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d);
 
 /* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x).  Stride-2 convolutions are
  * computed as four dense parity-class GEMMs staged in `workspace` (query the size; 0 for stride 1). */

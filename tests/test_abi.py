@@ -28,7 +28,7 @@ def test_version_and_error_string(pkg):
     lib = pkg._lib.lib()
     assert lib.p3d_version() == 100
     # a call with a null descriptor must fail cleanly with a message, without touching the GPU
-    code = lib.p3d_conv2d_fwd(None, None, None, None, None, None, None, None)
+    code = lib.p3d_conv2d_fwd(None, None, None, None, None, None, None, None, 0, None)
     assert code == -1
     assert b'null descriptor' in lib.p3d_last_error()
 

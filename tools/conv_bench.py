@@ -63,7 +63,8 @@ def main():
         st_ = ops._stream()
         p = ops._p
         gflop = 2.0 * a.batch * k * d.Ho * d.Wo * c * ks * ks / 1e9
-        t_f = timeit(lambda: L.p3d_conv2d_fwd(ctypes.byref(d), p(x), p(w), None, None, None, p(y), st_), a.iters) if a.mode in ('all', 'fwd') else 1e9
+        wsf = torch.empty(max(L.p3d_conv2d_fwd_workspace_bytes(ctypes.byref(d)), 16), dtype=torch.uint8, device='cuda')
+        t_f = timeit(lambda: L.p3d_conv2d_fwd(ctypes.byref(d), p(x), p(w), None, None, None, p(y), p(wsf), wsf.numel(), st_), a.iters) if a.mode in ('all', 'fwd') else 1e9
         wsd = torch.empty(max(L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)), 16), dtype=torch.uint8, device='cuda')
         t_d = timeit(lambda: L.p3d_conv2d_dgrad(ctypes.byref(d), p(dy), p(w), None, None, p(dx), p(wsd), wsd.numel(), st_), a.iters) if (c > 4 and a.mode in ('all', 'dgrad')) else 0.0
         t_w = timeit(lambda: L.p3d_conv2d_wgrad(ctypes.byref(d), p(dy), p(x), None, None, p(dw), p(ws), ws.numel(), st_), a.iters) if a.mode in ('all', 'wgrad') else 1e9
