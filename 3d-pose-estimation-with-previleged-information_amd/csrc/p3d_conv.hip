@@ -592,6 +592,27 @@ __global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict
     }
 }
 
+// First stage of a deep split-K reduction: slab[g] <- sum of slabs g, g+G, g+2G, ... (in place; only group g touches slab[g]).
+// A small dw with ~1000 slabs would otherwise be summed by a handful of blocks, each chasing 1000 dependent loads.
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slab, size_t total, int splits, int G) {
+    const int g = blockIdx.y;
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0) {
+        float4* s4 = reinterpret_cast<float4*>(slab);
+        const size_t n4 = total >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 a = s4[(size_t)g * n4 + i];
+            for (int z = g + G; z < splits; z += G) { const float4 b = s4[(size_t)z * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            s4[(size_t)g * n4 + i] = a;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float a = slab[(size_t)g * total + i];
+        for (int z = g + G; z < splits; z += G) a += slab[(size_t)z * total + i];
+        slab[(size_t)g * total + i] = a;
+    }
+}
+
 // dw[k][woff + j] (=|+=) sum_z slab[z][k][j]   (generic column order j = c*RS + rs)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int Ncols,
                                                            int splits, int ldw, int woff, int accumulate) {
@@ -1007,15 +1028,24 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
     launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
+    int nslab = pl.splits;
+    if (nslab > 16) {            // deep split: fold to <= 16 slabs with a grid that fills the chip, then the final (layout) pass
+        const size_t total = (size_t)p.M * p.Ncols;
+        const int G = 16;
+        const int64_t bx = ceil_div((int64_t)ceil_div((int64_t)total, 4), 256);
+        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)(bx < 256 ? bx : 256), G), dim3(256), 0, (hipStream_t)stream, (float*)workspace, total, nslab, G);
+        if (int32_t e = check_launch("conv2d_wgrad fold")) return e;
+        nslab = G;
+    }
     if (pl.tapm && d->R * d->S > 1) {
         const int RS = d->R * d->S;
         hipLaunchKernelGGL(wgrad_reduce_tapm_kernel, dim3(d->K, d->C / REDUCE_CH), dim3(256), RS * REDUCE_CH * sizeof(float), (hipStream_t)stream,
-                           (const float*)workspace, dw, p.M, d->C, RS, pl.splits, p.ldw, p.woff, d->accumulate);
+                           (const float*)workspace, dw, p.M, d->C, RS, nslab, p.ldw, p.woff, d->accumulate);
     } else {
         const size_t total = (size_t)p.M * p.Ncols;
         const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 2048 ? ceil_div((int64_t)total, 256) : 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                           p.M, p.Ncols, pl.splits, p.ldw, p.woff, d->accumulate);
+                           p.M, p.Ncols, nslab, p.ldw, p.woff, d->accumulate);
     }
     return check_launch("conv2d_wgrad reduce");
 }

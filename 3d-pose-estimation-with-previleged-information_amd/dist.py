@@ -28,7 +28,7 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'       # 'nccl' is RCCL on ROCm
+            backend = os.environ.get('P3D_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')   # 'nccl' is RCCL on ROCm
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
@@ -77,21 +77,30 @@ class GradReducer:
         self.reset()
 
     def reset(self):
+        self._seen = [False] * len(self.opt.params)      # a parameter counts once per step, whichever path reports it first
         self._pending = [len(m) for _, _, m in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
 
     def _make_hook(self, idx):
         def hook(param):
+            # Both paths can report one parameter: the HIP kernels signal as soon as they have written .grad in place
+            # (ops._grad_done), and autograd still runs the post-accumulate hook of a parameter whose Function returned None.
+            if self._seen[idx]:
+                return
+            self._seen[idx] = True
             b = self._bucket_of[idx]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
+            if self._pending[b] == 0 and not os.environ.get('P3D_REDUCE_AT_END'):      # debugging aid: defer every bucket to finish()
                 self._launch(b)
         return hook
 
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         self._launched[b] = True
+        if os.environ.get('P3D_REDUCE_BLOCKING'):                     # debugging aid
+            dist.all_reduce(self.opt.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.group)
+            return
         self._handles.append(dist.all_reduce(self.opt.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
