@@ -592,6 +592,31 @@ __global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict
     }
 }
 
+// stride-2 specialisation: 4 consecutive wi per thread = two 8-B reads from each of the row's two class buffers, one 16-B store
+__global__ __launch_bounds__(256) void dgrad_interleave2_kernel(const float* __restrict__ stage, float* __restrict__ dx, const float* __restrict__ mask_in,
+                                                                int NC, int C, int H, int W, size_t cls_stride, int live_mask, int accumulate) {
+    const int Wq = W >> 2, hc0 = (H + 1) >> 1, hc1 = H >> 1, wc = W >> 1;       // W % 4 == 0 -> both column classes are W/2 wide
+    const size_t total = (size_t)NC * H * Wq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wq = (int)(i % Wq);
+        const int hi = (int)((i / Wq) % H);
+        const size_t nc = i / ((size_t)Wq * H);
+        const int ph = hi & 1, ih = hi >> 1;
+        const size_t row = (nc * (ph ? hc1 : hc0) + ih) * wc + 2 * wq;
+        float2 a = {0.f, 0.f}, b = {0.f, 0.f};
+        if ((live_mask >> (ph * 2)) & 1) a = *reinterpret_cast<const float2*>(stage + (size_t)(ph * 2) * cls_stride + row);
+        if ((live_mask >> (ph * 2 + 1)) & 1) b = *reinterpret_cast<const float2*>(stage + (size_t)(ph * 2 + 1) * cls_stride + row);
+        float4 v = {a.x, b.x, a.y, b.y};
+        const size_t o = (nc * H + hi) * W + 4 * wq;
+        if (mask_in) {
+            const float4 m = *reinterpret_cast<const float4*>(mask_in + ((nc / C) * H + hi) * W + 4 * wq);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        }
+        if (accumulate) { const float4 p = *reinterpret_cast<const float4*>(dx + o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        *reinterpret_cast<float4*>(dx + o) = v;
+    }
+}
+
 // First stage of a deep split-K reduction: slab[g] <- sum of slabs g, g+G, g+2G, ... (in place; only group g touches slab[g]).
 // A small dw with ~1000 slabs would otherwise be summed by a handful of blocks, each chasing 1000 dependent loads.
 __global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slab, size_t total, int splits, int G) {
@@ -964,7 +989,9 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
         if (p.nr[c / st] * p.ns[c % st] > 0) live |= 1 << c;
     const int hc = (int)ceil_div(d->H, st), wc = (int)ceil_div(d->W, st);
     p.Ncols = d->N * hc * wc;                    // the largest class (0,0) sizes the grid
-    const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, p.ncls), masked);
+    int nlive = 0;
+    for (int c = 0; c < p.ncls; ++c) nlive += (live >> c) & 1;
+    const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, nlive > 0 ? nlive : 1), masked);     // classes no tap reaches exit at once
     p.cpad = (int)ceil_div(d->K, kCfgs[cfg].bk) * kCfgs[cfg].bk;
     if (st == 1) {
         launch_igemm<MODE_DGRAD>(cfg, true, masked, p, 1, (hipStream_t)stream);
@@ -985,6 +1012,12 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
     launch_igemm<MODE_DGRAD>(cfg, true, masked && mult != nullptr, p, p.ncls, (hipStream_t)stream);
     if (int32_t e = check_launch("conv2d_dgrad")) return e;
     const int64_t total = (int64_t)d->N * d->C * d->H * d->W;
+    if (st == 2 && d->W % 4 == 0 && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(mask_in)) & 15) == 0) {
+        const unsigned blocks4 = (unsigned)(ceil_div(total / 4, 256) < 8192 ? ceil_div(total / 4, 256) : 8192);
+        hipLaunchKernelGGL(dgrad_interleave2_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dx, mask_in,
+                           d->N * d->C, d->C, d->H, d->W, p.cls_stride, live, d->accumulate);
+        return check_launch("conv2d_dgrad interleave");
+    }
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(dgrad_interleave_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dx, mask_in,
                        d->N * d->C, d->C, d->H, d->W, st, p.cls_stride, live, d->accumulate);

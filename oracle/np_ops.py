@@ -342,3 +342,72 @@ def adapt_learn_rate(epoch, learn_rate, warmup=1, warmup_factor=0.2, learn_decay
     if epoch - 1 < 25:
         return learn_rate * learn_decay * learn_decay
     return learn_rate * learn_decay * learn_decay * learn_decay
+
+
+# --------------------------------------------------------------------------------------
+# colour / eraser augmentation (augment_colour.py:6-67, augment_occluder.py:84-105).
+# PARITY UNPINNED for the HSV steps: the reference calls cv2.cvtColor on float32 images and cv2 is
+# neither vendored nor installed, and the reference has no fixture for it.  The restatement follows
+# OpenCV's documented float conventions (H in [0,360), S,V in [0,1], V = max, S = (V-min)/V,
+# H = 60*(G-B)/(V-min) [+120, +240 by argmax], +360 if negative).  Brightness / contrast / the final
+# uint8 truncation / the eraser are plain numpy in the reference and are restated exactly.
+# --------------------------------------------------------------------------------------
+
+def rgb_to_hsv(rgb):
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    v = np.max(rgb, axis=-1)
+    mn = np.min(rgb, axis=-1)
+    diff = v - mn
+    eps = np.float32(1.1920929e-07)
+    s = np.where(v > eps, diff / np.where(v > eps, v, 1), 0).astype(np.float32)
+    safe = np.where(diff > eps, diff, 1)
+    h = np.where(v == r, (g - b) * (60 / safe), np.where(v == g, (b - r) * (60 / safe) + 120, (r - g) * (60 / safe) + 240))
+    h = np.where(diff > eps, h, 0)
+    h = np.where(h < 0, h + 360, h).astype(np.float32)
+    return np.stack([h, s, v], axis=-1)
+
+
+def hsv_to_rgb(hsv):
+    h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+    hh = h / np.float32(60)
+    sector = np.floor(hh)
+    f = (hh - sector).astype(np.float32)
+    sector = (sector.astype(np.int64) % 6 + 6) % 6
+    p = v * (1 - s)
+    q = v * (1 - s * f)
+    t = v * (1 - s * (1 - f))
+    table = [(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]
+    out = np.zeros(hsv.shape, dtype=np.float32)
+    for k, (rr, gg, bb) in enumerate(table):
+        m = sector == k
+        out[..., 0] = np.where(m, rr, out[..., 0])
+        out[..., 1] = np.where(m, gg, out[..., 1])
+        out[..., 2] = np.where(m, bb, out[..., 2])
+    return out
+
+
+def augment_colour(image_hwc, brightness, contrast, hue, saturation):
+    """random_color with its four draws made explicit: image [H,W,3] holding 0..255 values -> same, truncated to integers."""
+    x = (image_hwc / 255.0).astype(np.float32)
+    x = np.clip(x + np.float32(brightness), 0, 1)                                   # augment_colour.py:6-12
+    x = np.clip((x - np.float32(0.5)) * np.float32(contrast) + np.float32(0.5), 0, 1)   # :15-24
+    hsv = rgb_to_hsv(x.astype(np.float32))
+    hsv[..., 0] += np.float32(hue)                                                  # :27-36
+    hsv[..., 0][hsv[..., 0] < 0] += 360
+    hsv[..., 0][hsv[..., 0] >= 360] -= 360
+    hsv[..., 1] = np.clip(hsv[..., 1] * np.float32(saturation), 0, 1)               # :39-45
+    x = hsv_to_rgb(hsv)
+    return np.floor(np.clip(x * np.float32(255), 0, 255)).astype(np.float32)        # (dest * 255).astype(np.uint8), :67
+
+
+def erase_rect(image_shape_hw, area_frac, aspect, start_frac):
+    """random_erase geometry (augment_occluder.py:87-101) with its draws made explicit -> (x0, y0, x1, y1)."""
+    h, w = image_shape_hw
+    erase_area = area_frac * h * w
+    eh = (erase_area * aspect) ** 0.5
+    ew = (erase_area / aspect) ** 0.5
+    start = (np.array([h, w]) - np.array([eh, ew])) * np.asarray(start_frac)
+    end = start + np.array([eh, ew])
+    start = np.round(start).astype(int)
+    end = np.round(end).astype(int)
+    return int(start[1]), int(start[0]), int(end[1]), int(end[0])

@@ -241,3 +241,25 @@ def test_clip_and_adam_two_steps(pkg):
 def test_ops_refuse_cpu_tensors(pkg):
     with pytest.raises(pkg._lib.P3DError):
         pkg.ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+def test_augment_colour_and_erase(pkg):
+    """On-GPU colour augmentation and eraser (config 5) against the numpy restatement (HSV part: parity unpinned, see oracle)."""
+    ops = pkg.ops
+    rng = np.random.default_rng(21)
+    b, h, w = 3, 32, 40
+    img = np.floor(rng.random((b, 3, h, w)) * 256).astype(np.float32)
+    img[0, :, :4, :4] = 128.0                                       # a grey patch: zero saturation, hue undefined
+    img[1, :, 5, 5] = [255, 0, 0]
+    params = np.stack([rng.uniform(-0.125, 0.125, b), rng.uniform(0.8, 1.25, b), rng.uniform(-18, 18, b), rng.uniform(0.8, 1.25, b)], 1).astype(np.float32)
+    want = np.stack([ref.augment_colour(img[i].transpose(1, 2, 0), *params[i]).transpose(2, 0, 1) for i in range(b)])
+    got = host(ops.augment_colour_(dev(img), dev(params)))
+    diff = np.abs(got - want)
+    assert (diff > 1).sum() == 0 and (diff > 0).mean() < 0.01      # at most a rounding flip of the final truncation
+    rects = np.array([ref.erase_rect((h, w), 0.2, 1.5, (0.3, 0.6)), ref.erase_rect((h, w), 0.1, 0.5, (1.0, 1.0)), (5, 5, 5, 9)], dtype=np.int32)
+    colour = np.floor(rng.random((b, 3)) * 256).astype(np.float32)
+    want = img.copy()
+    for i, (x0, y0, x1, y1) in enumerate(rects):
+        want[i, :, max(y0, 0):y1, max(x0, 0):x1] = colour[i][:, None, None]
+    got = host(ops.augment_erase_(dev(img), torch.from_numpy(rects).cuda(), dev(colour)))
+    assert np.array_equal(got, want)
