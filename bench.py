@@ -112,6 +112,13 @@ def main():
             conv_flops += flops
         conv_total_ms = sum(conv_ms.values())
         launches = len(prof)
+        # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r01_traffic.json);
+        # a profiler cannot run inside the timed region, so the committed measurement of the same workload is quoted
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64:
+            with open(tpath) as f:
+                traffic = round(json.load(f)['bytes_per_launch_raw'])
         gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if opt.model == 'resnet50' else conv_flops / 1e9 / (opt.batch * opt.steps)
         achieved = gflop_crop * opt.batch * opt.steps / conv_total_ms          # GFLOP/ms == TFLOP/s
         out = {
@@ -123,7 +130,7 @@ def main():
                                    'RCCL grad all-reduce + clip + Adam' % (opt.model, opt.batch),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'launches_per_step': launches // max(opt.steps, 1),
                          'avg_launch_ms': round(conv_total_ms / max(launches, 1), 4),
                          'conv_ms_per_step': {k: round(v / opt.steps, 3) for k, v in conv_ms.items()},
