@@ -67,6 +67,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise P3DError('libp3d_hip.so is not built (%s missing): run __graft_entry__.build() or `make -C %s`'
                            % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime in the process BEFORE this library is mapped, or
+        # the kernels would be launched through a second runtime instance that owns no device ("no ROCm-capable device").
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
