@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         nk = (k_end - k_begin + BK - 1) / BK;
     } else if constexpr (MODE == MODE_DGRAD) {
         // parity class of this block (uniform): pixels hi = ph + stride*i, wi = pw + stride*j
-        const int cls = blockIdx.y;
+        const int cls = p.kchunk > 0 ? 0 : blockIdx.y;      // (stride-1 split-K uses blockIdx.y for the K slice instead)
         ph = cls / p.stride; pw = cls - ph * p.stride;
         Hc = (p.H - ph + p.stride - 1) / p.stride;
         Wc = (p.W - pw + p.stride - 1) / p.stride;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     } else {
         nk = TAPM ? RS * (p.cpad / BK) : (p.Kd + BK - 1) / BK;
     }
-    int kt_first = 0;                 // FWD split-K: this block reduces K-steps [kt_first, kt_first + nk) into slab blockIdx.y
-    if constexpr (MODE == MODE_FWD && TAPM) {
+    int kt_first = 0;                 // FWD / stride-1 DGRAD split-K: this block reduces K-steps [kt_first, kt_first + nk) into slab blockIdx.y
+    if constexpr ((MODE == MODE_FWD || MODE == MODE_DGRAD) && TAPM) {
         if (p.kchunk > 0) {
             kt_first = blockIdx.y * p.kchunk;
             nk = min(nk - kt_first, p.kchunk);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     float ra[VA ? 4 * A_VPER : A_PER], rb[VB ? 4 * B_VPER : B_PER];
     int ld_tp = 0, ld_c0 = 0;         // tap and channel base of the next K-step to fetch (TAPM, FWD/DGRAD)
-    if constexpr (MODE == MODE_FWD && TAPM) {
+    if constexpr ((MODE == MODE_FWD || MODE == MODE_DGRAD) && TAPM) {
         ld_tp = (kt_first * BK) / p.cpad;
         ld_c0 = kt_first * BK - ld_tp * p.cpad;
     }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 base = (size_t)blockIdx.y * p.cls_stride + (size_t)n * p.C * hw + pix;
                 rstride = hw;
             } else {
-                base = (size_t)n * p.C * HW + pix;
+                base = (size_t)n * p.C * HW + pix + (size_t)blockIdx.y * p.cls_stride;      // (+ slab offset under split-K, else 0)
                 rstride = HW;
                 if constexpr (MASKED) { if (p.mask_in) scale = p.mask_in[(size_t)n * HW + pix]; }
             }
@@ -964,8 +964,41 @@ int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, c
     return check_launch("conv2d_fwd");
 }
 
+// stride-1 dgrad split-K, same reasoning as the forward one (few long blocks: 256 -> 256 3x3 at 16x16 is 256 blocks x 144 K-steps)
+static FwdPlan plan_dgrad1(const p3d_conv_desc* d, bool masked) {
+    FwdPlan pl;
+    const int M = d->C, Ncols = d->N * d->H * d->W;
+    pl.tapm = true;
+    pl.cfg = mask_cfg(pick_cfg(M, Ncols, 1), masked);
+    pl.splits = 1; pl.kchunk = 0;
+    if (masked || forced_cfg() >= 0) return pl;
+    int cfgA = 0;
+    double best = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        const double cost = (double)ceil_div(M, kCfgs[i].bm) * kCfgs[i].bm * ceil_div(Ncols, kCfgs[i].bn) * kCfgs[i].bn / kCfgs[i].eff;
+        if (cost < best * 0.999) { best = cost; cfgA = i; }
+    }
+    const int64_t blocksA = ceil_div(M, kCfgs[cfgA].bm) * ceil_div(Ncols, kCfgs[cfgA].bn);
+    if (blocksA > 400) return pl;
+    const int cpad = (int)ceil_div(d->K, kCfgs[cfgA].bk) * kCfgs[cfgA].bk;
+    const int nk = d->R * d->S * (cpad / kCfgs[cfgA].bk);
+    int64_t splits = ceil_div(768, blocksA);
+    if (splits > nk / 32) splits = nk / 32;
+    if (splits > 8) splits = 8;
+    if (splits < 2) return pl;
+    pl.cfg = cfgA;
+    pl.kchunk = (int)ceil_div(nk, splits);
+    pl.splits = (int)ceil_div(nk, pl.kchunk);
+    if (pl.splits < 2) { pl.splits = 1; pl.kchunk = 0; pl.cfg = mask_cfg(pick_cfg(M, Ncols, 1), masked); }
+    return pl;
+}
+
 size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
-    if (validate(d) || d->stride == 1) return 0;
+    if (validate(d)) return 0;
+    if (d->stride == 1) {
+        const FwdPlan pl = plan_dgrad1(d, false);
+        return pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0;
+    }
     const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
     return (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
 }
@@ -994,6 +1027,18 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
     const int cfg = mask_cfg(pick_cfg(p.M, p.Ncols, nlive > 0 ? nlive : 1), masked);     // classes no tap reaches exit at once
     p.cpad = (int)ceil_div(d->K, kCfgs[cfg].bk) * kCfgs[cfg].bk;
     if (st == 1) {
+        const FwdPlan pl = plan_dgrad1(d, masked);
+        const size_t xsize = (size_t)d->N * d->C * d->H * d->W;
+        if (pl.splits > 1 && workspace && workspace_bytes >= pl.splits * xsize * sizeof(float)) {
+            p.cpad = (int)ceil_div(d->K, kCfgs[pl.cfg].bk) * kCfgs[pl.cfg].bk;
+            p.Cout = (float*)workspace; p.accumulate = 0; p.kchunk = pl.kchunk; p.cls_stride = xsize;
+            launch_igemm<MODE_DGRAD>(pl.cfg, true, false, p, pl.splits, (hipStream_t)stream);
+            if (int32_t e = check_launch("conv2d_dgrad")) return e;
+            const unsigned rb = (unsigned)(ceil_div((int64_t)xsize, 1024) < 4096 ? ceil_div((int64_t)xsize, 1024) : 4096);
+            hipLaunchKernelGGL(fwd_reduce_kernel, dim3(rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dx, (const float*)nullptr, xsize,
+                               d->C, d->H * d->W, pl.splits, d->accumulate);
+            return check_launch("conv2d_dgrad reduce");
+        }
         launch_igemm<MODE_DGRAD>(cfg, true, masked, p, 1, (hipStream_t)stream);
         return check_launch("conv2d_dgrad");
     }

@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='crops per GPU')
     ap.add_argument('--model', default='resnet50')
+    ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet'],
+                    help='informational runs of BASELINE configs 4/5; the contract line is depthnet (config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     opt = ap.parse_args()
@@ -67,7 +69,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
-    args = pkg.opts.parse(['-model', opt.model] + FLAGS)
+    extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv']}[opt.family]
+    args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra)
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model, _ = pkg.depth_main.create_model(args)
     model = model.to(device).train()
@@ -79,7 +82,9 @@ def main():
     batches = []
     for i in range(nbuf):
         c, d, tc, tv = pkg.synth.make_batch(opt.batch, side=256, rank=rank, step=i)
-        batches.append((torch.from_numpy(c).to(device), None, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
+        color = torch.from_numpy(c).to(device) if opt.family != 'partial_depthnet' else None
+        depth = torch.from_numpy(d).to(device) if opt.family != 'depthnet' else None
+        batches.append((color, depth, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
 
     def sync():
         if world > 1:
@@ -119,15 +124,15 @@ def main():
         if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64:
             with open(tpath) as f:
                 traffic = round(json.load(f)['bytes_per_launch_raw'])
-        gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if opt.model == 'resnet50' else conv_flops / 1e9 / (opt.batch * opt.steps)
+        gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if (opt.model == 'resnet50' and opt.family == 'depthnet') else conv_flops / 1e9 / (opt.batch * opt.steps)
         achieved = gflop_crop * opt.batch * opt.steps / conv_total_ms          # GFLOP/ms == TFLOP/s
         out = {
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'depthnet %s RGB pose head, 256x256x3 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
-                                   'RCCL grad all-reduce + clip + Adam' % (opt.model, opt.batch),
+            'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
+                                   'RCCL grad all-reduce + clip + Adam' % (opt.family, opt.model, opt.batch),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -136,7 +141,7 @@ def main():
                          'conv_ms_per_step': {k: round(v / opt.steps, 3) for k, v in conv_ms.items()},
                          'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1)},
         }
-        if world == 1 and not opt.no_cpu_baseline:
+        if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet':
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:

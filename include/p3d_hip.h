@@ -65,7 +65,8 @@ int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, c
 size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d);
 
 /* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x).  Stride-2 convolutions are
- * computed as four dense parity-class GEMMs staged in `workspace` (query the size; 0 for stride 1). */
+ * computed as four dense parity-class GEMMs staged in `workspace`; a stride-1 launch of few long blocks is split over K into
+ * slabs there (optional: without workspace it runs unsplit).  Query the size; 0 when none is used. */
 size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d);
 int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
                          const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream);
