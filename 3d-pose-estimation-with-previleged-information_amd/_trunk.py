@@ -52,33 +52,40 @@ class _ResidualBlock(nn.Module):
         self.skip_relu = skip_relu
         self.partial = partial
 
-    def _shortcut(self, x):
+    def _shortcut(self, x, join):
+        """Returns (res, res_join): with a downsample branch its conv hands its input gradient to `join`; an identity shortcut lets
+        the closing BN hand over the residual gradient instead."""
         if self.downsample is None:
-            return x
-        return self.downsample[1](self.downsample[0](x))
+            return x, join
+        return self.downsample[1](self.downsample[0](x, join_put=join)), None
 
     def forward(self, x):
         if self.partial:                      # partial_depthnet.py:44-46: blocks receive an (x, veil) tuple
             return self.forward_partial(*x)
+        # the block input fans out to conv1 and the shortcut: join the two input gradients inside conv1's dgrad kernel (ops.GradJoin)
+        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1
         for i, (cname, bname) in enumerate(self._chain):
-            out = getattr(self, cname)(out)
+            out = getattr(self, cname)(out, join_take=join) if i == 0 else getattr(self, cname)(out)
             if i < last:
                 out = getattr(self, bname)(out, relu=True)
             else:
-                out = getattr(self, bname)(out, res=self._shortcut(x), relu=not self.skip_relu)
+                res, res_join = self._shortcut(x, join)
+                out = getattr(self, bname)(out, res=res, relu=not self.skip_relu, res_join=res_join)
         return out
 
     def forward_partial(self, x, veil):
+        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1
         for i, (cname, bname) in enumerate(self._chain):
-            out, veil = getattr(self, cname)(out, veil)
+            out, veil = getattr(self, cname)(out, veil, join_take=join) if i == 0 else getattr(self, cname)(out, veil)
             if i < last:
                 out = getattr(self, bname)(out, relu=True)
             else:
-                out = getattr(self, bname)(out, res=self._shortcut(x), relu=True)   # shortcut stays dense (partial_depthnet.py:70-75)
+                res, res_join = self._shortcut(x, join)                             # shortcut stays dense (partial_depthnet.py:70-75)
+                out = getattr(self, bname)(out, res=res, relu=True, res_join=res_join)
         return out, veil
 
 

@@ -126,6 +126,7 @@ class Trainer:
         self.last_spec_cam = spec_cam
         self.optimizer.zero_grad()
         loss.backward()
+        assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
         scale = self.reducer.finish()
         self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
         return loss.detach()

@@ -28,15 +28,16 @@ class Conv2d(nn.Conv2d):
         if self.groups != 1 or self.padding_mode != 'zeros' or isinstance(self.padding, str):
             raise ops.P3DError('Conv2d: groups != 1 / non-zero padding modes are not on the hot path')
 
-    def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation))
+    def forward(self, x, join_put=None, join_take=None):
+        return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation),
+                          join_put=join_put, join_take=join_take)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d; forward(x, res=None, relu=False) fuses the residual add and the ReLU that the
     reference applies right after it (depthnet.py:42-56,98-116)."""
 
-    def forward(self, x, res=None, relu=False):
+    def forward(self, x, res=None, relu=False, res_join=None):
         if not (self.affine and self.track_running_stats):
             raise ops.P3DError('BatchNorm2d: only affine=True, track_running_stats=True is on the hot path')
         training = self.training
@@ -44,7 +45,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         if training:
             self.num_batches_tracked.add_(1)
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training,
-                                  momentum, self.eps)
+                                  momentum, self.eps, res_join)
 
 
 class MaxPool2d(nn.MaxPool2d):

@@ -101,12 +101,35 @@ def _desc(x_shape, w_shape, stride, pad, dil, c_offset=0, c_total=None, accumula
 
 
 # --------------------------------------------------------------------------------------------
+class GradJoin:
+    """Where a tensor fans out inside a residual block (block input -> first conv + shortcut), autograd would sum the two
+    gradients with an extra elementwise pass (read 2, write 1 over the block input).  A GradJoin hands the gradient that is
+    produced FIRST (the shortcut's: residual gradient of the closing BN, or the dgrad of the downsample conv) to the op that runs
+    LAST (the first conv of the main path, created first in forward, hence last in backward), whose dgrad kernel then accumulates
+    into that buffer (`accumulate = 1`).  The producer returns None to autograd, the consumer returns the joined buffer.
+    If the consumer finds the slot empty it behaves normally, so a different execution order costs speed, never correctness;
+    `pending_joins()` lets the trainer assert that no produced gradient was left unconsumed."""
+    __slots__ = ('buf', '__weakref__')
+    _live = None
+
+    def __init__(self):
+        self.buf = None
+        if GradJoin._live is None:
+            import weakref
+            GradJoin._live = weakref.WeakSet()
+        GradJoin._live.add(self)
+
+
+def pending_joins():
+    return 0 if GradJoin._live is None else sum(1 for j in GradJoin._live if j.buf is not None)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (depthnet.py:16-33,65-89,138,156) and, with mask_in/mult, PartialConv's masked,
-    renormalised convolution (partial_conv.py:45-53)."""
+    renormalised convolution (partial_conv.py:45-53).  join_put / join_take: see GradJoin."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, mask_in, mult, stride, pad, dil):
+    def forward(ctx, x, w, bias, mask_in, mult, stride, pad, dil, join_put=None, join_take=None):
         _need_gpu(x, w, bias, mask_in, mult)
         x, w = x.contiguous(), w.contiguous()
         d = _desc(x.shape, w.shape, stride, pad, dil)
@@ -122,22 +145,32 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, mask_in, mult)
         ctx.cfg = (stride, pad, dil, bias is not None)
         ctx.params = (w, bias)
+        ctx.joins = (join_put, join_take)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mask_in, mult = ctx.saved_tensors
         stride, pad, dil, has_bias = ctx.cfg
+        join_put, join_take = ctx.joins
         dy = dy.contiguous()
         d = _desc(x.shape, w.shape, stride, pad, dil)
         L = lib()
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            joined = join_take.buf if join_take is not None else None
+            if joined is not None and joined.shape == x.shape:
+                dx, join_take.buf = joined, None              # accumulate onto the shortcut's gradient: no separate add pass
+                d.accumulate = 1
+            else:
+                dx = torch.empty_like(x)
             ws = workspace(x.device, L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
             with _Timed('dgrad', d):
                 check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), _p(ws), ws.numel(), st), 'p3d_conv2d_dgrad')
+            d.accumulate = 0
+            if join_put is not None:
+                join_put.buf, dx = dx, None                   # the consumer returns it
         w_param, b_param = ctx.params
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(w_param)
@@ -157,11 +190,11 @@ class Conv2dFn(torch.autograd.Function):
             if sink is not None:
                 db = None
                 _grad_done(b_param)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, mask_in=None, mult=None):
-    return Conv2dFn.apply(x, w, bias, mask_in, mult, stride, pad, dil)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, mask_in=None, mult=None, join_put=None, join_take=None):
+    return Conv2dFn.apply(x, w, bias, mask_in, mult, stride, pad, dil, join_put, join_take)
 
 
 class ConvCat1x1Fn(torch.autograd.Function):
@@ -244,7 +277,7 @@ class BatchNormActFn(torch.autograd.Function):
     (depthnet.py:42-56,98-116).  running_mean/running_var are updated in place in training."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, res_join=None):
         _need_gpu(x, gamma, beta, running_mean, running_var, res)
         x = x.contiguous()
         res = None if res is None else res.contiguous()
@@ -264,6 +297,7 @@ class BatchNormActFn(torch.autograd.Function):
             ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var)
         ctx.cfg = (bool(relu), bool(training), eps, res is not None)
         ctx.params = (gamma, beta)
+        ctx.res_join = res_join
         return y
 
     @staticmethod
@@ -294,11 +328,13 @@ class BatchNormActFn(torch.autograd.Function):
             dgamma = dbeta = None
             _grad_done(g_param)
             _grad_done(b_param)
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+        if ctx.res_join is not None and dres is not None and relu:     # (without ReLU dres aliases dy: never hand that out)
+            ctx.res_join.buf, dres = dres, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
-    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5, res_join=None):
+    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, res_join)
 
 
 class ReluFn(torch.autograd.Function):

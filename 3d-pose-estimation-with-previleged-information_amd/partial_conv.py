@@ -22,14 +22,14 @@ class PartialConv(Conv2d):
         super().__init__(*args, **kwargs)
         self.slide_winsize = self.kernel_size[0] * self.kernel_size[1]      # partial_conv.py:28
 
-    def forward(self, input, mask_in):
+    def forward(self, input, mask_in, join_put=None, join_take=None):
         assert len(input.shape) == 4                                          # partial_conv.py:33
         k, stride, pad, dil = _one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)
         with torch.no_grad():
             mult, mask_out = ops.mask_count(mask_in, k, stride, pad, dil)    # partial_conv.py:35-43
         if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled():
             raise ops.P3DError('PartialConv with a trainable bias: backward is not implemented (no reference network uses it)')
-        output = ops.conv2d(input, self.weight, self.bias, stride, pad, dil, mask_in=mask_in, mult=mult)
+        output = ops.conv2d(input, self.weight, self.bias, stride, pad, dil, mask_in=mask_in, mult=mult, join_put=join_put, join_take=join_take)
         if self.return_mask:
             return output, mask_out
         return output
