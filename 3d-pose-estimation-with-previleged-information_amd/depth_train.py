@@ -8,12 +8,13 @@
 One step = forward (conv/BN/pool kernels) -> fused soft-argmax head -> fused loss (value + gradient) ->
 backward -> [RCCL all-reduce of the flat gradient, overlapped] -> global-norm clip + Adam (2 launches).
 Differences from the reference, all documented in DESIGN.md: one process per GPU instead of
-nn.DataParallel; `-half_acc`, distillation (`-do_teach`) and the evaluation path are "next" rows of the scope
-table and raise NotImplementedError; metadata.json is optional (only `no_depth` / `thresholds` are read).
+nn.DataParallel; `-half_acc` and distillation (`-do_teach`) are "next" rows of the scope table and raise
+NotImplementedError; evaluation (`.test`) is implemented; metadata.json is optional (only `no_depth` / `thresholds` are read).
 """
 import json
 import os
 
+import numpy as np
 import torch
 
 from . import dist as p3d_dist
@@ -36,6 +37,23 @@ def wrap_by_name(names, params):
     group_a = [param for name, param in zip(names, params) if 'bn' in name]
     group_b = [param for name, param in zip(names, params) if 'bn' not in name]
     return [dict(params=group_a), dict(params=group_b)]
+
+
+def to_test_worker(test_loader, no_depth, depth_only, do_fusion=False):
+    """Normalises the loader's tuple arity (depth_train.py:28-37) to (color, depth, true_cam, true_val, back_rotate); the
+    stream a non-fusion model does not read comes back as None."""
+    for items in test_loader:
+        if no_depth:
+            color, true_cam, true_val, color_br = items
+            yield color, None, true_cam, true_val, color_br
+        else:
+            color, depth, true_cam, true_val, color_br = items
+            if do_fusion:
+                yield color, depth, true_cam, true_val, color_br
+            elif depth_only:
+                yield None, depth, true_cam, true_val, color_br
+            else:
+                yield color, None, true_cam, true_val, color_br
 
 
 class Trainer:
@@ -171,8 +189,56 @@ class Trainer:
             return self.fusion_train(epoch, data_loader, device)
         return self.vanilla_train(epoch, data_loader, device)
 
+    # ---- evaluation (depth_train.py:477-607) ------------------------------------------------------
+    def _run_test(self, epoch, test_loader, device):
+        """vanilla_test / fusion_test: no-grad forward with frozen BN statistics, the same head and loss as training, then the
+        reference's host-side metrics on the back-rotated coordinates."""
+        if self.thresh is None:
+            raise RuntimeError('evaluation needs the `thresholds` entry of metadata.json (-metadata / $P3D_METADATA)')
+        n_batches = len(test_loader)
+        loss_avg, total, cam_stats = 0.0, 0, []
+        side_out = (self.side_in - 1) // self.stride + 1
+        for i_batch, items in enumerate(to_test_worker(test_loader, self.no_depth, self.depth_only, self.do_fusion)):
+            color_image, depth_image, true_cam, true_val, color_br = items
+            color_image = None if color_image is None else self.to(color_image, device)
+            depth_image = None if depth_image is None else self.to(depth_image, device)
+            true_cam = true_cam.to(device)
+            true_val = true_val.to(device)
+            batch = true_cam.size(0)
+            with torch.no_grad():
+                if self.do_fusion:
+                    cam_feat = self.fusion_infer(color_image, depth_image, i_batch)
+                else:
+                    cam_feat = self.vanilla_infer(depth_image if self.depth_only else color_image, i_batch)
+                heat_cam = utils.to_heatmap(cam_feat, self.depth, self.num_joints, side_out, side_out)
+                relat_cam = utils.decode(heat_cam, self.depth_range)
+                loss, spec_cam = ops.pose_loss(relat_cam, true_cam, true_val, self.data_info.key_index, self.loss_div, self.criterion)
+            value = loss.item()
+            loss_avg += value * batch
+            total += batch
+            valid = true_val.cpu().numpy().astype(bool)
+            rotate = np.asarray(color_br, dtype=np.float32)
+            spec_np = np.einsum('Bij,BCj->BCi', rotate, spec_cam.cpu().numpy())         # back-rotation to the original camera
+            true_np = np.einsum('Bij,BCj->BCi', rotate, true_cam.cpu().numpy())
+            cam_stats.append(utils.analyze(spec_np, true_np, valid, self.data_info.mirror, self.thresh))
+            if self.verbose:
+                print('| test Epoch[%d] [%d/%d]  Cam Loss %1.4f' % (epoch, i_batch, n_batches, value))
+        record = dict(test_loss=loss_avg / max(total, 1))
+        record.update(utils.parse_epoch(cam_stats))
+        if self.verbose:
+            print('\n=> test Epoch[%d]  Cam Loss: %1.4f\n' % (epoch, record['test_loss']))
+            print('=>[SPEC] cam_mean: %1.3f  [pck]: %1.3f  [auc]: %1.3f\n' % (record['cam_mean'], record['score_pck'], record['score_auc']))
+        return record
+
+    def vanilla_test(self, epoch, test_loader, device):
+        return self._run_test(epoch, test_loader, device)
+
+    def fusion_test(self, epoch, test_loader, device):
+        return self._run_test(epoch, test_loader, device)
+
     def test(self, epoch, test_loader):
-        raise NotImplementedError('evaluation (vanilla_test / fusion_test, depth_train.py:477-607) is the first "next" row')
+        self.model.eval()
+        return self._run_test(epoch, test_loader, self.list_params[0].device)
 
     def set_teacher(self, teacher):
         raise NotImplementedError('distillation is a "next" row')

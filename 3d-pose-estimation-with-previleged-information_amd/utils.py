@@ -56,3 +56,41 @@ def get_info():
     mirror = np.array([index[h36m_mirror.get(n, n)] for n in names])
     parent = np.array([index[h36m_parent.get(n, n)] for n in names])
     return JointInfo(names, parent, mirror, index[h36m_base_joint])
+
+
+# ---- evaluation metrics (reference utils.py:197-276); host-side numpy after the timed path, as in the reference ----------
+
+def statistics(basic, flip, tangent, thresh):
+    """Cascade of error classes over the valid joints (utils.py:197-224): each sample is counted by the FIRST test it passes
+    -- solid (error <= thresh.solid), close (<= close), depth (image-plane error <= close), jitter (<= rough), switch (error against
+    the mirrored joint <= rough) -- and what is left is `fail`.  Fractions of the total."""
+    basic, flip, tangent = (np.asarray(a) for a in (basic, flip, tangent))
+    count = float(basic.size)
+    alive = np.ones(basic.shape, dtype=bool)
+    out = {}
+    for key, values, limit in (('solid', basic, thresh['solid']), ('close', basic, thresh['close']), ('depth', tangent, thresh['close']),
+                               ('jitter', basic, thresh['rough']), ('switch', flip, thresh['rough'])):
+        hit = alive & (values <= limit)
+        out[key] = np.count_nonzero(hit) / count
+        alive &= ~hit
+    out['fail'] = np.count_nonzero(alive) / count
+    return out
+
+
+def analyze(spec_cam, true_cam, valid_mask, mirror, thresh):
+    """Per-batch metrics (utils.py:237-276): mean joint error, PCK and AUC at thresh.rough, and the error-class fractions."""
+    valid = np.asarray(valid_mask).reshape(-1).astype(bool)
+    dist = np.linalg.norm(spec_cam - true_cam, axis=-1).reshape(-1)[valid]
+    dist_flip = np.linalg.norm(spec_cam - true_cam[:, mirror], axis=-1).reshape(-1)[valid]
+    dist_tangent = np.linalg.norm(spec_cam[:, :, :2] - true_cam[:, :, :2], axis=-1).reshape(-1)[valid]
+    stats = statistics(dist, dist_flip, dist_tangent, thresh)
+    stats.update(batch_size=dist.shape[0], score_pck=np.mean(dist / thresh['rough'] <= 1.0),
+                 score_auc=np.mean(np.maximum(0, 1 - dist / thresh['rough'])), cam_mean=np.mean(dist))
+    return stats
+
+
+def parse_epoch(stats):
+    """Valid-joint-count weighted average of the per-batch dicts (utils.py:227-234)."""
+    keys = ('solid', 'close', 'jitter', 'depth', 'switch', 'fail', 'score_pck', 'score_auc', 'cam_mean')
+    weights = np.array([patch['batch_size'] for patch in stats], dtype=np.float64)
+    return {key: float(np.sum(weights * np.array([patch[key] for patch in stats])) / np.sum(weights)) for key in keys}

@@ -232,6 +232,49 @@ def gen_step(case):
     print('step_%s.npz' % case, 'losses', rec['losses'], 'clip_total', rec['clip_total'])
 
 
+def gen_eval():
+    """utils.analyze / statistics / parse_epoch on random poses, and the unmodified Trainer.vanilla_test on two synthetic
+    batches (depth_train.py:543-607).  (vanilla_test's np.bool, depth_train.py:583, exists again in numpy 2.)"""
+    args = ref_args('resnet18', 256)
+    import depth_train
+    import depth_main
+    import depthnet
+    import utils
+    thresh = dict(solid=40.0, close=80.0, rough=150.0)
+    info = depth_main.get_info()
+    rng = np.random.Generator(np.random.PCG64(123))
+    out = {}
+    stats = []
+    for i in range(3):
+        true = (rng.standard_normal((5, 17, 3)) * 300).astype(np.float32)
+        spec = true + (rng.standard_normal((5, 17, 3)) * rng.choice([10.0, 60.0, 200.0], size=(5, 17, 1))).astype(np.float32)
+        spec[0, 3], spec[0, 0] = true[0, info.mirror[3]], true[0, info.mirror[0]]           # left/right switches
+        val = rng.random((5, 17)) > 0.2
+        st = utils.analyze(spec, true, val, info.mirror, thresh)
+        stats.append(st)
+        out.update({'an%d.spec' % i: spec, 'an%d.true' % i: true, 'an%d.val' % i: val,
+                    'an%d.stats' % i: np.array(json.dumps({k: float(v) for k, v in st.items()}))})
+    out['epoch'] = np.array(json.dumps({k: float(v) for k, v in utils.parse_epoch(stats).items()}))
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'metadata.json'), 'w') as f:
+        json.dump(dict(loader=dict(h36m='depth_datasets'), no_depth=dict(h36m=False), thresholds=dict(h36m=thresh), root=dict(h36m=tmp)), f)
+    depth_train.root_me = tmp
+    model = depthnet.resnet18(args, False)
+    load_det_weights(model, seed=0)
+    tr = depth_train.Trainer(args, model, info)
+    batches = []
+    for it in range(2):
+        c, d, tc, tv = synth.make_batch(2, side=256, rank=7, step=it, invalid_frac=0.2)
+        rot = np.linalg.qr(np.random.Generator(np.random.PCG64(it)).standard_normal((2, 3, 3)))[0].astype(np.float32)
+        batches.append((torch.from_numpy(c), torch.from_numpy(d), torch.from_numpy(tc), torch.from_numpy(tv), torch.from_numpy(rot)))
+    tr.model.eval()
+    rec = tr.vanilla_test(1, batches, torch.device('cpu'))
+    out['test_record'] = np.array(json.dumps({k: float(v) for k, v in rec.items()}))
+    out['thresh'] = np.array(json.dumps(thresh))
+    np.savez_compressed(os.path.join(HERE, 'eval.npz'), **out)
+    print('eval.npz', rec)
+
+
 def gen_legacy_resnet():
     """resnet.py forward only (train.Trainer cannot be constructed: it reads args.thresh_* that opts.py lacks)."""
     args = ref_args('resnet18', 256, ['-joint_space'])
@@ -275,7 +318,7 @@ def gen_state_keys():
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'head', 'legacy', 'keys'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
@@ -285,5 +328,7 @@ if __name__ == '__main__':
             gen_legacy_resnet()
         elif t == 'keys':
             gen_state_keys()
+        elif t == 'eval':
+            gen_eval()
         else:
             gen_step(t)
