@@ -32,6 +32,8 @@ class Dataset(data.Dataset):
         self.num_joints = args.num_joints
         self.count = args.synthetic * args.batch_size
         self.at_test = phase != 'train'
+        self.do_teach = bool(getattr(args, 'do_teach', False)) and phase == 'train'
+        self.stride, self.attention = args.stride, args.attention
 
     def __len__(self):
         return self.count
@@ -41,4 +43,8 @@ class Dataset(data.Dataset):
         items = [torch.from_numpy(color[0]), torch.from_numpy(depth[0]), torch.from_numpy(cam[0]), torch.from_numpy(val[0])]
         if self.at_test:
             items.append(torch.eye(3))
+        if self.do_teach:                      # (color, depth, cam, valid, atten_map): depth_datasets.py:231-234
+            from .utils import get_attention
+            coords = np.random.Generator(np.random.PCG64(index)).uniform(0, self.side_in, size=(self.num_joints, 2))
+            items.append(torch.from_numpy(get_attention(self.side_in, self.stride, coords, self.attention)).float())
         return tuple(items)

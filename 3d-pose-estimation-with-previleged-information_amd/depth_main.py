@@ -35,19 +35,45 @@ def create_model(args):
     return model, state
 
 
+def create_pair(args):
+    """depth_main.py:77-108: teacher = {partial_}{fusion|depth}net loaded from args.teacher_path, student = depthnet.
+    (The reference wraps `model` instead of `teacher` in DataParallel when n_cudas > 1, depth_main.py:106; not reproduced.)"""
+    name = ('partial_' if args.partial_conv else '') + ('fusion' if args.do_fusion else 'depth') + 'net'
+    teacher_module = importlib.import_module('.' + name, package=__package__)
+    assert hasattr(teacher_module, args.model)
+    teacher = getattr(teacher_module, args.model)(args, False)
+    teacher.load_state_dict(torch.load(args.teacher_path, map_location='cpu')['model'])
+    student_module = importlib.import_module('.depthnet', package=__package__)
+    model = getattr(student_module, args.model)(args, args.pretrain)
+    state = None
+    if args.resume:
+        print('=> Loads checkpoint from ' + args.model_path)
+        checkpoint = torch.load(args.model_path, map_location='cpu')
+        model.load_state_dict(checkpoint['model'])
+        state = checkpoint['state']
+    return model, teacher, state
+
+
 def main(argv=None):
     from . import opts
     args = opts.parse(argv)
     assert not (args.do_teach and args.do_fusion and args.depth_only)
     rank, world, local_rank = p3d_dist.init_from_env()
     torch.cuda.set_device(local_rank)
-    model, state = create_model(args)
+    teacher = None
+    if args.do_teach:
+        model, teacher, state = create_pair(args)
+        teacher = teacher.cuda()
+    else:
+        model, state = create_model(args)
     model = model.cuda()
     data_info = get_info()
     loader_mod = importlib.import_module('.depth_datasets', package=__package__)
     train_loader = loader_mod.data_loader(args, 'train', data_info)
     trainer = depth_train.Trainer(args, model, data_info)
     trainer.verbose = rank == 0
+    if teacher is not None:
+        trainer.set_teacher(teacher)
     start = state['epoch'] + 1 if state else 1
     for epoch in range(start, args.n_epochs + 1):
         record = trainer.train(epoch, train_loader)

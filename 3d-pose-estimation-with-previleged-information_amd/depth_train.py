@@ -61,8 +61,8 @@ class Trainer:
     def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
         if args.half_acc:
             raise NotImplementedError('-half_acc (fp16 master-copy path, depth_train.py:73-83,413-449) is a "next" row; fp32 is the parity path')
-        if args.do_teach or args.semi_teach:
-            raise NotImplementedError('distillation (-do_teach / -semi_teach, depth_train.py:161-283) is a "next" row')
+        if args.semi_teach:
+            raise NotImplementedError('-semi_teach needs the unlabelled PKU loader (depth_train.py:67-71,132-153): out of scope')
         self.model = model
         self.data_info = data_info
         self.list_names = [name for name, param in model.named_parameters()]
@@ -71,7 +71,12 @@ class Trainer:
         self.half_acc = False
         self.depth_only = args.depth_only
         self.do_fusion = args.do_fusion
-        self.do_teach = False
+        self.do_teach = args.do_teach
+        self.sigmoid = args.sigmoid
+        self.bin_dist = args.bin_dist
+        self.do_freeze = args.do_freeze
+        self.alpha_dest, self.alpha_init, self.alpha_span = args.alpha_dest, args.alpha_init, args.alpha_span
+        self.teacher = None
 
         metadata = _load_metadata(args)
         self.no_depth = metadata['no_depth'][args.data_name] if metadata else False
@@ -185,6 +190,8 @@ class Trainer:
         self.model.train()
         self.adapt_learn_rate(epoch)
         device = self.list_params[0].device
+        if self.do_teach:
+            return self.distill_train(epoch, data_loader, device)
         if self.do_fusion:
             return self.fusion_train(epoch, data_loader, device)
         return self.vanilla_train(epoch, data_loader, device)
@@ -198,7 +205,8 @@ class Trainer:
         n_batches = len(test_loader)
         loss_avg, total, cam_stats = 0.0, 0, []
         side_out = (self.side_in - 1) // self.stride + 1
-        for i_batch, items in enumerate(to_test_worker(test_loader, self.no_depth, self.depth_only, self.do_fusion)):
+        fusion = self.do_fusion and not self.do_teach           # under -do_teach the student (single stream) is what gets evaluated
+        for i_batch, items in enumerate(to_test_worker(test_loader, self.no_depth, self.depth_only, fusion)):
             color_image, depth_image, true_cam, true_val, color_br = items
             color_image = None if color_image is None else self.to(color_image, device)
             depth_image = None if depth_image is None else self.to(depth_image, device)
@@ -206,7 +214,7 @@ class Trainer:
             true_val = true_val.to(device)
             batch = true_cam.size(0)
             with torch.no_grad():
-                if self.do_fusion:
+                if fusion:
                     cam_feat = self.fusion_infer(color_image, depth_image, i_batch)
                 else:
                     cam_feat = self.vanilla_infer(depth_image if self.depth_only else color_image, i_batch)
@@ -238,7 +246,70 @@ class Trainer:
 
     def test(self, epoch, test_loader):
         self.model.eval()
-        return self._run_test(epoch, test_loader, self.list_params[0].device)
+        return self._run_test(epoch, test_loader, self.list_params[0].device)      # -do_teach evaluates the student (depth_train.py:613-614)
 
+    # ---- distillation: the "privileged information" training (depth_train.py:107-129,161-283,641-647,682-691) --------
     def set_teacher(self, teacher):
-        raise NotImplementedError('distillation is a "next" row')
+        self.teacher = teacher
+
+    def get_dist_weight(self, epoch):
+        alphas = np.linspace(self.alpha_init, self.alpha_dest, self.alpha_span)
+        return float(alphas[epoch - 1]) if epoch - 1 < self.alpha_span else float(self.alpha_dest)
+
+    def freeze_batchnorm(self):
+        self.teacher.eval()
+        self.model.freeze_batchnorm()
+
+    def teach_infer(self, color_image, depth_image):
+        if self.do_fusion:
+            return self.teacher(color_image, depth_image)
+        return self.teacher(depth_image if self.depth_only else color_image)
+
+    def distill(self, batch, teach_last, last_feat, atten_map, weight=1.0, unit_grad=False):
+        """Returns (weight * dist_loss, dist_loss); modes as in the reference: -bin_dist, -sigmoid, plain L2 norm."""
+        mode = 'bce' if self.bin_dist else ('sigmoid' if self.sigmoid else 'l2')
+        return ops.distill_loss(teach_last, last_feat, atten_map, mode, weight, unit_grad)
+
+    def distill_step(self, epoch, color_image, depth_image, true_cam, true_val, atten_map):
+        """One iteration of distill_train on device tensors; returns (cam_loss, dist_loss) as 0-d device tensors."""
+        side_out = (self.side_in - 1) // self.stride + 1
+        with torch.no_grad():
+            teach_cam, teach_last = self.teach_infer(color_image, depth_image)
+        cam_feat, last_feat = self.vanilla_infer(color_image, 0, True)
+        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map, self.get_dist_weight(epoch), unit_grad=True)
+        heat_cam = utils.to_heatmap(cam_feat, self.depth, self.num_joints, side_out, side_out)
+        relat_cam = utils.decode(heat_cam, self.depth_range)
+        count = p3d_dist.global_valid_divisor(true_val) if self.world > 1 else None
+        cam_loss, spec_cam = ops.pose_loss(relat_cam, true_cam, true_val, self.data_info.key_index, self.loss_div, self.criterion,
+                                           count_override=count)
+        self.last_spec_cam = spec_cam
+        loss = weighted + cam_loss                      # dist_loss * alpha + cam_loss (depth_train.py:220)
+        self.optimizer.zero_grad()
+        loss.backward()
+        assert ops.pending_joins() == 0
+        scale = self.reducer.finish()
+        self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
+        return cam_loss.detach(), dist_loss.detach()
+
+    def distill_train(self, epoch, data_loader, device):
+        if self.teacher is None:
+            raise RuntimeError('distill_train: call set_teacher() first')
+        n_batches = len(data_loader)
+        cam_sum = dist_sum = 0.0
+        samples = 0
+        if self.do_freeze:
+            self.freeze_batchnorm()
+        if self.verbose:
+            print('\n=> alpha value: {:.2f}'.format(self.get_dist_weight(epoch)))
+        for i_batch, (color_image, depth_image, true_cam, true_val, atten_map) in enumerate(data_loader):
+            color_image, depth_image, atten_map = (self.to(t, device) for t in (color_image, depth_image, atten_map))
+            true_cam, true_val = true_cam.to(device), true_val.to(device)
+            batch = true_cam.size(0)
+            cam_loss, dist_loss = self.distill_step(epoch, color_image, depth_image, true_cam, true_val, atten_map.float())
+            cam_value, dist_value = cam_loss.item(), dist_loss.item()
+            cam_sum += cam_value * batch
+            dist_sum += dist_value * batch
+            samples += batch
+            if self.verbose:
+                print('[=] train Epoch[{0}] Batch[{1}|{2}]  Cam Loss {3:.4f}  Dist Loss {4:.4f} '.format(epoch, i_batch, n_batches, cam_value, dist_value))
+        return dict(dist_train_loss=dist_sum / max(samples, 1), cam_train_loss=cam_sum / max(samples, 1))

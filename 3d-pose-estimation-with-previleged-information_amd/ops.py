@@ -459,6 +459,47 @@ def pose_loss(relat, true_cam, true_val, key_index, loss_div, criterion='SmoothL
     return PoseLossFn.apply(relat, true_cam, true_val, int(key_index), float(loss_div), criterion, count_override)
 
 
+DISTILL_MODES = {'l2': 0, 'sigmoid': 1, 'bce': 2}
+
+
+class DistillFn(torch.autograd.Function):
+    """Trainer.distill (depth_train.py:115-129): feature-distillation loss of the student against the (no-grad) teacher.
+    Returns (weight * loss, loss); the gradient of the first output w.r.t. the student features is produced in the forward
+    launch already (scaled by `weight`), so backward is free when the incoming gradient is 1 (loss = cam_loss + weight*dist)."""
+
+    @staticmethod
+    def forward(ctx, teach, student, atten, mode, weight, unit_grad):
+        _need_gpu(teach, student, atten)
+        teach, student, atten = teach.contiguous(), student.contiguous(), atten.contiguous()
+        b, c, h, w = student.shape
+        if teach.shape != student.shape or tuple(atten.shape) != (b, 1, h, w):
+            raise P3DError('distill: teacher %s / student %s / attention %s do not match' % (tuple(teach.shape), tuple(student.shape), tuple(atten.shape)))
+        L = lib()
+        loss = torch.empty(1, dtype=torch.float32, device=student.device)
+        need = ctx.needs_input_grad[1]
+        ds = torch.empty_like(student) if need else None
+        ws = workspace(student.device, L.p3d_distill_workspace_bytes(b))
+        check(L.p3d_distill_fwd_bwd(_p(teach), _p(student), _p(atten), _p(loss), _p(ds), b, c, h * w, DISTILL_MODES[mode], float(weight),
+                                    _p(ws), ws.numel(), _stream()), 'p3d_distill_fwd_bwd')
+        ctx.save_for_backward(ds)
+        ctx.unit_grad = unit_grad
+        raw = loss.view(())
+        weighted = raw * weight if weight != 1.0 else raw.clone()
+        ctx.mark_non_differentiable(raw)
+        return weighted, raw
+
+    @staticmethod
+    def backward(ctx, dweighted, draw):
+        (ds,) = ctx.saved_tensors
+        if ds is not None and not ctx.unit_grad:
+            ds = ds * dweighted
+        return None, ds, None, None, None, None
+
+
+def distill_loss(teach, student, atten, mode='l2', weight=1.0, unit_grad=False):
+    return DistillFn.apply(teach, student, atten, mode, float(weight), unit_grad)
+
+
 # --------------------------------------------------------------------------------------------
 def l2norm_sq_accum(flat, accum):
     check(lib().p3d_l2norm_sq_accum(_p(flat), flat.numel(), _p(accum), _stream()), 'p3d_l2norm_sq_accum')

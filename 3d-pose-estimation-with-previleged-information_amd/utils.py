@@ -49,6 +49,19 @@ def decode(heatmap, depth_range):
     return ops.softargmax3d(heatmap.logits, heatmap.depth, heatmap.num_joints, heatmap.height, heatmap.width, depth_range)
 
 
+def get_attention(side_in, stride, image_coords, attention):
+    """Distillation attention map (utils.py:14-42): sum over joints of exp(-r^2/5) around each joint's position on the
+    side_out x side_out feature grid, normalised to max 1; all ones without -attention.  Host numpy, made in the loader."""
+    side_out = (side_in - 1) // stride + 1
+    if not attention:
+        return np.ones((1, side_out, side_out))
+    gx, gy = np.meshgrid(np.arange(side_out), np.arange(side_out))
+    scale = side_in / side_out
+    dist = (gx[..., None] - image_coords[:, 0] / scale) ** 2 + (gy[..., None] - image_coords[:, 1] / scale) ** 2
+    radial = np.exp(-dist / 5.0).sum(axis=-1)
+    return (radial / np.amax(radial))[None, :, :]
+
+
 def get_info():
     """depth_main.get_info (depth_main.py:14-33): the H36M 17-joint JointInfo with index arrays."""
     from .joint_settings import h36m_base_joint, h36m_mirror, h36m_parent, h36m_short_names as names

@@ -160,6 +160,17 @@ int32_t p3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, f
                       float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Feature distillation loss, teacher -> student: Trainer.distill (depth_train.py:115-129).
+ * teach, student [B,C,H,W]; atten [B,1,H,W].  mode 0: mean_b ||(t-s)*a||_2;  1: the same on sigmoid(t)-sigmoid(s) (-sigmoid);
+ * 2 (-bin_dist): mean(BCEWithLogits(s, sigmoid(t))) * mean_b(sum a_b), as the reference computes it.
+ * Outputs loss[1] and, if dstudent != NULL, loss_scale * dloss/dstudent.
+ * ------------------------------------------------------------------------------------------ */
+size_t p3d_distill_workspace_bytes(int32_t B);
+int32_t p3d_distill_fwd_bwd(const float* teach, const float* student, const float* atten, float* loss, float* dstudent,
+                            int32_t B, int32_t C, int32_t HW, int32_t mode, float loss_scale,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * On-GPU augmentation (config 5): augment_colour.random_color (augment_colour.py:48-67) and
  * augment_occluder.random_erase (augment_occluder.py:84-105) on float images [B,3,H,W] in [0,1].
  * params [B,4]: brightness delta, contrast factor, hue shift (deg), saturation factor.

@@ -275,6 +275,62 @@ def gen_eval():
     print('eval.npz', rec)
 
 
+def gen_distill():
+    """Trainer.distill in its three modes + utils.get_attention, and one unmodified distill_train iteration with a fusionnet
+    teacher and a depthnet student (depth_train.py:115-129,161-283)."""
+    import importlib
+    out = {}
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'metadata.json'), 'w') as f:
+        json.dump(dict(loader=dict(h36m='depth_datasets'), no_depth=dict(h36m=False),
+                       thresholds=dict(h36m=dict(solid=10, close=20, rough=150)), root=dict(h36m=tmp)), f)
+    rng = np.random.Generator(np.random.PCG64(55))
+    t = rng.standard_normal((3, 8, 5, 5)).astype(np.float32)
+    s_ = rng.standard_normal((3, 8, 5, 5)).astype(np.float32)
+    coords = rng.uniform(0, 80, size=(17, 2))
+    for mode, extra in (('l2', []), ('sigmoid', ['-sigmoid']), ('bce', ['-bin_dist'])):
+        args = ref_args('resnet18', 80, ['-do_teach', '-do_fusion'] + extra)
+        import depth_train, depth_main, utils, depthnet
+        depth_train.root_me = tmp
+        att = utils.get_attention(80, 16, coords, True).astype(np.float32)
+        a = np.stack([att, att * 0.5, np.ones_like(att)]).astype(np.float32)
+        tr = depth_train.Trainer(args, depthnet.resnet18(args, False), depth_main.get_info())
+        st = torch.from_numpy(s_).requires_grad_(True)
+        loss = tr.distill(3, torch.from_numpy(t), st, torch.from_numpy(a))
+        loss.backward()
+        out.update({mode + '.loss': np.array(float(loss)), mode + '.ds': tnp(st.grad)})
+    out.update(t=t, s=s_, a=a, coords=coords, att=att)
+    # whole iteration
+    args = ref_args('resnet18', 128, ['-do_teach', '-do_fusion'])
+    import depth_train, depth_main, depthnet, fusionnet
+    depth_train.root_me = tmp
+    student = depthnet.resnet18(args, False)
+    teacher = fusionnet.resnet18(args, False)
+    load_det_weights(student, seed=0)
+    load_det_weights(teacher, seed=1)
+    tr = depth_train.Trainer(args, student, depth_main.get_info())
+    tr.set_teacher(teacher)
+    c, d, tc, tv = synth.make_batch(2, side=128, rank=11, step=0)
+    att2 = np.stack([utils.get_attention(128, 16, np.random.Generator(np.random.PCG64(i)).uniform(0, 128, size=(17, 2)), True) for i in range(2)]).astype(np.float32)
+    batch = tuple(torch.from_numpy(x) for x in (c, d, tc, tv, att2))
+    tr.model.train()
+    tr.adapt_learn_rate(1)
+    rec = tr.distill_train(1, [batch], torch.device('cpu'))
+    sd = {k: tnp(v) for k, v in student.state_dict().items()}
+    names = tr.list_names
+    out['step.record'] = np.array(json.dumps({k: float(v) for k, v in rec.items()}))
+    out['step.att'] = att2
+    out['step.param_norms'] = np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names])
+    rs = np.random.Generator(np.random.PCG64(5))
+    idx = np.array([rs.integers(0, sd[n].size, size=4) for n in names])
+    out['step.sample_idx'] = idx
+    out['step.param_samples'] = np.array([sd[n].reshape(-1)[idx[i]] for i, n in enumerate(names)])
+    out['step.names'] = np.array(json.dumps(names))
+    out['step.alpha'] = np.array(tr.get_dist_weight(1))
+    np.savez_compressed(os.path.join(HERE, 'distill.npz'), **out)
+    print('distill.npz', rec)
+
+
 def gen_legacy_resnet():
     """resnet.py forward only (train.Trainer cannot be constructed: it reads args.thresh_* that opts.py lacks)."""
     args = ref_args('resnet18', 256, ['-joint_space'])
@@ -318,7 +374,7 @@ def gen_state_keys():
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval', 'distill'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
@@ -330,5 +386,7 @@ if __name__ == '__main__':
             gen_state_keys()
         elif t == 'eval':
             gen_eval()
+        elif t == 'distill':
+            gen_distill()
         else:
             gen_step(t)
