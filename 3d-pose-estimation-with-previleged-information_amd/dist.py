@@ -26,7 +26,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_GROUP) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('P3D_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')   # 'nccl' is RCCL on ROCm
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -54,6 +54,11 @@ def plan_buckets(slices, bucket_bytes=DEFAULT_BUCKET_BYTES, total=None):
     return buckets
 
 
+# P3D_FORCE_DIST=1: join a process group and run the bucketed all-reduce even with ONE rank -- rehearses the RCCL path
+# (communicator set-up, stream hand-over, bucket launches) on a single-GPU box.
+FORCE_GROUP = bool(os.environ.get('P3D_FORCE_DIST'))
+
+
 class GradReducer:
     """Bucketed, backward-overlapped sum-all-reduce of a FlatAdam gradient buffer."""
 
@@ -69,7 +74,8 @@ class GradReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        self.active = self.world > 1 or (FORCE_GROUP and dist.is_initialized())
+        if self.active:
             for idx, p in enumerate(optimizer.params):
                 hook = self._make_hook(idx)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))       # gradients that arrive through autograd
@@ -106,7 +112,7 @@ class GradReducer:
     def finish(self):
         """Call after backward: launches any bucket whose hooks did not all fire (unused parameters), waits for
         every transfer, and returns the scale (1/world) to hand to FlatAdam.clip_and_step."""
-        if self.world > 1:
+        if self.active:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
@@ -130,7 +136,7 @@ def global_valid_divisor(true_val, group=None):
     3 * sum_over_ranks(n_valid) / world, as a 1-element fp32 device tensor.  One 4-byte all-reduce, no host sync."""
     count = true_val.sum().to(torch.float32).reshape(1)
     world = 1
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_GROUP):
         world = dist.get_world_size(group)
         dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
     return count * (3.0 / world)

@@ -87,7 +87,7 @@ def main():
         batches.append((color, depth, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -101,7 +101,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -144,7 +144,7 @@ def main():
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet':
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
