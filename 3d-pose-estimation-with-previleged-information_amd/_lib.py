@@ -41,7 +41,7 @@ SIGNATURES = {
     'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
     'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'p3d_bn_train_fwd': (_i32, [_ptr] * 9 + [_i32, _i32, _i32, _f32, _f32, _i32, _ptr, _sz, _ptr]),
-    'p3d_bn_train_bwd': (_i32, [_ptr] * 10 + [_i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
+    'p3d_bn_train_bwd': (_i32, [_ptr] * 11 + [_i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_bn_eval_fwd': (_i32, [_ptr] * 7 + [_i32, _i32, _i32, _f32, _i32, _ptr]),
     'p3d_bn_eval_bwd': (_i32, [_ptr] * 10 + [_i32, _i32, _i32, _f32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_relu_fwd': (_i32, [_ptr, _ptr, _i64, _ptr]),

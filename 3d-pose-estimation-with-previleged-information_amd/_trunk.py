@@ -120,8 +120,22 @@ def normal_fan_out_(module):
             m.bias.data.zero_()
 
 
+def _tick_batchnorm(module, inputs):
+    """Forward pre-hook of the whole network: one multi-tensor add bumps `num_batches_tracked` of every BatchNorm2d in training
+    mode (53 one-element launches per ResNet-50 step otherwise); each layer then skips its own increment for this call."""
+    layers = [m for m in module.modules() if isinstance(m, BatchNorm2d) and m.training and m.num_batches_tracked.is_cuda]
+    if layers:
+        torch._foreach_add_([m.num_batches_tracked for m in layers], 1)
+        for m in layers:
+            m._ticked = True
+
+
 class TrunkBase(nn.Module):
     """Holds `inplanes` bookkeeping and the stage factory shared by every family."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_forward_pre_hook(_tick_batchnorm)
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1, skip_relu=False, partial=False):
         downsample = None

@@ -25,6 +25,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /*[
     __syncthreads();
 }
 
+// y = fmaf(x, sc, sh): the backward recomputes the ReLU mask of a residual-free layer from x with the SAME two constants
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return __fmaf_rn(-mean, sc, beta); }
+
 // partial[(c*split + s)*2 + {0,1}] = sum x, sum x^2 over this block's images
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int N, int C, int HW) {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
     }
     const float sc = invstd * gamma[c];
-    const float sh = beta[c] - fmean * sc;
+    const float sh = bn_shift(beta[c], fmean, sc);
     for (int n = s; n < N; n += split) {
         const size_t off = ((size_t)n * C + c) * HW;
         if constexpr (VEC) {
@@ -142,13 +145,19 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ 
 
 // backward pass 1: partial sums of g and g*xhat with g = relu ? dy*(y>0) : dy.
 // `stat2_is_var`: stat2 holds a variance (eval mode) instead of invstd.
+// y == nullptr with relu: the layer had no residual input, so y > 0 <=> fmaf(x, sc, sh) > 0 is recomputed from x (one tensor
+// read less in both backward passes); needs beta.
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ stat2, int stat2_is_var,
                                                             float eps, double* __restrict__ partial, int N, int C, int HW, int relu) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     const float mu = mean[c];
     const float is = stat2_is_var ? 1.f / sqrtf(stat2[c] + eps) : stat2[c];
+    const bool recompute = relu && y == nullptr;
+    const float sc = recompute ? is * gamma[c] : 0.f;
+    const float sh = recompute ? bn_shift(beta[c], mu, sc) : 0.f;
     double s1 = 0.0, s2 = 0.0;
     for (int n = s; n < N; n += split) {
         const size_t off = ((size_t)n * C + c) * HW;
@@ -159,7 +168,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             for (int i = threadIdx.x; i < HW / 4; i += 256) {
                 float4 g = gv[i];
                 const float4 q = xv[i];
-                if (relu) {
+                if (recompute) {
+                    g.x = fmaf(q.x, sc, sh) > 0.f ? g.x : 0.f; g.y = fmaf(q.y, sc, sh) > 0.f ? g.y : 0.f;
+                    g.z = fmaf(q.z, sc, sh) > 0.f ? g.z : 0.f; g.w = fmaf(q.w, sc, sh) > 0.f ? g.w : 0.f;
+                } else if (relu) {
                     const float4 o = yv[i];
                     g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
                 }
@@ -170,7 +182,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         } else {
             for (int i = threadIdx.x; i < HW; i += 256) {
                 float g = dy[off + i];
-                if (relu && !(y[off + i] > 0.f)) g = 0.f;
+                if (recompute) { if (!(fmaf(x[off + i], sc, sh) > 0.f)) g = 0.f; }
+                else if (relu && !(y[off + i] > 0.f)) g = 0.f;
                 s1 += g;
                 s2 += (double)(g * ((x[off + i] - mu) * is));
             }
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // train: dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); eval (frozen stats): dx = gamma*invstd*g
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ stat2, int stat2_is_var, float eps,
                                                            const double* __restrict__ partial, int nsplit, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* dgamma, float* dbeta, int N, int C, int HW,
@@ -206,6 +219,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float mu = mean[c];
     const float is = stat2_is_var ? 1.f / sqrtf(stat2[c] + eps) : stat2[c];
     const float gs = gamma[c] * is;
+    const bool recompute = relu && y == nullptr;
+    const float sc = recompute ? is * gamma[c] : 0.f;
+    const float sh = recompute ? bn_shift(beta[c], mu, sc) : 0.f;
     const double cnt = (double)N * HW;
     const float k1 = train ? (float)(s1 / cnt) : 0.f;
     const float k2 = train ? (float)(s2 / cnt) : 0.f;
@@ -220,7 +236,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             for (int i = threadIdx.x; i < HW / 4; i += 256) {
                 float4 g = gv[i];
                 const float4 q = xv[i];
-                if (relu) {
+                if (recompute) {
+                    g.x = fmaf(q.x, sc, sh) > 0.f ? g.x : 0.f; g.y = fmaf(q.y, sc, sh) > 0.f ? g.y : 0.f;
+                    g.z = fmaf(q.z, sc, sh) > 0.f ? g.z : 0.f; g.w = fmaf(q.w, sc, sh) > 0.f ? g.w : 0.f;
+                } else if (relu) {
                     const float4 o = yv[i];
                     g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
                 }
@@ -235,7 +254,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         } else {
             for (int i = threadIdx.x; i < HW; i += 256) {
                 float g = dy[off + i];
-                if (relu && !(y[off + i] > 0.f)) g = 0.f;
+                if (recompute) { if (!(fmaf(x[off + i], sc, sh) > 0.f)) g = 0.f; }
+                else if (relu && !(y[off + i] > 0.f)) g = 0.f;
                 if (dres) dres[off + i] = g;
                 dx[off + i] = gs * (g - k1 - (x[off + i] - mu) * is * k2);
             }
@@ -301,11 +321,11 @@ int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, c
     return check_launch("bn_train_fwd");
 }
 
-static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* stat2,
+static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* mean, const float* stat2,
                              int stat2_is_var, float eps, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
                              int32_t HW, int32_t relu, int train, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     P3D_REQUIRE(dy && x && gamma && mean && stat2 && dx && dgamma && dbeta, "bn_bwd: null tensor");
-    P3D_REQUIRE(!relu || y, "bn_bwd: relu backward needs the forward output");
+    P3D_REQUIRE(!relu || y || (beta && !stat2_is_var && !dres), "bn_bwd: relu backward needs the forward output (or beta, train mode, no residual)");
     P3D_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd: bad shape %d %d %d", N, C, HW);
     if (!workspace || workspace_bytes < p3d_bn_workspace_bytes(N, C, HW)) {
         set_error("bn_bwd: workspace too small");
@@ -315,23 +335,22 @@ static int32_t bn_bwd_common(const float* dy, const float* x, const float* y, co
     const int split = pick_split(N, C);
     dim3 grid(C, split);
     double* partial = (double*)workspace;
-    const float* yy = y ? y : x;
-    if (vec_ok(HW, dy, x, yy, dx, dres)) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
+    if (vec_ok(HW, dy, x, y, dx, dres)) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, x, y, gamma, beta, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, x, y, gamma, beta, mean, stat2, stat2_is_var, eps, partial, split,
                            dx, dres, dgamma, dbeta, N, C, HW, relu, train, accumulate);
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, x, yy, gamma, mean, stat2, stat2_is_var, eps, partial, split,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, x, y, gamma, beta, mean, stat2, stat2_is_var, eps, partial, N, C, HW, relu);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, x, y, gamma, beta, mean, stat2, stat2_is_var, eps, partial, split,
                            dx, dres, dgamma, dbeta, N, C, HW, relu, train, accumulate);
     }
     return check_launch("bn_bwd");
 }
 
-int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
                          int32_t HW, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    return bn_bwd_common(dy, x, y, gamma, save_mean, save_invstd, 0, 0.f, dx, dres, dgamma, dbeta, N, C, HW, relu, 1, accumulate, workspace,
+    return bn_bwd_common(dy, x, y, gamma, beta, save_mean, save_invstd, 0, 0.f, dx, dres, dgamma, dbeta, N, C, HW, relu, 1, accumulate, workspace,
                          workspace_bytes, stream);
 }
 
@@ -351,7 +370,7 @@ int32_t p3d_bn_eval_fwd(const float* x, const float* res, const float* gamma, co
 int32_t p3d_bn_eval_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* running_mean,
                         const float* running_var, float* dx, float* dres, float* dgamma, float* dbeta, int32_t N, int32_t C,
                         int32_t HW, float eps, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    return bn_bwd_common(dy, x, y, gamma, running_mean, running_var, 1, eps, dx, dres, dgamma, dbeta, N, C, HW, relu, 0, accumulate, workspace,
+    return bn_bwd_common(dy, x, y, gamma, nullptr, running_mean, running_var, 1, eps, dx, dres, dgamma, dbeta, N, C, HW, relu, 0, accumulate, workspace,
                          workspace_bytes, stream);
 }
 

@@ -64,6 +64,72 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// W % 4 == 0 variants (every shape of the reference: 128x128 -> 64x64): a thread owns 4 consecutive input columns 4j..4j+3 of one
+// row, which is exactly the footprint (plus the left neighbour 4j-1) of the two windows wo = 2j, 2j+1 -> 16-B accesses on the
+// large tensor instead of nine strided dwords per output (forward) / four byte+dword gathers per input pixel (backward).
+// Same comparison order (r, then s; strict '>'; NaN wins) and the same summation order (ho, then wo) as the generic kernels.
+__global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                                           int NC, int H, int W, int Ho, int Wo) {
+    const int W4 = W / 4;
+    const size_t total = (size_t)NC * Ho * W4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % W4);
+        const int ho = (int)((i / W4) % Ho);
+        const size_t nc = i / ((size_t)W4 * Ho);
+        const float* src = x + nc * H * W;
+        float b0 = -INFINITY, b1 = -INFINITY;
+        int i0 = 0, i1 = 0;
+        bool f0 = true, f1 = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            const float4 q = *reinterpret_cast<const float4*>(src + (size_t)hi * W + 4 * j);
+            if (j > 0) {
+                const float l = src[(size_t)hi * W + 4 * j - 1];
+                if (f0 || l > b0 || l != l) { b0 = l; i0 = r * 3; f0 = false; }
+            }
+            if (f0 || q.x > b0 || q.x != q.x) { b0 = q.x; i0 = r * 3 + 1; f0 = false; }
+            if (f0 || q.y > b0 || q.y != q.y) { b0 = q.y; i0 = r * 3 + 2; f0 = false; }
+            if (f1 || q.y > b1 || q.y != q.y) { b1 = q.y; i1 = r * 3; f1 = false; }
+            if (f1 || q.z > b1 || q.z != q.z) { b1 = q.z; i1 = r * 3 + 1; f1 = false; }
+            if (f1 || q.w > b1 || q.w != q.w) { b1 = q.w; i1 = r * 3 + 2; f1 = false; }
+        }
+        const size_t o = (nc * Ho + ho) * Wo + 2 * j;
+        *reinterpret_cast<float2*>(y + o) = make_float2(b0, b1);
+        if (idx) { idx[o] = (uint8_t)i0; idx[o + 1] = (uint8_t)i1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                           int NC, int H, int W, int Ho, int Wo) {
+    const int W4 = W / 4;
+    const size_t total = (size_t)NC * H * W4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % W4);
+        const int hi = (int)((i / W4) % H);
+        const size_t nc = i / ((size_t)W4 * H);
+        const float* g = dy + nc * Ho * Wo;
+        const uint8_t* ix = idx + nc * Ho * Wo;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            const int base = (hi - (2 * ho - 1)) * 3;
+            const int row = ho * Wo + 2 * j;
+            const float2 gg = *reinterpret_cast<const float2*>(g + row);
+            const int k0 = ix[row], k1 = ix[row + 1];
+            if (k0 == base + 1) acc.x += gg.x;
+            if (k0 == base + 2) acc.y += gg.x;
+            if (k1 == base) acc.y += gg.y;
+            if (k1 == base + 1) acc.z += gg.y;
+            if (k1 == base + 2) acc.w += gg.y;
+            if (2 * j + 2 < Wo && ix[row + 2] == base) acc.w += g[row + 2];
+        }
+        *reinterpret_cast<float4*>(dx + (nc * H + hi) * W + 4 * j) = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // soft-argmax head: one 256-thread block per (b, j).  Logit (h, w, d) of joint j lives at
 // z[((b*D*J + d*J + j)*H + h)*W + w]: for fixed d the H*W plane is contiguous -> coalesced reads.
@@ -216,6 +282,12 @@ extern "C" {
 int32_t p3d_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int32_t NC, int32_t H, int32_t W, void* stream) {
     P3D_REQUIRE(x && y && NC > 0 && H > 0 && W > 0, "maxpool_fwd: bad argument");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0) {
+        const int64_t total4 = (int64_t)NC * Ho * (W / 4);
+        const unsigned blocks4 = (unsigned)(ceil_div(total4, 256) < 16384 ? ceil_div(total4, 256) : 16384);
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, x, y, idx, NC, H, W, Ho, Wo);
+        return check_launch("maxpool_fwd");
+    }
     const int64_t total = (int64_t)NC * Ho * Wo;
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, idx, NC, H, W, Ho, Wo);
@@ -225,6 +297,12 @@ int32_t p3d_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int32_t NC,
 int32_t p3d_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t NC, int32_t H, int32_t W, void* stream) {
     P3D_REQUIRE(dy && idx && dx && NC > 0 && H > 0 && W > 0, "maxpool_bwd: bad argument");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (W % 4 == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dy & 7) == 0) {
+        const int64_t total4 = (int64_t)NC * H * (W / 4);
+        const unsigned blocks4 = (unsigned)(ceil_div(total4, 256) < 16384 ? ceil_div(total4, 256) : 16384);
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, NC, H, W, Ho, Wo);
+        return check_launch("maxpool_bwd");
+    }
     const int64_t total = (int64_t)NC * H * W;
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, NC, H, W, Ho, Wo);

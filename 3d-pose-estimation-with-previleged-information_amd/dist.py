@@ -104,6 +104,9 @@ class GradReducer:
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         self._launched[b] = True
+        if self.opt.flat_g.is_cuda:
+            from . import ops
+            ops.join_side_stream(self.opt.flat_g.device)       # weight gradients are written on the side stream (ops.WGRAD_STREAM)
         if os.environ.get('P3D_REDUCE_BLOCKING'):                     # debugging aid
             dist.all_reduce(self.opt.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.group)
             return

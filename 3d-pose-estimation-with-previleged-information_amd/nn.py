@@ -43,7 +43,10 @@ class BatchNorm2d(nn.BatchNorm2d):
         training = self.training
         momentum = 0.1 if self.momentum is None else self.momentum
         if training:
-            self.num_batches_tracked.add_(1)
+            if getattr(self, '_ticked', False):       # already counted by the network's pre-hook (_trunk._tick_batchnorm)
+                self._ticked = False
+            else:
+                self.num_batches_tracked.add_(1)
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training,
                                   momentum, self.eps, res_join)
 

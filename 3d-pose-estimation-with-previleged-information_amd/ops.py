@@ -5,6 +5,7 @@ happens only in the hand-written HIP kernels.  Tensors must be fp32 on a HIP dev
 no CPU or eager-PyTorch fallback: anything else raises P3DError.
 """
 import ctypes
+import os
 
 import torch
 
@@ -65,6 +66,52 @@ def workspace(device, nbytes):
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[device] = ws
     return ws
+
+
+# Weight-gradient kernels leave the critical path of backward (dy -> BN backward -> dgrad -> next layer): they only feed the
+# optimizer.  With P3D_WGRAD_STREAM != 0 they are launched on a second HIP stream, so the matrix-core-bound wgrad of layer i
+# overlaps the HBM-bound BN backward and the grid tails of layer i-1's kernels instead of queueing behind them.
+# join_side_stream() orders the launch stream after everything issued there (before an all-reduce / the optimizer reads .grad).
+WGRAD_STREAM = os.environ.get('P3D_WGRAD_STREAM', '1') != '0'
+_side_streams = {}
+_side_workspaces = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
+
+
+def _side_workspace(device, nbytes):
+    ws = _side_workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        with torch.cuda.stream(_side_stream(device)):
+            ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _side_workspaces[device] = ws
+    return ws
+
+
+_join_queued = False
+
+
+def join_side_stream(device=None):
+    global _join_queued
+    _join_queued = False
+    for dev, st in _side_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def _queue_join():
+    """First side-stream launch of a backward pass: have the autograd engine join the streams when the pass ends, so whoever
+    called .backward() sees complete gradients on the launch stream (like any other autograd result)."""
+    global _join_queued
+    if not _join_queued:
+        _join_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
 
 
 def _grad_sink(param):
@@ -177,9 +224,22 @@ class Conv2dFn(torch.autograd.Function):
             dw = torch.empty_like(w) if sink is None else sink
             d.accumulate = 0 if sink is None else 1
             nbytes = L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
-            ws = workspace(x.device, nbytes)
-            with _Timed('wgrad', d):
-                check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
+            if WGRAD_STREAM and sink is not None:
+                side = _side_stream(x.device)
+                _queue_join()
+                side.wait_stream(torch.cuda.current_stream())          # dy (and the zeroed gradient buffer) are ready
+                ws = _side_workspace(x.device, nbytes)
+                with torch.cuda.stream(side):
+                    with _Timed('wgrad', d):
+                        check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), _stream()),
+                              'p3d_conv2d_wgrad')
+                for t in (dy, x, mult, mask_in):                        # freed by autograd while the side stream may still read them
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                ws = workspace(x.device, nbytes)
+                with _Timed('wgrad', d):
+                    check(L.p3d_conv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mult), _p(mask_in), _p(dw), _p(ws), ws.numel(), st), 'p3d_conv2d_wgrad')
             if sink is not None:
                 dw = None
                 _grad_done(w_param)
@@ -290,11 +350,12 @@ class BatchNormActFn(torch.autograd.Function):
             ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
             check(L.p3d_bn_train_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
                                      n, c, h * w, momentum, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_bn_train_fwd')
-            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+            # the ReLU mask of a residual-free layer is recomputed from x in backward: y is not read (nor kept alive) for it
+            ctx.save_for_backward(x, y if (relu and res is not None) else None, gamma, mean, invstd, beta)
         else:
             check(L.p3d_bn_eval_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y),
                                     n, c, h * w, eps, int(relu), st), 'p3d_bn_eval_fwd')
-            ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var)
+            ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var, beta)
         ctx.cfg = (bool(relu), bool(training), eps, res is not None)
         ctx.params = (gamma, beta)
         ctx.res_join = res_join
@@ -302,7 +363,7 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, s1, s2 = ctx.saved_tensors
+        x, y, gamma, s1, s2, beta = ctx.saved_tensors
         relu, training, eps, has_res = ctx.cfg
         dy = dy.contiguous()
         n, c, h, w = x.shape
@@ -319,7 +380,7 @@ class BatchNormActFn(torch.autograd.Function):
         ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
         dres_ptr = _p(dres) if (dres is not None and relu) else None
         if training:
-            check(L.p3d_bn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
+            check(L.p3d_bn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),
                                      n, c, h * w, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_bn_train_bwd')
         else:
             check(L.p3d_bn_eval_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(s1), _p(s2), _p(dx), dres_ptr, _p(dgamma), _p(dbeta),

@@ -100,32 +100,54 @@ def main():
         loss = trainer.train_step(*batches[i % nbuf])
     sync()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof_overlapped, ops.PROFILE = ops.PROFILE, None
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(loss)
 
+    # Kernel pass (not part of `value`): the same steps once more with the weight-gradient kernels back on the launch stream.
+    # In the product configuration they run concurrently with the dgrad / BN-backward chain on a second stream, so a HIP-event
+    # bracket around one launch also spans time its CUs were lent to the other stream; serialised, a bracket is that kernel alone.
+    overlap = ops.WGRAD_STREAM
+    ops.WGRAD_STREAM = False
+    ksteps = min(opt.steps, 10)
+    trainer.train_step(*batches[0])
+    sync()
+    ops.PROFILE = [] if rank == 0 else None
+    t1 = time.perf_counter()
+    for i in range(ksteps):
+        trainer.train_step(*batches[i % nbuf])
+    sync()
+    serial_elapsed = time.perf_counter() - t1
+    prof, ops.PROFILE = ops.PROFILE, None
+    ops.WGRAD_STREAM = overlap
+
     if rank == 0:
         crops = opt.batch * world * opt.steps
         value = crops / elapsed
-        conv_ms = {}
-        conv_flops = 0.0
-        for kind, flops, start, end in prof:
-            conv_ms[kind] = conv_ms.get(kind, 0.0) + start.elapsed_time(end)
-            conv_flops += flops
-        conv_total_ms = sum(conv_ms.values())
-        launches = len(prof)
+        def conv_stats(records, nsteps):
+            ms, flops = {}, 0.0
+            for kind, fl, start, end in records:
+                ms[kind] = ms.get(kind, 0.0) + start.elapsed_time(end)
+                flops += fl
+            return ms, flops, sum(ms.values()), len(records) // max(nsteps, 1)
+
+        conv_ms, conv_flops, conv_total_ms, launches = conv_stats(prof, ksteps)
+        ov_ms, _, ov_total_ms, _ = conv_stats(prof_overlapped, opt.steps)
         # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r01_traffic.json);
         # a profiler cannot run inside the timed region, so the committed measurement of the same workload is quoted
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64:
+        if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64 and opt.family == 'depthnet':
             with open(tpath) as f:
                 traffic = round(json.load(f)['bytes_per_launch_raw'])
-        gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if (opt.model == 'resnet50' and opt.family == 'depthnet') else conv_flops / 1e9 / (opt.batch * opt.steps)
-        achieved = gflop_crop * opt.batch * opt.steps / conv_total_ms          # GFLOP/ms == TFLOP/s
+        is_contract = opt.model == 'resnet50' and opt.family == 'depthnet'
+        gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if is_contract else conv_flops / 1e9 / (opt.batch * ksteps)
+        achieved = gflop_crop * opt.batch * ksteps / conv_total_ms             # GFLOP/ms == TFLOP/s
+        achieved_ov = gflop_crop * opt.batch * opt.steps / ov_total_ms
+        step_tflops = value / world * gflop_crop / 1e3                          # crops/s x GFLOP/crop, whole step, per GPU
         out = {
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
@@ -136,10 +158,15 @@ def main():
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                         'launches_per_step': launches // max(opt.steps, 1),
-                         'avg_launch_ms': round(conv_total_ms / max(launches, 1), 4),
-                         'conv_ms_per_step': {k: round(v / opt.steps, 3) for k, v in conv_ms.items()},
-                         'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1)},
+                         'launches_per_step': launches,
+                         'avg_launch_ms': round(conv_total_ms / max(len(prof), 1), 4),
+                         'conv_ms_per_step': {k: round(v / ksteps, 3) for k, v in conv_ms.items()},
+                         'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1),
+                         'measured': 'HIP events around every conv launch over %d extra steps of this run with the wgrad kernels serialised on the '
+                                     'launch stream (%.3f ms/step); in the timed region they share the GPU with the dgrad/BN chain on a second '
+                                     'stream, where the same brackets read %.2f TFLOP/s' % (ksteps, serial_elapsed / ksteps * 1e3, achieved_ov),
+                         'achieved_in_timed_region': round(achieved_ov, 2),
+                         'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet':
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)

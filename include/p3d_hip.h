@@ -101,9 +101,11 @@ int32_t p3d_bn_train_fwd(const float* x, const float* res, const float* gamma, c
                          int32_t N, int32_t C, int32_t HW, float momentum, float eps, int32_t relu,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the above.  y is the forward output (its sign is the ReLU mask; ignored when relu == 0).
+ * y may be NULL with relu != 0 when the forward had NO residual input: the mask is then recomputed from x, gamma, beta and the
+ * saved statistics (one tensor read less per pass); beta is only read in that case and may be NULL otherwise.
  * dres (may be NULL) receives the gradient of the residual input = masked dy.
  * accumulate != 0: dgamma / dbeta are added to (the caller's .grad buffers) instead of overwritten. */
-int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+int32_t p3d_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres,
                          float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -160,7 +160,7 @@ def test_bn_eval_fwd_bwd(pkg):
     assert relerr(host(gt.grad), dg_ref) < 1e-5 and relerr(host(bt.grad), db_ref) < 1e-5
 
 
-@pytest.mark.parametrize('shape', [(2, 5, 16, 16), (1, 3, 17, 15), (3, 2, 7, 9), (2, 64, 128, 128)])
+@pytest.mark.parametrize('shape', [(2, 5, 16, 16), (1, 3, 17, 15), (3, 2, 7, 9), (2, 3, 10, 12), (1, 2, 9, 8), (2, 3, 5, 4), (2, 64, 128, 128)])
 def test_maxpool_fwd_bwd_with_ties(shape, pkg):
     ops = pkg.ops
     rng = np.random.default_rng(sum(shape))
