@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int V_ROWS = 256 / KQ;            // rows covered per pass of the vector mapping
     constexpr int A_VPER = (BM * KQ + 255) / 256, B_VPER = (BN * KQ + 255) / 256;
     constexpr int A_PIECES = VA ? A_VPER : A_PER, B_PIECES = VB ? B_VPER : B_PER;
-    static_assert(WV == 0 || (MODE == MODE_WGRAD && !MASKED), "vector fetch is a WGRAD, unmasked variant");
+    static_assert(WV == 0 || MODE == MODE_WGRAD, "vector fetch is a WGRAD variant");
     static_assert(A_PER * 256 == BM * BK && B_PER * 256 == BN * BK, "tile must be a multiple of the block");
     static_assert(256 % BN == 0 || B_KFAST, "column-fast B mapping needs BN | 256");
 
@@ -172,12 +172,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     } else {
         rA = make_rsrc(p.A + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
         rB = make_rsrc(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
-        rM = make_rsrc(nullptr, 0);
+        rM = make_rsrc(MASKED && p.mask_in ? p.mask_in + (size_t)nfirst * HW : nullptr, MASKED && p.mask_in ? (size_t)(p.N - nfirst) * HW * 4 : 0);
     }
-    i32x4 rA4 = {0, 0, 0, 0}, rB4 = {0, 0, 0, 0};
+    // WGRAD of a partial conv: dy is scaled by mult (per output pixel), x by mask_in (per input pixel)
+    __amdgpu_buffer_rsrc_t rMu = make_rsrc(nullptr, 0);
+    if constexpr (MODE == MODE_WGRAD && MASKED)
+        rMu = make_rsrc(p.mult ? p.mult + (size_t)nfirst * HoWo : nullptr, p.mult ? (size_t)(p.N - nfirst) * HoWo * 4 : 0);
+    i32x4 rA4 = {0, 0, 0, 0}, rB4 = {0, 0, 0, 0}, rM4 = {0, 0, 0, 0}, rMu4 = {0, 0, 0, 0};
     if constexpr (MODE == MODE_WGRAD && WV >= 1) {
         rA4 = make_rsrc4(p.A + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
         rB4 = make_rsrc4(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
+        if constexpr (MASKED) {
+            rMu4 = make_rsrc4(p.mult ? p.mult + (size_t)nfirst * HoWo : nullptr, p.mult ? (size_t)(p.N - nfirst) * HoWo * 4 : 0);
+            rM4 = make_rsrc4(p.mask_in ? p.mask_in + (size_t)nfirst * HW : nullptr, p.mask_in ? (size_t)(p.N - nfirst) * HW * 4 : 0);
+        }
     }
     const bool use_mask = MASKED && (MODE == MODE_FWD ? p.mask_in != nullptr : (MODE == MODE_DGRAD ? p.mult != nullptr : false));
 
@@ -263,7 +271,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // step) and A_PER + B_PER single loads, so that the main loop can drop one piece between two MFMAs: the matrix pipe is busy
     // 64 cycles per MFMA and the wave's VALU / VMEM issue slots in that shadow are otherwise idle.
     int st_a_soff = 0, st_a_bad = 0, st_b_voff = 0, st_b_soff0 = 0, st_tail = 0;   // st_tail = OOB when there is no next K-step
+    // partial conv: per-pixel scale of the fetched operand, fetched with it and applied when the tile goes to LDS (a product in the
+    // fetch slot would make the wave wait for both loads right there)
     float st_a_scale = 1.f, st_b_scale = 1.f;
+    f32x4v st_a_scale4 = {1.f, 1.f, 1.f, 1.f}, st_b_scale4 = {1.f, 1.f, 1.f, 1.f};
 
     auto ld_prologue = [&](int kt) {
         if constexpr (MODE == MODE_FWD && TAPM) {
@@ -316,9 +327,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const bool kok = kk < k_end;
             const int n = kk / HoWo, pp = kk - n * HoWo;
             st_a_soff = ((((n - nfirst) * p.K + m0 + (VA ? t / KQ : t / BK)) * HoWo + pp) * 4) | (kok ? 0 : OOB);     // a voffset here
-            if constexpr (MASKED) { if (p.mult) st_a_scale = kok ? p.mult[(size_t)n * HoWo + pp] : 0.f; }
+            if constexpr (MASKED) {
+                if (p.mult) {
+                    if constexpr (VA) st_a_scale4 = raw_buffer_load_f32x4(rMu4, (((n - nfirst) * HoWo + pp) * 4) | (kok ? 0 : OOB) | st_tail, 0, 0);
+                    else st_a_scale = bload(rMu, (((n - nfirst) * HoWo + pp) * 4) | (kok ? 0 : OOB) | st_tail);
+                }
+            }
             const int nb = (n - nfirst) * p.C;
             if constexpr (VB) {
+                if constexpr (MASKED) {
+                    if (p.mask_in) st_b_scale4 = raw_buffer_load_f32x4(rM4, (((n - nfirst) * HW + pp) * 4) | (kok ? 0 : OOB) | st_tail, 0, 0);
+                }
                 // 1x1 / stride 1 / no padding: x[n][c][pp], 4 consecutive pixels per lane; with VA the scalar kk mapping is not used
                 st_b_voff = (((nb + (TAPM ? wg_c0 : n0) + t / KQ) * HW + pp) * 4) | (kok ? 0 : OOB);
             } else {
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 const bool okp = kokb && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const int pix = hi * p.W + wi;
                 st_b_voff = (((nbB + wg_c0 + t / BK) * HW + pix) * 4) | (okp ? 0 : OOB);
-                if constexpr (MASKED) { if (p.mask_in) st_b_scale = okp ? p.mask_in[(size_t)nB * HW + pix] : 0.f; }
+                if constexpr (MASKED) { if (p.mask_in) st_b_scale = bload(rM, (((nB - nfirst) * HW + pix) * 4) | (okp ? 0 : OOB) | st_tail); }
             } else {
 #pragma unroll
                 for (int i = 0; i < B_PER; ++i) {
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     const int hi = hb + r * p.dil, wi = wb + s * p.dil;
                     const bool ok = kokb && j < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && st_tail == 0;
                     float v = bload(rB, ok ? ((nbB + c) * HW + hi * p.W + wi) * 4 : OOB);
-                    if constexpr (MASKED) { if (p.mask_in) v *= ok ? p.mask_in[(size_t)nB * HW + hi * p.W + wi] : 0.f; }
+                    if constexpr (MASKED) { if (p.mask_in) v *= bload(rM, ok ? ((nB - nfirst) * HW + hi * p.W + wi) * 4 : OOB); }
                     rb[i] = v;
                 }
             }
@@ -365,7 +384,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             return;
         } else {
             v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, st_a_soff | a_voff[i] | st_tail, K_ROWS * i * HoWo * 4, 0));
-            if constexpr (MASKED) v *= st_a_scale;
         }
         ra[i] = v;
     };
@@ -385,7 +403,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int bad = (chan_pad && crow + t / BN >= chan_lim) ? OOB : 0;
             v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, st_b_voff | bad | st_tail, crow * (MODE == MODE_FWD ? HW : HoWo) * 4, 0));
         }
-        if constexpr (MASKED) v *= st_b_scale;
         rb[i] = v;
     };
     auto load_tiles = [&](int kt) {           // whole fetch at once (prologue of the K loop)
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 const int row = t / KQ + V_ROWS * i;
                 if (row < BM) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) As[(buf * BK + 4 * (t % KQ) + j) * LDA + row] = ra[4 * i + j];
+                    for (int j = 0; j < 4; ++j) As[(buf * BK + 4 * (t % KQ) + j) * LDA + row] = MASKED ? ra[4 * i + j] * st_a_scale4[j] : ra[4 * i + j];
                 }
             }
         } else
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             int kk_l, m_l;
             if constexpr (A_MFAST) { const int e = t + 256 * i; m_l = e % BM; kk_l = e / BM; }
             else { kk_l = t % BK; m_l = t / BK + K_ROWS * i; }
-            As[(buf * BK + kk_l) * LDA + m_l] = ra[i];
+            As[(buf * BK + kk_l) * LDA + m_l] = (MASKED && MODE == MODE_WGRAD) ? ra[i] * st_a_scale : ra[i];
         }
         if constexpr (VB) {
 #pragma unroll
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 const int row = t / KQ + V_ROWS * i;
                 if (row < BN) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[(buf * BK + 4 * (t % KQ) + j) * LDB + row] = rb[4 * i + j];
+                    for (int j = 0; j < 4; ++j) Bs[(buf * BK + 4 * (t % KQ) + j) * LDB + row] = MASKED ? rb[4 * i + j] * st_b_scale4[j] : rb[4 * i + j];
                 }
             }
         } else
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             int kk_l, c_l;
             if constexpr (B_KFAST) { kk_l = t % BK; c_l = t / BK + K_ROWS * i; }
             else { c_l = t % BN; kk_l = t / BN + (256 / BN) * i; }
-            Bs[(buf * BK + kk_l) * LDB + c_l] = rb[i];
+            Bs[(buf * BK + kk_l) * LDB + c_l] = (MASKED && TAPM) ? rb[i] * st_b_scale : rb[i];
         }
     };
 
@@ -793,7 +810,19 @@ static int pick_cfg(int M, int Ncols, int64_t zmult) {
 
 template <int MODE, int BM, int BN, int WM, int WN, int BK>
 static void launch_variant(bool tapm, bool masked, int wv, dim3 grid, hipStream_t st, const IgemmParams& p) {
-    constexpr bool ALLOW_MASK = (BM == 128 && BN == 128) || (BM == 64 && BN == 256);
+    constexpr bool ALLOW_MASK = BK == 16 || (BM == 64 && BN == 64);          // every production shape; not the BK = 32 experiments (cfg 6, 7)
+    if constexpr (MODE == MODE_WGRAD && ALLOW_MASK) {
+        if (masked && wv == 2) {
+            if (tapm) hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, true, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, true, 2>), grid, dim3(256), 0, st, p);
+            return;
+        }
+        if (masked && wv == 1) {
+            if (tapm) hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, true, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, false, true, 1>), grid, dim3(256), 0, st, p);
+            return;
+        }
+    }
     if constexpr (MODE == MODE_WGRAD) {
         if (!masked && wv == 2) {
             if (tapm) hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, false, 2>), grid, dim3(256), 0, st, p);
@@ -821,8 +850,8 @@ static void launch_variant(bool tapm, bool masked, int wv, dim3 grid, hipStream_
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, BK, true, false>), grid, dim3(256), 0, st, p);
 }
 
-static int mask_cfg(int cfg, bool masked) {   // masked variants exist for the two largest shapes only
-    if (masked && cfg != 0 && cfg != 1) return (kCfgs[cfg].bm == 64) ? 1 : 0;
+static int mask_cfg(int cfg, bool masked) {   // masked (partial-conv) variants exist for the production shapes 0..5
+    if (masked && cfg > 5) return (kCfgs[cfg].bm == 64) ? 3 : 0;
     return cfg;
 }
 
@@ -853,7 +882,7 @@ static WgradPlan plan_wgrad(const p3d_conv_desc* d, bool masked) {
     bool tapm = false;
     double best = 1e300;
     for (int i = 0; i < 8; ++i) {
-        if (masked && i > 1) break;
+        if (masked && i >= 6) break;                      // no masked instances of the experimental shapes
         if (!masked && forced_cfg() >= 0 && i != forced_cfg()) continue;
         if (forced_cfg() < 0 && i >= 6) break;            // experimental shapes only when forced
         const bool tm = d->C % kCfgs[i].bn == 0;
@@ -1099,9 +1128,10 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     p.kchunk = pl.kchunk;
     p.cpad = d->C;
     int wv = 0;
-    if (!masked && (d->Ho * d->Wo) % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };     // NULL counts as aligned
+    if ((d->Ho * d->Wo) % 4 == 0 && al16(dy) && al16(mult)) {
         wv = 1;
-        if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) wv = 2;
+        if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && al16(x) && al16(mask_in)) wv = 2;
     }
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
     launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
