@@ -55,11 +55,15 @@ def create_pair(args):
 
 
 def main(argv=None):
-    from . import opts
+    """depth_main.py:110-161.  One process per GPU (torchrun) replaces nn.DataParallel / -n_cudas."""
+    from . import log, opts
     args = opts.parse(argv)
-    assert not (args.do_teach and args.do_fusion and args.depth_only)
+    assert not (args.resume and args.pretrain)
+    assert not (args.do_fusion and args.depth_only)
+    assert not (args.depth_host and args.depth_only)
     rank, world, local_rank = p3d_dist.init_from_env()
     torch.cuda.set_device(local_rank)
+    say = print if rank == 0 else (lambda *a, **k: None)
     teacher = None
     if args.do_teach:
         model, teacher, state = create_pair(args)
@@ -67,22 +71,43 @@ def main(argv=None):
     else:
         model, state = create_model(args)
     model = model.cuda()
+    say('=> Models are created and filled')
+
     data_info = get_info()
-    loader_mod = importlib.import_module('.depth_datasets', package=__package__)
-    train_loader = loader_mod.data_loader(args, 'train', data_info)
+    module = depth_train.get_loader(args)
+    data_loader = None
+    if args.test_only:
+        test_loader = module.data_loader(args, 'test', data_info)
+    elif args.val_only:
+        test_loader = module.data_loader(args, 'valid', data_info)
+    else:
+        test_loader = module.data_loader(args, 'valid', data_info)
+        data_loader = module.data_loader(args, 'train', data_info)
+    say('=> Dataloaders are ready')
+
+    logger = log.Logger(args, state)
+    say('=> Logger is ready')
     trainer = depth_train.Trainer(args, model, data_info)
     trainer.verbose = rank == 0
+    say('=> Trainer is ready')
     if teacher is not None:
         trainer.set_teacher(teacher)
-    start = state['epoch'] + 1 if state else 1
-    for epoch in range(start, args.n_epochs + 1):
-        record = trainer.train(epoch, train_loader)
-        if rank == 0 and args.save_record:
-            save_dir = os.path.join(args.save_path, args.model + '-' + args.suffix)
-            os.makedirs(save_dir, exist_ok=True)
-            torch.save(dict(state=dict(epoch=epoch), model=model.state_dict()), os.path.join(save_dir, 'model_%d.pth' % epoch))   # log.py:32-40
+
+    if args.test_only or args.val_only:
+        say('=> Evaluation starts')
+        test_rec = trainer.test(0, test_loader)
         if rank == 0:
-            print(record)
+            logger.print_rec(test_rec)
+        return test_rec
+    start_epoch = logger.state['epoch'] + 1
+    say('=> Train starts')
+    for epoch in range(start_epoch, args.n_epochs + 1):
+        train_rec = trainer.train(epoch, data_loader)
+        test_rec = trainer.test(epoch, test_loader) if trainer.thresh is not None else {}     # metrics need metadata thresholds
+        logger.record(epoch, train_rec, test_rec, model)
+    if rank == 0:
+        logger.final_print()
+    return logger.state
 
 
 if __name__ == '__main__':

@@ -32,6 +32,17 @@ def _load_metadata(args):
     return None
 
 
+def get_loader(args):
+    """depth_train.py:15-19: the loader module metadata.json names for this dataset ('datasets' = RGB-only tuples,
+    'depth_datasets' = RGB + depth tuples); without a metadata file the RGB + depth loader."""
+    import importlib
+    metadata = _load_metadata(args)
+    name = metadata['loader'][args.data_name] if metadata and 'loader' in metadata else 'depth_datasets'
+    if name not in ('datasets', 'depth_datasets'):
+        raise ValueError('metadata.json names loader module %r; this build ships `datasets` and `depth_datasets`' % name)
+    return importlib.import_module('.' + name, package=__package__)
+
+
 def wrap_by_name(names, params):
     """depth_train.py:22-25 (the two groups get identical hyper-parameters; kept for interface parity)."""
     group_a = [param for name, param in zip(names, params) if 'bn' in name]
