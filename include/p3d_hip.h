@@ -182,6 +182,26 @@ int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H
 int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C,
                           int32_t H, int32_t W, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp16 path of -half_acc (depth_train.py:73-83,413-449: model.half(), fp32 master copies, static loss scale).
+ * Activations are NHWC fp16 (`void*` = device pointer to IEEE half), channel counts multiples of 8; accumulation is fp32.
+ * Weights come as fp16 images of the fp32 master [K][C][R][S]: [K][R][S][Cpad] (forward, wgrad columns) and
+ * [Cpad][R][S][K] (dgrad), produced by p3d_weight_images_f16 after every optimizer step.
+ * The descriptor is the fp32 one; d->C is the (padded) channel count of x.  Replaces the cuDNN half kernels behind
+ * nn.Conv2d after model.half() (depthnet.py:16-33,65-89).
+ * ------------------------------------------------------------------------------------------ */
+int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x_nhwc, const void* w_krsc, const float* bias, void* y_nhwc, void* stream);
+int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, void* dx_nhwc, void* stream);
+size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
+/* dw (fp32 master gradient [K][c_real][R][S]) = (d->accumulate ? dw : 0) + scale * wgrad; c_real <= d->C (stem: 3 of 8) */
+int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* x_nhwc, float* dw, int32_t c_real, float scale,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* layout / precision converters: dst = scale * src; Cpad >= C, multiple of 8, the padding channels are written as 0 */
+int32_t p3d_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t N, int32_t C, int32_t HW, int32_t Cpad, float scale, void* stream);
+int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, float scale, void* stream);
+int32_t p3d_weight_images_f16(const float* w, void* krsc, void* crsk /* may be NULL */, int32_t K, int32_t C, int32_t RS, int32_t Cpad,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif
