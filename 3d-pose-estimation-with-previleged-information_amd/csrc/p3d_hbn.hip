@@ -1,0 +1,380 @@
+// BatchNorm2d (+ residual + ReLU) and the 3x3/2 max pool on NHWC fp16 tensors: the HBM-bound half of `-half_acc`
+// (reference: nn.BatchNorm2d / F.relu / nn.MaxPool2d after model.half(), depthnet.py:42-56,98-116,139-140).
+//
+// x is [P pixels][C] fp16; a thread owns one 16-B group of 8 channels (g = t % G') for a strided set of pixels, so its
+// per-channel constants live in registers and every access is a 16-B vector, coalesced across the block.
+// Statistics: fp32 per-thread sums (a few hundred fp16 values each) -> LDS -> one fp32 partial per block, combined in fp64 by a
+// one-block-per-256-channels finalize kernel that also writes the per-channel coefficient table the apply pass reads.
+// gamma / beta / running statistics / their gradients stay fp32 (they ARE the master parameters).
+#include "p3d_common.h"
+
+namespace p3d {
+
+using h8 = _Float16 __attribute__((ext_vector_type(8)));
+constexpr int HBN_MAX_BLOCKS = 512;
+
+struct HbnGeom { int G, Gb, PL, nblk; };
+
+static HbnGeom hbn_geom(int P, int C) {
+    HbnGeom g;
+    g.G = C / 8;
+    g.Gb = g.G < 256 ? g.G : 256;
+    g.PL = 256 / g.Gb;
+    int64_t nb = ceil_div(ceil_div(P, g.PL), 4);                // ~4 pixels per thread at least
+    if (nb > HBN_MAX_BLOCKS) nb = HBN_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    g.nblk = (int)nb;
+    return g;
+}
+
+__device__ __forceinline__ float hbn_shift(float beta, float mean, float sc) { return __fmaf_rn(-mean, sc, beta); }
+
+// block-level sum of acc[16] over the PL pixel-lanes that share a channel group; result to partial[(blk * G + g) * 16 + e]
+__device__ __forceinline__ void hbn_block_reduce(const float (&acc)[16], float* sm, float* partial, int G, int Gb, int PL, int gbase) {
+    const int t = threadIdx.x, g = t % Gb, pl = t / Gb;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sm[(pl * Gb + g) * 16 + e] = acc[e];
+    __syncthreads();
+    for (int i = t; i < Gb * 16; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < PL; ++q) s += sm[q * Gb * 16 + i];
+        partial[((size_t)blockIdx.x * G + gbase) * 16 + i] = s;
+    }
+    __syncthreads();
+}
+
+// partial[blk][g][0..7] = sum x, [8..15] = sum x^2.  grid (nblk, G / Gb)
+__global__ __launch_bounds__(256) void hbn_stats_kernel(const _Float16* __restrict__ x, float* __restrict__ partial, int P, int C) {
+    __shared__ float sm[256 * 16];
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
+    const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
+        const h8 v = *reinterpret_cast<const h8*>(x + (size_t)p * C + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; acc[e] += f; acc[8 + e] = fmaf(f, f, acc[8 + e]); }
+    }
+    hbn_block_reduce(acc, sm, partial, G, Gb, PL, blockIdx.y * Gb);
+}
+
+// coef[c] = {sc, sh, mean, invstd}; also save_mean / save_invstd and the running statistics
+__global__ __launch_bounds__(256) void hbn_fwd_finalize_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                               float* save_mean, float* save_invstd, float4* __restrict__ coef, int P, int C,
+                                                               float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int G = C >> 3;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* q = partial + ((size_t)b * G + (c >> 3)) * 16 + (c & 7);
+        s1 += q[0]; s2 += q[8];
+    }
+    const double cnt = (double)P;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    save_mean[c] = fmean;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+    const float sc = invstd * gamma[c];
+    coef[c] = make_float4(sc, hbn_shift(beta[c], fmean, sc), fmean, invstd);
+}
+
+// eval mode: coefficients from the running statistics
+__global__ __launch_bounds__(256) void hbn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                                            const float* __restrict__ rv, float4* __restrict__ coef, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    coef[c] = make_float4(sc, beta[c] - rm[c] * sc, rm[c], invstd);
+}
+
+// y = act(x * sc + sh + res)
+__global__ __launch_bounds__(256) void hbn_apply_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res, const float4* __restrict__ coef,
+                                                        _Float16* __restrict__ y, int P, int C, int relu) {
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
+    const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float4 q = coef[g * 8 + e]; sc[e] = q.x; sh[e] = q.y; }
+    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
+        const size_t off = (size_t)p * C + g * 8;
+        const h8 v = *reinterpret_cast<const h8*>(x + off);
+        h8 r;
+        if (res) r = *reinterpret_cast<const h8*>(res + off);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = fmaf((float)v[e], sc[e], sh[e]);
+            if (res) f += (float)r[e];
+            if (relu) f = fmaxf(f, 0.f);
+            o[e] = (_Float16)f;
+        }
+        *reinterpret_cast<h8*>(y + off) = o;
+    }
+}
+
+// backward pass 1: partial[blk][g][0..7] = sum g, [8..15] = sum g * xhat, g = dy masked by the ReLU
+__global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ partial, int P, int C, int relu) {
+    __shared__ float sm[256 * 16];
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
+    const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
+    const bool recompute = relu && y == nullptr;
+    float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        mu[e] = mean[c]; is[e] = invstd[c];
+        sc[e] = is[e] * gamma[c];
+        sh[e] = recompute ? hbn_shift(beta[c], mu[e], sc[e]) : 0.f;
+    }
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
+        const size_t off = (size_t)p * C + g * 8;
+        const h8 gv = *reinterpret_cast<const h8*>(dy + off);
+        const h8 xv = *reinterpret_cast<const h8*>(x + off);
+        h8 yv;
+        if (relu && !recompute) yv = *reinterpret_cast<const h8*>(y + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gq = (float)gv[e];
+            const float xf = (float)xv[e];
+            if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+            else if (relu && !((float)yv[e] > 0.f)) gq = 0.f;
+            acc[e] += gq;
+            acc[8 + e] = fmaf(gq, (xf - mu[e]) * is[e], acc[8 + e]);
+        }
+    }
+    hbn_block_reduce(acc, sm, partial, G, Gb, PL, blockIdx.y * Gb);
+}
+
+// dgamma / dbeta and the per-channel constants of pass 2: coef[c] = {gamma*invstd, k1 = sum g / P, k2 = sum g xhat / P, 0}
+__global__ __launch_bounds__(256) void hbn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* dgamma, float* dbeta, float4* __restrict__ coef,
+                                                               int P, int C, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int G = C >> 3;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* q = partial + ((size_t)b * G + (c >> 3)) * 16 + (c & 7);
+        s1 += q[0]; s2 += q[8];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    coef[c] = make_float4(gamma[c] * invstd[c], (float)(s1 / P), (float)(s2 / P), 0.f);
+}
+
+// backward pass 2: dx = gamma*invstd*(g - k1 - xhat*k2), dres = g
+__global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float4* __restrict__ coef, _Float16* __restrict__ dx,
+                                                            _Float16* __restrict__ dres, int P, int C, int relu) {
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
+    const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
+    const bool recompute = relu && y == nullptr;
+    float mu[8], is[8], sc[8], sh[8], gs[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        mu[e] = mean[c]; is[e] = invstd[c];
+        sc[e] = is[e] * gamma[c];
+        sh[e] = recompute ? hbn_shift(beta[c], mu[e], sc[e]) : 0.f;
+        const float4 q = coef[c];
+        gs[e] = q.x; k1[e] = q.y; k2[e] = q.z;
+    }
+    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
+        const size_t off = (size_t)p * C + g * 8;
+        const h8 gv = *reinterpret_cast<const h8*>(dy + off);
+        const h8 xv = *reinterpret_cast<const h8*>(x + off);
+        h8 yv;
+        if (relu && !recompute) yv = *reinterpret_cast<const h8*>(y + off);
+        h8 o, gr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gq = (float)gv[e];
+            const float xf = (float)xv[e];
+            if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+            else if (relu && !((float)yv[e] > 0.f)) gq = 0.f;
+            gr[e] = (_Float16)gq;
+            o[e] = (_Float16)(gs[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
+        }
+        *reinterpret_cast<h8*>(dx + off) = o;
+        if (dres) *reinterpret_cast<h8*>(dres + off) = gr;
+    }
+}
+
+// ---- max pool 3x3 / stride 2 / pad 1 on NHWC fp16: one thread per (output pixel, 8-channel group) ----------------
+__global__ __launch_bounds__(256) void hmaxpool_fwd_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, uint8_t* __restrict__ idx,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const size_t pix = i / G;
+        const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Wo * Ho));
+        float best[8];
+        int bi[8];
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const h8 v = *reinterpret_cast<const h8*>(x + (((size_t)n * H + hi) * W + wi) * C + g * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    if (first || f > best[e] || f != f) { best[e] = f; bi[e] = r * 3 + s; }
+                }
+                first = false;
+            }
+        }
+        h8 o;
+        uint8_t ix[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = (_Float16)best[e]; ix[e] = (uint8_t)bi[e]; }
+        *reinterpret_cast<h8*>(y + i * 8) = o;
+        if (idx) *reinterpret_cast<uint2*>(idx + i * 8) = *reinterpret_cast<const uint2*>(ix);
+    }
+}
+
+__global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const _Float16* __restrict__ dy, const uint8_t* __restrict__ idx, _Float16* __restrict__ dx,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const size_t pix = i / G;
+        const int wi = (int)(pix % W), hi = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1, wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            const int r = hi - (2 * ho - 1);
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const int code = r * 3 + wi - (2 * wo - 1);
+                const size_t o = ((((size_t)n * Ho + ho) * Wo + wo) * G + g) * 8;
+                const h8 gq = *reinterpret_cast<const h8*>(dy + o);
+                const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+                const uint8_t* ix = reinterpret_cast<const uint8_t*>(&raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (ix[e] == code) acc[e] += (float)gq[e];
+            }
+        }
+        h8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (_Float16)acc[e];
+        *reinterpret_cast<h8*>(dx + i * 8) = o8;
+    }
+}
+
+static bool hbn_shape_ok(int C) { return C >= 8 && C % 8 == 0 && ((C / 8) <= 256 ? 256 % (C / 8) == 0 : (C / 8) % 256 == 0); }
+
+}  // namespace p3d
+
+using namespace p3d;
+
+extern "C" {
+
+size_t p3d_hbn_workspace_bytes(int32_t C) { return (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float) + (size_t)C * sizeof(float4); }
+
+int32_t p3d_hbn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          void* y, float* save_mean, float* save_invstd, int32_t P, int32_t C, float momentum, float eps, int32_t relu,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "hbn_train_fwd: null tensor");
+    P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_fwd: bad shape P=%d C=%d (C/8 must divide or be a multiple of 256)", P, C);
+    P3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hbn_train_fwd: running stats must come as a pair");
+    if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_train_fwd: workspace too small"); return P3D_EWORKSPACE; }
+    const HbnGeom g = hbn_geom(P, C);
+    float* partial = (float*)workspace;
+    float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(g.nblk, g.G / g.Gb);
+    hipLaunchKernelGGL(hbn_stats_kernel, grid, dim3(256), 0, st, (const _Float16*)x, partial, P, C);
+    hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, coef, P, C, momentum, eps);
+    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
+    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
+    hipLaunchKernelGGL(hbn_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef, (_Float16*)y, P, C, relu);
+    return check_launch("hbn_train_fwd");
+}
+
+int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, void* y, int32_t P, int32_t C, float eps, int32_t relu, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(x && gamma && beta && running_mean && running_var && y, "hbn_eval_fwd: null tensor");
+    P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_eval_fwd: bad shape P=%d C=%d", P, C);
+    if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_eval_fwd: workspace too small"); return P3D_EWORKSPACE; }
+    const HbnGeom g = hbn_geom(P, C);
+    float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hbn_eval_coef_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, coef, C, eps);
+    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
+    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
+    hipLaunchKernelGGL(hbn_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef, (_Float16*)y, P, C, relu);
+    return check_launch("hbn_eval_fwd");
+}
+
+int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta, int32_t P, int32_t C, int32_t relu,
+                          int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "hbn_train_bwd: null tensor");
+    P3D_REQUIRE(!relu || y || (beta && !dres), "hbn_train_bwd: relu backward needs the forward output (or beta and no residual)");
+    P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_bwd: bad shape P=%d C=%d", P, C);
+    if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_train_bwd: workspace too small"); return P3D_EWORKSPACE; }
+    const HbnGeom g = hbn_geom(P, C);
+    float* partial = (float*)workspace;
+    float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(g.nblk, g.G / g.Gb);
+    hipLaunchKernelGGL(hbn_bwd_reduce_kernel, grid, dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y, gamma, beta, save_mean,
+                       save_invstd, partial, P, C, relu);
+    hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, save_invstd,
+                       dgamma, dbeta, coef, P, C, accumulate);
+    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
+    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
+    hipLaunchKernelGGL(hbn_bwd_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y, gamma, beta, save_mean,
+                       save_invstd, (const float4*)coef, (_Float16*)dx, (_Float16*)dres, P, C, relu);
+    return check_launch("hbn_train_bwd");
+}
+
+int32_t p3d_hmaxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    P3D_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "hmaxpool_fwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
+    hipLaunchKernelGGL(hmaxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, idx, N, H, W, C, Ho, Wo);
+    return check_launch("hmaxpool_fwd");
+}
+
+int32_t p3d_hmaxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    P3D_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "hmaxpool_bwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
+    hipLaunchKernelGGL(hmaxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, idx, (_Float16*)dx, N, H, W, C, Ho, Wo);
+    return check_launch("hmaxpool_bwd");
+}
+
+}  // extern "C"

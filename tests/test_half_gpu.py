@@ -109,3 +109,90 @@ def test_layout_converters(pkg):
     back = torch.empty(3, 8, 7, 9, dtype=torch.float32, device='cuda')
     pkg._lib.check(L.p3d_nhwc_f16_to_nchw_f32(ops._p(out), ops._p(back), 3, 8, 63, 0.5, ops._stream()), 'to nchw')
     assert np.array_equal(back.cpu().numpy()[:, :5], (2 * x).astype(np.float16).astype(np.float32) * 0.5)
+
+
+@pytest.mark.parametrize('n,c,h,w,relu,with_res', [(4, 64, 16, 16, True, False), (3, 256, 9, 7, True, True), (2, 8, 33, 31, False, False),
+                                                  (2, 2048, 4, 4, True, True), (5, 128, 8, 8, False, True), (64, 64, 32, 32, True, False)])
+def test_hbn_train_fwd_bwd(n, c, h, w, relu, with_res, pkg):
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    p, st = ops._p, ops._stream()
+    rng = np.random.default_rng(n * 1000 + c)
+    x = r16(rng.standard_normal((n, c, h, w)) * 2 + 1)
+    res = r16(rng.standard_normal((n, c, h, w))) if with_res else None
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(c)).astype(np.float32)
+    rm = rng.standard_normal(c).astype(np.float32)
+    rv = (1 + rng.random(c)).astype(np.float32)
+    y_ref, mean, invstd, nrm, nrv = ref.bn_train_fwd(x, gamma, beta, rm, rv)
+    pre = y_ref + (res if with_res else 0)
+    out_ref = np.maximum(pre, 0) if relu else pre
+    P = n * h * w
+    xt = nhwc16(x)
+    rt = nhwc16(res) if with_res else None
+    gt, bt, rmt, rvt = (torch.from_numpy(a.copy()).cuda() for a in (gamma, beta, rm, rv))
+    yt = torch.empty_like(xt)
+    sm, si = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    ws = torch.empty(L.p3d_hbn_workspace_bytes(c), dtype=torch.uint8, device='cuda')
+    pkg._lib.check(L.p3d_hbn_train_fwd(p(xt), p(rt), p(gt), p(bt), p(rmt), p(rvt), p(yt), p(sm), p(si), P, c, 0.1, 1e-5, int(relu),
+                                       p(ws), ws.numel(), st), 'hbn fwd')
+    assert np.abs(nchw32(yt) - out_ref).max() < 2e-3 * max(1.0, np.abs(out_ref).max())
+    assert relerr(sm.cpu().numpy(), mean) < 1e-5 and relerr(si.cpu().numpy(), invstd) < 1e-5
+    assert relerr(rmt.cpu().numpy(), nrm) < 1e-5 and relerr(rvt.cpu().numpy(), nrv) < 1e-5
+    # backward: the mask comes from the kernel's own fp16 output (or is recomputed from x when there is no residual)
+    dy = r16(rng.standard_normal(x.shape))
+    y_dev = nchw32(yt)
+    g = (dy * (y_dev > 0)).astype(np.float32) if relu else dy
+    dx_ref, dg_ref, db_ref = ref.bn_train_bwd(g, x, mean, invstd, gamma)
+    dyt = nhwc16(dy)
+    dxt = torch.empty_like(xt)
+    drt = torch.empty_like(xt) if with_res else None
+    dg, db = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
+    y_arg = yt if (relu and with_res) else None
+    pkg._lib.check(L.p3d_hbn_train_bwd(p(dyt), p(xt), p(y_arg), p(gt), p(bt), p(sm), p(si), p(dxt), p(drt), p(dg), p(db), P, c, int(relu), 1,
+                                       p(ws), ws.numel(), st), 'hbn bwd')
+    assert np.abs(nchw32(dxt) - dx_ref).max() < 3e-3 * max(1.0, np.abs(dx_ref).max())
+    assert relerr(dg.cpu().numpy() - 1, dg_ref) < 2e-3 and relerr(db.cpu().numpy() - 1, db_ref) < 2e-3
+    if with_res:
+        assert np.array_equal(nchw32(drt), g)
+
+
+def test_hbn_eval_fwd(pkg):
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    p, st = ops._p, ops._stream()
+    rng = np.random.default_rng(3)
+    n, c, h, w = 3, 32, 9, 9
+    x = r16(rng.standard_normal((n, c, h, w)))
+    gamma, beta = rng.standard_normal(c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    rm, rv = rng.standard_normal(c).astype(np.float32), (0.5 + rng.random(c)).astype(np.float32)
+    y_ref = np.maximum(ref.bn_eval_fwd(x, gamma, beta, rm, rv), 0)
+    xt = nhwc16(x)
+    yt = torch.empty_like(xt)
+    ws = torch.empty(L.p3d_hbn_workspace_bytes(c), dtype=torch.uint8, device='cuda')
+    args = [torch.from_numpy(a).cuda() for a in (gamma, beta, rm, rv)]
+    pkg._lib.check(L.p3d_hbn_eval_fwd(p(xt), None, p(args[0]), p(args[1]), p(args[2]), p(args[3]), p(yt), n * h * w, c, 1e-5, 1, p(ws), ws.numel(), st), 'eval')
+    assert np.abs(nchw32(yt) - y_ref).max() < 2e-3 * max(1.0, np.abs(y_ref).max())
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (1, 16, 17, 15), (3, 64, 7, 9), (2, 64, 128, 128)])
+def test_hmaxpool(shape, pkg):
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    p, st = ops._p, ops._stream()
+    n, c, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = r16(np.maximum(rng.standard_normal(shape), 0))
+    y_ref, idx_ref = ref.maxpool3x3s2_fwd(x)
+    ho, wo = y_ref.shape[2:]
+    xt = nhwc16(x)
+    yt = torch.empty(n, ho, wo, c, dtype=torch.float16, device='cuda')
+    it = torch.empty(n, ho, wo, c, dtype=torch.uint8, device='cuda')
+    pkg._lib.check(L.p3d_hmaxpool3x3s2_fwd(p(xt), p(yt), p(it), n, h, w, c, st), 'pool')
+    assert np.array_equal(nchw32(yt), y_ref)
+    assert np.array_equal(it.permute(0, 3, 1, 2).cpu().numpy(), idx_ref)
+    dy = r16(rng.standard_normal(y_ref.shape))
+    dxt = torch.empty_like(xt)
+    pkg._lib.check(L.p3d_hmaxpool3x3s2_bwd(p(nhwc16(dy)), p(it), p(dxt), n, h, w, c, st), 'pool bwd')
+    want = ref.maxpool3x3s2_bwd(dy, idx_ref, x.shape)
+    assert np.abs(nchw32(dxt) - want).max() < 2e-3 * max(1.0, np.abs(want).max())
