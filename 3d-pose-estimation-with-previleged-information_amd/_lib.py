@@ -61,6 +61,7 @@ SIGNATURES = {
     'p3d_hconv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
     'p3d_hconv2d_wgrad_workspace_bytes': (_sz, [_desc]),
     'p3d_hconv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _i32, _f32, _ptr, _sz, _ptr]),
+    'p3d_hconv2d_bgrad': (_i32, [_ptr, _i32, _i32, _ptr, _f32, _i32, _ptr]),
     'p3d_nchw_f32_to_nhwc_f16': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_nhwc_f16_to_nchw_f32': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_weight_images_f16': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),

@@ -63,7 +63,7 @@ class _ResidualBlock(nn.Module):
         if self.partial:                      # partial_depthnet.py:44-46: blocks receive an (x, veil) tuple
             return self.forward_partial(*x)
         # the block input fans out to conv1 and the shortcut: join the two input gradients inside conv1's dgrad kernel (ops.GradJoin)
-        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
+        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32) else None
         out = x
         last = len(self._chain) - 1
         for i, (cname, bname) in enumerate(self._chain):
@@ -136,6 +136,19 @@ class TrunkBase(nn.Module):
     def __init__(self):
         super().__init__()
         self.register_forward_pre_hook(_tick_batchnorm)
+
+    # -half_acc (depth_train.py:73-83): the Trainer sets `_p3d_half`; the network then runs on NHWC fp16 activations between
+    # these two conversions, parameters stay fp32 masters with fp16 weight images beside them (ops_half.refresh_weights).
+    _p3d_half = False
+
+    def _half_in(self, x):
+        from . import ops_half
+        return ops_half.to_half_nhwc(x, ops_half.pad8(x.shape[1])) if self._p3d_half else x
+
+    def _half_out(self, *tensors):
+        from . import ops_half
+        out = tuple(ops_half.to_float(t) if (t is not None and t.dtype == torch.float16) else t for t in tensors)
+        return out if len(out) > 1 else out[0]
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1, skip_relu=False, partial=False):
         downsample = None

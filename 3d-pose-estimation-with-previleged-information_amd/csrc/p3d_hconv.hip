@@ -560,3 +560,36 @@ int32_t p3d_weight_images_f16(const float* w, void* krsc, void* crsk, int32_t K,
 }
 
 }  // extern "C"
+
+namespace p3d {
+// db[k] (+)= scale * sum over pixels of dy[p][k]   (regressor bias, depthnet.py:156): one block per 8-channel group
+__global__ __launch_bounds__(256) void hbgrad_kernel(const _Float16* __restrict__ dy, float* __restrict__ db, int P, int K, float scale, int accumulate) {
+    const int g = blockIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const h8 v = *reinterpret_cast<const h8*>(dy + (size_t)p * K + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float s = wave_sum(acc[e]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale;
+        float* o = db + g * 8 + threadIdx.x;
+        *o = accumulate ? *o + s : s;
+    }
+}
+}  // namespace p3d
+
+extern "C" int32_t p3d_hconv2d_bgrad(const void* dy, int32_t P, int32_t K, float* db, float scale, int32_t accumulate, void* stream) {
+    P3D_REQUIRE(dy && db && P > 0 && K > 0 && K % 8 == 0, "hconv2d_bgrad: bad argument");
+    hipLaunchKernelGGL(p3d::hbgrad_kernel, dim3(K / 8), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, db, P, K, scale, accumulate);
+    return p3d::check_launch("hconv2d_bgrad");
+}

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import dist as p3d_dist
-from . import ops, utils
+from . import ops, ops_half, utils
 from .optim import FlatAdam
 
 root_me = os.path.join(os.sep, 'globalwork', 'liu')      # depth_train.py:12; override with -metadata / $P3D_METADATA
@@ -70,8 +70,9 @@ def to_test_worker(test_loader, no_depth, depth_only, do_fusion=False):
 class Trainer:
 
     def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
-        if args.half_acc:
-            raise NotImplementedError('-half_acc (fp16 master-copy path, depth_train.py:73-83,413-449) is a "next" row; fp32 is the parity path')
+        if args.half_acc and (args.do_fusion or args.partial_conv or args.do_teach or args.skip_relu):
+            raise NotImplementedError('-half_acc is implemented for the single-stream dense networks (depthnet / resnet); the fusion, '
+                                      'partial-conv and distillation variants run in fp32')
         if args.semi_teach:
             raise NotImplementedError('-semi_teach needs the unlabelled PKU loader (depth_train.py:67-71,132-153): out of scope')
         self.model = model
@@ -79,7 +80,9 @@ class Trainer:
         self.list_names = [name for name, param in model.named_parameters()]
         self.list_params = [param for name, param in model.named_parameters()]
 
-        self.half_acc = False
+        self.half_acc = bool(args.half_acc)
+        self.grad_scaling = args.grad_scaling
+        self.skipped_steps = 0
         self.depth_only = args.depth_only
         self.do_fusion = args.do_fusion
         self.do_teach = args.do_teach
@@ -96,6 +99,11 @@ class Trainer:
         self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
         self.reducer = p3d_dist.GradReducer(self.optimizer, reducer_bucket_bytes)
         self.world = self.reducer.world
+        if self.half_acc:
+            # depth_train.py:73-83: the reference halves the model and keeps fp32 `copy_params` for Adam.  Here the parameters stay
+            # fp32 (they are those copies, already flat inside FlatAdam) and every convolution gets fp16 weight images beside them.
+            model._p3d_half = True
+            ops_half.refresh_weights(model)
 
         self.depth = args.depth
         self.num_joints = args.num_joints
@@ -159,6 +167,18 @@ class Trainer:
                                        self.criterion, count_override=count)
         self.last_spec_cam = spec_cam
         self.optimizer.zero_grad()
+        if self.half_acc:
+            # static loss scaling (depth_train.py:413-449): gradients carry grad_scaling through the fp16 backward, the optimizer
+            # divides it out, and a step whose gradients overflowed is skipped
+            loss.backward(torch.full_like(loss, self.grad_scaling))
+            scale = self.reducer.finish()
+            if self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True):
+                ops_half.refresh_weights(self.model)
+            else:
+                self.skipped_steps += 1
+                if self.verbose:
+                    print('update step skipped')
+            return loss.detach()
         loss.backward()
         assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
         scale = self.reducer.finish()

@@ -35,13 +35,13 @@ class ResNet(TrunkBase):
         self.regressor = Conv2d(512 * block.expansion, args.depth * args.num_joints, 3, padding=1)
 
     def forward(self, x):
-        x = stem(self.conv1, self.bn1, self.maxpool, x)
+        x = stem(self.conv1, self.bn1, self.maxpool, self._half_in(x))
         x = self.layer1(x)
         x = self.layer2(x)
         m = self.layer3(x)
         n = self.layer4(ops.relu(m) if self.skip_relu else m)
         z = self.regressor(ops.relu(n) if self.skip_relu else n)
-        return z, m if self.early_dist else n
+        return self._half_out(z, m if self.early_dist else n)
 
 
 def build_resnet(block, layers, args, pretrain):

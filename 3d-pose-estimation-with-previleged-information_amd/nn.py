@@ -9,7 +9,7 @@ kernel is reachable from their forward.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops_half
 
 
 def _one(v):
@@ -29,6 +29,8 @@ class Conv2d(nn.Conv2d):
             raise ops.P3DError('Conv2d: groups != 1 / non-zero padding modes are not on the hot path')
 
     def forward(self, x, join_put=None, join_take=None):
+        if x.dtype == torch.float16:                        # -half_acc: NHWC fp16 kernels (ops_half.py)
+            return ops_half.conv2d(x, self, _one(self.stride), _one(self.padding), _one(self.dilation))
         return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation),
                           join_put=join_put, join_take=join_take)
 
@@ -47,6 +49,8 @@ class BatchNorm2d(nn.BatchNorm2d):
                 self._ticked = False
             else:
                 self.num_batches_tracked.add_(1)
+        if x.dtype == torch.float16:
+            return ops_half.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training, momentum, self.eps)
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training,
                                   momentum, self.eps, res_join)
 
@@ -57,7 +61,7 @@ class MaxPool2d(nn.MaxPool2d):
     def forward(self, x):
         if (_one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)) != (3, 2, 1, 1) or self.ceil_mode:
             raise ops.P3DError('MaxPool2d: only kernel 3, stride 2, padding 1 is on the hot path')
-        return ops.maxpool3x3s2(x)
+        return ops_half.maxpool3x3s2(x) if x.dtype == torch.float16 else ops.maxpool3x3s2(x)
 
 
 class Sequential(nn.Sequential):

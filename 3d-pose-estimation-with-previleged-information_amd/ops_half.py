@@ -1,0 +1,264 @@
+"""torch.autograd.Function wrappers of the fp16 kernels (`-half_acc`, reference depth_train.py:73-83,413-449).
+
+Activations are torch.float16 tensors of logical shape [N, C, H, W] in torch.channels_last memory format, i.e. NHWC in memory:
+what the f16 matrix-core kernels read with 16-B vectors.  Parameters stay fp32 (they are the masters the reference keeps in
+`copy_params`); every convolution owns two fp16 weight images refreshed after each optimizer step (`refresh_weights`).
+Weight / bias / BN-parameter gradients are produced in fp32, straight into the FlatAdam gradient buffer when there is one.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import P3DError, check, lib
+from .ops import _desc, _grad_done, _grad_sink, _p, _stream, workspace
+
+CL = torch.channels_last
+
+
+def _need_half(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float16 or t.dim() != 4:
+            raise P3DError('fp16 ops take 4-d torch.float16 tensors on a HIP device (got %s %s)' % (t.dtype, t.device))
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def _empty(n, c, h, w, device):
+    return torch.empty((n, c, h, w), dtype=torch.float16, device=device, memory_format=CL)
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def to_half_nhwc(x, cpad=None, scale=1.0):
+    """fp32 NCHW -> fp16 channels_last with the channel dimension zero-padded to cpad (input of the stem)."""
+    ops._need_gpu(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    cpad = pad8(c) if cpad is None else cpad
+    out = _empty(n, cpad, h, w, x.device)
+    check(lib().p3d_nchw_f32_to_nhwc_f16(_p(x), _p(out), n, c, h * w, cpad, scale, _stream()), 'p3d_nchw_f32_to_nhwc_f16')
+    return out
+
+
+class ToFloatFn(torch.autograd.Function):
+    """fp16 channels_last -> fp32 NCHW (the regressor output entering the fp32 head); backward converts the gradient back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_half(x)
+        x = _cl(x)
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        check(lib().p3d_nhwc_f16_to_nchw_f32(_p(x), _p(out), n, c, h * w, 1.0, _stream()), 'p3d_nhwc_f16_to_nchw_f32')
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return to_half_nhwc(dy.contiguous(), cpad=dy.shape[1])
+
+
+def to_float(x):
+    return ToFloatFn.apply(x)
+
+
+class WeightImages:
+    """fp16 images of one convolution's fp32 master weight: krsc [K,R,S,Cpad] and crsk [Cpad,R,S,K]."""
+
+    def __init__(self, weight, need_dgrad=True):
+        k, c, r, s = weight.shape
+        self.c_real, self.cpad = c, pad8(c)
+        self.krsc = torch.empty((k, r, s, self.cpad), dtype=torch.float16, device=weight.device)
+        self.crsk = torch.empty((self.cpad, r, s, k), dtype=torch.float16, device=weight.device) if need_dgrad else None
+        self.refresh(weight)
+
+    def refresh(self, weight):
+        k, c, r, s = weight.shape
+        check(lib().p3d_weight_images_f16(_p(weight.detach()), _p(self.krsc), _p(self.crsk), k, c, r * s, self.cpad, _stream()), 'p3d_weight_images_f16')
+
+
+def refresh_weights(model):
+    """(Re)build the fp16 weight images of every convolution of `model` from the fp32 masters: after construction, after
+    load_state_dict and after every optimizer step (the reference's `h_param.data.copy_(c_param.data)`, depth_train.py:448-449)."""
+    from .nn import Conv2d
+    for m in model.modules():
+        if isinstance(m, Conv2d):
+            ops._need_gpu(m.weight)
+            img = getattr(m, '_h_images', None)
+            if img is None or img.krsc.device != m.weight.device:
+                m._h_images = WeightImages(m.weight, need_dgrad=m.weight.shape[1] >= 8)
+            else:
+                img.refresh(m.weight)
+
+
+class HConv2dFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, w, bias, images, stride, pad, dil):
+        _need_half(x)
+        ops._need_gpu(w, bias)
+        x = _cl(x)
+        n, c, h, wd = x.shape
+        k, _, r, s = w.shape
+        if c != images.cpad:
+            raise P3DError('hconv2d: input has %d channels, the weight image expects %d' % (c, images.cpad))
+        d = _desc((n, c, h, wd), (k, c, r, s), stride, pad, dil)
+        y = _empty(n, k, d.Ho, d.Wo, x.device)
+        with ops._Timed('fwd', d):
+            check(lib().p3d_hconv2d_fwd(ctypes.byref(d), _p(x), _p(images.krsc), _p(bias), _p(y), _stream()), 'p3d_hconv2d_fwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (stride, pad, dil, tuple(w.shape))
+        ctx.params = (w, bias)
+        ctx.images = images
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        stride, pad, dil, wshape = ctx.cfg
+        w_param, b_param = ctx.params
+        images = ctx.images
+        dy = _cl(dy)
+        n, c, h, wd = x.shape
+        k, _, r, s = wshape
+        d = _desc((n, c, h, wd), (k, c, r, s), stride, pad, dil)
+        L, st = lib(), _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if images.crsk is None:
+                raise P3DError('hconv2d: this layer was built without a dgrad weight image')
+            dx = _empty(n, c, h, wd, x.device)
+            with ops._Timed('dgrad', d):
+                check(L.p3d_hconv2d_dgrad(ctypes.byref(d), _p(dy), _p(images.crsk), _p(dx), st), 'p3d_hconv2d_dgrad')
+        if ctx.needs_input_grad[1]:
+            sink = _grad_sink(w_param)
+            dw = torch.empty(wshape, dtype=torch.float32, device=x.device) if sink is None else sink
+            d.accumulate = 0 if sink is None else 1
+            nbytes = L.p3d_hconv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            if ops.WGRAD_STREAM and sink is not None:
+                side = ops._side_stream(x.device)
+                ops._queue_join()
+                side.wait_stream(torch.cuda.current_stream())
+                ws = ops._side_workspace(x.device, nbytes)
+                with torch.cuda.stream(side):
+                    with ops._Timed('wgrad', d):
+                        check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), _stream()),
+                              'p3d_hconv2d_wgrad')
+                dy.record_stream(side)
+                x.record_stream(side)
+            else:
+                ws = workspace(x.device, nbytes)
+                with ops._Timed('wgrad', d):
+                    check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), st), 'p3d_hconv2d_wgrad')
+            d.accumulate = 0
+            if sink is not None:
+                dw = None
+                _grad_done(w_param)
+        if b_param is not None and ctx.needs_input_grad[2]:
+            sink = _grad_sink(b_param)
+            db = torch.empty(k, dtype=torch.float32, device=x.device) if sink is None else sink
+            check(L.p3d_hconv2d_bgrad(_p(dy), n * d.Ho * d.Wo, k, _p(db), 1.0, 0 if sink is None else 1, st), 'p3d_hconv2d_bgrad')
+            if sink is not None:
+                db = None
+                _grad_done(b_param)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, module, stride, pad, dil):
+    images = getattr(module, '_h_images', None)
+    if images is None:
+        raise P3DError('fp16 convolution without weight images: call ops_half.refresh_weights(model) first')
+    return HConv2dFn.apply(x, module.weight, module.bias, images, stride, pad, dil)
+
+
+class HBatchNormActFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps):
+        _need_half(x, res)
+        ops._need_gpu(gamma, beta, running_mean, running_var)
+        x = _cl(x)
+        res = None if res is None else _cl(res)
+        n, c, h, w = x.shape
+        L, st = lib(), _stream()
+        y = _empty(n, c, h, w, x.device)
+        ws = workspace(x.device, L.p3d_hbn_workspace_bytes(c))
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            check(L.p3d_hbn_train_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
+                                      n * h * w, c, momentum, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_hbn_train_fwd')
+            ctx.save_for_backward(x, y if (relu and res is not None) else None, gamma, beta, mean, invstd)
+        else:
+            check(L.p3d_hbn_eval_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), n * h * w, c, eps, int(relu),
+                                     _p(ws), ws.numel(), st), 'p3d_hbn_eval_fwd')
+            ctx.save_for_backward(x, None, gamma, beta, None, None)
+        ctx.cfg = (bool(relu), bool(training), res is not None)
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        relu, training, has_res = ctx.cfg
+        if not training:
+            raise P3DError('fp16 BatchNorm backward with frozen statistics is not implemented (-half_acc with -do_freeze)')
+        dy = _cl(dy)
+        n, c, h, w = x.shape
+        L, st = lib(), _stream()
+        dx = _empty(n, c, h, w, x.device)
+        dres = None
+        if has_res and ctx.needs_input_grad[5]:
+            dres = _empty(n, c, h, w, x.device) if relu else dy
+        g_param, b_param = ctx.params
+        g_sink, b_sink = _grad_sink(g_param), _grad_sink(b_param)
+        direct = g_sink is not None and b_sink is not None
+        dgamma = g_sink if direct else torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = b_sink if direct else torch.empty_like(dgamma)
+        ws = workspace(x.device, L.p3d_hbn_workspace_bytes(c))
+        check(L.p3d_hbn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dres) if (dres is not None and relu) else None,
+                                  _p(dgamma), _p(dbeta), n * h * w, c, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_hbn_train_bwd')
+        if direct:
+            dgamma = dbeta = None
+            _grad_done(g_param)
+            _grad_done(b_param)
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
+    return HBatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps)
+
+
+class HMaxPoolFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_half(x)
+        x = _cl(x)
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = _empty(n, c, ho, wo, x.device)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+        check(lib().p3d_hmaxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()), 'p3d_hmaxpool3x3s2_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy = _cl(dy)
+        dx = _empty(n, c, h, w, dy.device)
+        check(lib().p3d_hmaxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _stream()), 'p3d_hmaxpool3x3s2_bwd')
+        return dx
+
+
+def maxpool3x3s2(x):
+    return HMaxPoolFn.apply(x)

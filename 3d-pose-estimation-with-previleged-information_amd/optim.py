@@ -11,6 +11,8 @@ The reference's two param groups carry identical hyper-parameters (wrap_by_name,
 weight decay on BN and bias included), so one flat group reproduces it; `param_groups` keeps two dicts
 because adapt_learn_rate writes both (depth_train.py:637-638).
 """
+import math
+
 import torch
 
 from . import ops
@@ -65,15 +67,20 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p)
 
-    def clip_and_step(self, max_norm, grad_scale=1.0):
-        """clip_grad_norm_(params, max_norm) followed by Adam.step(); grad_scale (1/world_size) is applied first."""
+    def clip_and_step(self, max_norm, grad_scale=1.0, skip_nonfinite=False):
+        """clip_grad_norm_(params, max_norm) followed by Adam.step(); grad_scale (1/world_size) is applied first.
+        skip_nonfinite (the -half_acc overflow rule, depth_train.py:431-446): read the norm back and return False WITHOUT stepping
+        when any gradient is inf / nan; otherwise returns True."""
         self.norm_sq.zero_()
-        if max_norm and max_norm > 0:
+        if (max_norm and max_norm > 0) or skip_nonfinite:
             ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
+        if skip_nonfinite and not math.isfinite(float(self.norm_sq.item())):
+            return False
         self.step_count += 1
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, max_norm or 0.0,
                       self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
+        return True
 
     def step(self):
         self.clip_and_step(0.0)

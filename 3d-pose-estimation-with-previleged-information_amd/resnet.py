@@ -30,11 +30,11 @@ class ResNet(TrunkBase):
         self.mat_regressor = Conv2d(512 * block.expansion, args.num_joints, kernel_size=3, padding=1) if args.joint_space else None
 
     def forward(self, x):
-        x = stem(self.conv1, self.bn1, self.maxpool, x)
+        x = stem(self.conv1, self.bn1, self.maxpool, self._half_in(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         if self.mat_regressor is not None:
-            return self.cam_regressor(x), self.mat_regressor(x)
-        return self.cam_regressor(x)
+            return self._half_out(self.cam_regressor(x), self.mat_regressor(x))
+        return self._half_out(self.cam_regressor(x))
 
 
 def _build(block, layers, args):

@@ -196,6 +196,8 @@ size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 /* dw (fp32 master gradient [K][c_real][R][S]) = (d->accumulate ? dw : 0) + scale * wgrad; c_real <= d->C (stem: 3 of 8) */
 int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* x_nhwc, float* dw, int32_t c_real, float scale,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* db[K] (fp32) = (accumulate ? db : 0) + scale * sum over the P pixels of dy[P][K] */
+int32_t p3d_hconv2d_bgrad(const void* dy_nhwc, int32_t P, int32_t K, float* db, float scale, int32_t accumulate, void* stream);
 /* layout / precision converters: dst = scale * src; Cpad >= C, multiple of 8, the padding channels are written as 0 */
 int32_t p3d_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t N, int32_t C, int32_t HW, int32_t Cpad, float scale, void* stream);
 int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, float scale, void* stream);

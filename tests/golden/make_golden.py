@@ -142,6 +142,8 @@ STEP_CASES = {
     'fusion_r50_b1': ('fusionnet', 'resnet50', 256, 1, 1, 0.0, ['-do_fusion']),
     'partial_r18_b2': ('partial_depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only', '-partial_conv']),
     'partial_r50_b1': ('partial_depthnet', 'resnet50', 256, 1, 1, 0.0, ['-depth_only', '-partial_conv']),
+    # -half_acc: model.half() + fp32 copy_params + static loss scale (depth_train.py:73-83,413-449), on the CPU half kernels of torch
+    'half_r18_b2': ('depthnet', 'resnet18', 256, 2, 2, 0.0, ['-half_acc']),
 }
 
 
@@ -188,6 +190,11 @@ def gen_step(case):
         return total
     depth_train.nn.utils.clip_grad_norm_ = clip
 
+    if '-half_acc' in extra:
+        # depth_train.py:428 relies on optimizer.zero_grad() keeping the preallocated fp32 .grad tensors (the behaviour of the torch
+        # the reference was written for); torch >= 2.0 defaults to set_to_none=True, which makes :440 fail.  Restore the old default.
+        import functools
+        tr.optimizer.zero_grad = functools.partial(tr.optimizer.zero_grad, set_to_none=False)
     tr.model.train()
     tr.adapt_learn_rate(1)
     lr = tr.optimizer.param_groups[0]['lr']

@@ -196,3 +196,77 @@ def test_hmaxpool(shape, pkg):
     pkg._lib.check(L.p3d_hmaxpool3x3s2_bwd(p(nhwc16(dy)), p(it), p(dxt), n, h, w, c, st), 'pool bwd')
     want = ref.maxpool3x3s2_bwd(dy, idx_ref, x.shape)
     assert np.abs(nchw32(dxt) - want).max() < 2e-3 * max(1.0, np.abs(want).max())
+
+
+def test_half_train_step_matches_reference_half(pkg):
+    """Two -half_acc iterations against what the reference's own fp16 path (model.half() on torch's CPU half kernels, fp32
+    copy_params, loss scale 32; depth_train.py:73-83,413-449) produced for the same weights and batches.  The two fp16
+    implementations round at different places, so the bars are the fp16 noise measured between the reference's own fp32 and
+    fp16 runs (loss 3e-5, joints 4e-4, clip norm 6e-4, per-tensor gradient norms: median 2e-3, worst 5e-2)."""
+    import json
+    from conftest import golden_path
+    from test_step_gpu import build
+    g = np.load(golden_path('step_half_r18_b2.npz'))
+    meta = json.loads(str(g['meta']))
+    assert '-half_acc' in meta['extra']
+    args, model, trainer = build(pkg, meta)
+    assert trainer.half_acc and model._p3d_half and all(p.dtype == torch.float32 for p in model.parameters())
+    model.train()
+    trainer.adapt_learn_rate(1)
+    for it in range(meta['iters']):
+        c, d, tc, tv = pkg.synth.make_batch(meta['batch'], side=meta['side'], rank=0, step=it, invalid_frac=meta['invalid_frac'])
+        loss = float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+        assert abs(loss - g['losses'][it]) < 1e-3 * abs(g['losses'][it]), (it, loss, g['losses'][it])
+        spec_sel = trainer.last_spec_cam.cpu().numpy().reshape(-1, 3)[tv.reshape(-1)]
+        ref_sel = g['spec_sel_%d' % it]
+        assert np.abs(spec_sel - ref_sel).max() < 1e-3 * np.abs(ref_sel).max()
+        total = trainer.optimizer.total_norm(1.0 / args.grad_scaling)
+        assert abs(total - g['clip_total'][it]) < 5e-3 * g['clip_total'][it], (total, g['clip_total'][it])
+    assert trainer.skipped_steps == 0
+    names = meta['names']
+    grads = {n: p.grad.detach().cpu().numpy() / args.grad_scaling for n, p in zip(trainer.list_names, trainer.list_params)}
+    gn = np.array([np.linalg.norm(grads[n].astype(np.float64)) for n in names])
+    rel = np.abs(gn - g['grad_norms']) / np.maximum(g['grad_norms'], 1e-4 * g['grad_norms'].max())
+    assert np.median(rel) < 1e-2 and rel.max() < 0.1, (np.median(rel), rel.max())
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    pn = np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names])
+    assert np.abs(pn - g['param_norms']).max() < 1e-3 * g['param_norms'].max()           # the reference's state_dict is fp16
+    # the fp16 weight images follow the masters after the step
+    img = model.layer1[0].conv1._h_images
+    want = model.layer1[0].conv1.weight.detach().half().permute(0, 2, 3, 1)
+    assert torch.equal(img.krsc, want.contiguous())
+
+
+def test_half_overflow_skips_the_step(pkg):
+    import json
+    from conftest import golden_path
+    from test_step_gpu import build
+    meta = json.loads(str(np.load(golden_path('step_half_r18_b2.npz'))['meta']))
+    meta = dict(meta, side=128)
+    args, model, trainer = build(pkg, meta)
+    trainer.grad_scaling = 1e30                      # every fp16 gradient overflows
+    model.train()
+    trainer.adapt_learn_rate(1)
+    before = model.conv1.weight.detach().clone()
+    c, d, tc, tv = pkg.synth.make_batch(2, side=128, rank=0, step=0)
+    trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda())
+    assert trainer.skipped_steps == 1 and trainer.optimizer.step_count == 0
+    assert torch.equal(before, model.conv1.weight.detach())
+
+
+def test_half_eval_forward(pkg):
+    """Trainer.test under -half_acc: frozen-BN fp16 forward; the record stays close to the fp32 one."""
+    import json
+    from conftest import golden_path
+    from test_step_gpu import build
+    meta = json.loads(str(np.load(golden_path('step_half_r18_b2.npz'))['meta']))
+    args, model, trainer = build(pkg, meta)
+    args32, model32, trainer32 = build(pkg, dict(meta, extra=[]))
+    c, d, tc, tv = pkg.synth.make_batch(2, side=256, rank=1, step=0)
+    x = torch.from_numpy(c).cuda()
+    model.eval(); model32.eval()
+    with torch.no_grad():
+        z16, _ = model(x)
+        z32, _ = model32(x)
+    assert z16.dtype == torch.float32 and z16.shape == z32.shape
+    assert (z16 - z32).abs().max() < 2e-2 * z32.abs().max()
