@@ -20,7 +20,7 @@ static HbnGeom hbn_geom(int P, int C) {
     g.G = C / 8;
     g.Gb = g.G < 256 ? g.G : 256;
     g.PL = 256 / g.Gb;
-    int64_t nb = ceil_div(ceil_div(P, g.PL), 4);                // ~4 pixels per thread at least
+    int64_t nb = ceil_div(ceil_div(P, g.PL), 8);                // >= 8 pixels per thread
     if (nb > HBN_MAX_BLOCKS) nb = HBN_MAX_BLOCKS;
     if (nb < 1) nb = 1;
     g.nblk = (int)nb;
@@ -59,27 +59,38 @@ __global__ __launch_bounds__(256) void hbn_stats_kernel(const _Float16* __restri
     hbn_block_reduce(acc, sm, partial, G, Gb, PL, blockIdx.y * Gb);
 }
 
-// coef[c] = {sc, sh, mean, invstd}; also save_mean / save_invstd and the running statistics
+// fp64 sum over the per-block partials of one channel, spread over 16 threads: block = 16 channels x 16 slices of the block list
+__device__ __forceinline__ void hbn_sum_partials(const float* __restrict__ partial, int nblk, int G, int C, double& s1, double& s2, int& c) {
+    __shared__ double red[16][16][2];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int blk = sl; blk < nblk; blk += 16) {
+            const float* q = partial + ((size_t)blk * G + (c >> 3)) * 16 + (c & 7);
+            a += q[0]; b += q[8];
+        }
+    red[sl][cl][0] = a; red[sl][cl][1] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    if (sl == 0)
+        for (int i = 0; i < 16; ++i) { s1 += red[i][cl][0]; s2 += red[i][cl][1]; }
+}
+
+// coef[c] = {sc, sh, mean, invstd} (kept for backward) and the running statistics.  grid C/16
 __global__ __launch_bounds__(256) void hbn_fwd_finalize_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean, float* running_var,
-                                                               float* save_mean, float* save_invstd, float4* __restrict__ coef, int P, int C,
-                                                               float momentum, float eps) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int G = C >> 3;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* q = partial + ((size_t)b * G + (c >> 3)) * 16 + (c & 7);
-        s1 += q[0]; s2 += q[8];
-    }
+                                                               float4* __restrict__ coef, int P, int C, float momentum, float eps) {
+    double s1, s2;
+    int c;
+    hbn_sum_partials(partial, nblk, C >> 3, C, s1, s2, c);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
     const double cnt = (double)P;
     const double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
-    save_mean[c] = fmean;
-    save_invstd[c] = invstd;
     if (running_mean) {
         const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
@@ -124,22 +135,17 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(const _Float16* __restri
     }
 }
 
-// backward pass 1: partial[blk][g][0..7] = sum g, [8..15] = sum g * xhat, g = dy masked by the ReLU
+// backward pass 1: partial[blk][g][0..7] = sum g, [8..15] = sum g * xhat, g = dy masked by the ReLU (mask from y, or, with
+// y == nullptr (no residual), recomputed as fmaf(x, sc, sh) > 0 with the forward's own constants)
 __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, float* __restrict__ partial, int P, int C, int relu) {
+                                                             const float4* __restrict__ coef, float* __restrict__ partial, int P, int C, int relu) {
     __shared__ float sm[256 * 16];
     const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
     const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
     const bool recompute = relu && y == nullptr;
     float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = g * 8 + e;
-        mu[e] = mean[c]; is[e] = invstd[c];
-        sc[e] = is[e] * gamma[c];
-        sh[e] = recompute ? hbn_shift(beta[c], mu[e], sc[e]) : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) { const float4 q = coef[g * 8 + e]; sc[e] = q.x; sh[e] = q.y; mu[e] = q.z; is[e] = q.w; }
     float acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -162,40 +168,30 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
     hbn_block_reduce(acc, sm, partial, G, Gb, PL, blockIdx.y * Gb);
 }
 
-// dgamma / dbeta and the per-channel constants of pass 2: coef[c] = {gamma*invstd, k1 = sum g / P, k2 = sum g xhat / P, 0}
-__global__ __launch_bounds__(256) void hbn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ gamma,
-                                                               const float* __restrict__ invstd, float* dgamma, float* dbeta, float4* __restrict__ coef,
-                                                               int P, int C, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int G = C >> 3;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* q = partial + ((size_t)b * G + (c >> 3)) * 16 + (c & 7);
-        s1 += q[0]; s2 += q[8];
-    }
+// dgamma / dbeta and the constants of pass 2: coef2[c] = {k1 = sum g / P, k2 = sum g xhat / P, 0, 0}.  grid C/16
+__global__ __launch_bounds__(256) void hbn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* dgamma, float* dbeta,
+                                                               float4* __restrict__ coef2, int P, int C, int accumulate) {
+    double s1, s2;
+    int c;
+    hbn_sum_partials(partial, nblk, C >> 3, C, s1, s2, c);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-    coef[c] = make_float4(gamma[c] * invstd[c], (float)(s1 / P), (float)(s2 / P), 0.f);
+    coef2[c] = make_float4((float)(s1 / P), (float)(s2 / P), 0.f, 0.f);
 }
 
-// backward pass 2: dx = gamma*invstd*(g - k1 - xhat*k2), dres = g
+// backward pass 2: dx = gamma*invstd*(g - k1 - xhat*k2) (gamma*invstd is the forward's sc), dres = g
 __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const float4* __restrict__ coef, _Float16* __restrict__ dx,
+                                                            const float4* __restrict__ coef, const float4* __restrict__ coef2, _Float16* __restrict__ dx,
                                                             _Float16* __restrict__ dres, int P, int C, int relu) {
     const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
     const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
     const bool recompute = relu && y == nullptr;
-    float mu[8], is[8], sc[8], sh[8], gs[8], k1[8], k2[8];
+    float mu[8], is[8], sc[8], sh[8], k1[8], k2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = g * 8 + e;
-        mu[e] = mean[c]; is[e] = invstd[c];
-        sc[e] = is[e] * gamma[c];
-        sh[e] = recompute ? hbn_shift(beta[c], mu[e], sc[e]) : 0.f;
-        const float4 q = coef[c];
-        gs[e] = q.x; k1[e] = q.y; k2[e] = q.z;
+        const float4 q = coef[g * 8 + e], r = coef2[g * 8 + e];
+        sc[e] = q.x; sh[e] = q.y; mu[e] = q.z; is[e] = q.w; k1[e] = r.x; k2[e] = r.y;
     }
     for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
         const size_t off = (size_t)p * C + g * 8;
@@ -211,7 +207,7 @@ __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __re
             if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
             else if (relu && !((float)yv[e] > 0.f)) gq = 0.f;
             gr[e] = (_Float16)gq;
-            o[e] = (_Float16)(gs[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
+            o[e] = (_Float16)(sc[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
         }
         *reinterpret_cast<h8*>(dx + off) = o;
         if (dres) *reinterpret_cast<h8*>(dres + off) = gr;
@@ -299,24 +295,28 @@ extern "C" {
 
 size_t p3d_hbn_workspace_bytes(int32_t C) { return (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float) + (size_t)C * sizeof(float4); }
 
+static dim3 hbn_stream_grid(int P, const HbnGeom& g) {
+    int64_t nb = ceil_div(ceil_div(P, g.PL), 8);               // >= 8 pixels per thread: the per-channel constants are loaded once per block
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return dim3((unsigned)nb, (unsigned)(g.G / g.Gb));
+}
+
 int32_t p3d_hbn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                          void* y, float* save_mean, float* save_invstd, int32_t P, int32_t C, float momentum, float eps, int32_t relu,
+                          void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu,
                           void* workspace, size_t workspace_bytes, void* stream) {
-    P3D_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "hbn_train_fwd: null tensor");
+    P3D_REQUIRE(x && gamma && beta && y && coef, "hbn_train_fwd: null tensor");
     P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_fwd: bad shape P=%d C=%d (C/8 must divide or be a multiple of 256)", P, C);
     P3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hbn_train_fwd: running stats must come as a pair");
     if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_train_fwd: workspace too small"); return P3D_EWORKSPACE; }
     const HbnGeom g = hbn_geom(P, C);
     float* partial = (float*)workspace;
-    float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(g.nblk, g.G / g.Gb);
-    hipLaunchKernelGGL(hbn_stats_kernel, grid, dim3(256), 0, st, (const _Float16*)x, partial, P, C);
-    hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, coef, P, C, momentum, eps);
-    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
-    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
-    hipLaunchKernelGGL(hbn_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef, (_Float16*)y, P, C, relu);
+    hipLaunchKernelGGL(hbn_stats_kernel, dim3(g.nblk, g.G / g.Gb), dim3(256), 0, st, (const _Float16*)x, partial, P, C);
+    hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, beta,
+                       running_mean, running_var, (float4*)coef, P, C, momentum, eps);
+    hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
+                       (_Float16*)y, P, C, relu);
     return check_launch("hbn_train_fwd");
 }
 
@@ -330,32 +330,27 @@ int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, con
     float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hbn_eval_coef_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, coef, C, eps);
-    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
-    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
-    hipLaunchKernelGGL(hbn_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef, (_Float16*)y, P, C, relu);
+    hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
+                       (_Float16*)y, P, C, relu);
     return check_launch("hbn_eval_fwd");
 }
 
-int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
-                          const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta, int32_t P, int32_t C, int32_t relu,
-                          int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    P3D_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "hbn_train_bwd: null tensor");
-    P3D_REQUIRE(!relu || y || (beta && !dres), "hbn_train_bwd: relu backward needs the forward output (or beta and no residual)");
+int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                          int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(dy && x && coef && dx && dgamma && dbeta, "hbn_train_bwd: null tensor");
+    P3D_REQUIRE(!relu || y || !dres, "hbn_train_bwd: relu backward of a layer with a residual needs the forward output");
     P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_bwd: bad shape P=%d C=%d", P, C);
     if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_train_bwd: workspace too small"); return P3D_EWORKSPACE; }
     const HbnGeom g = hbn_geom(P, C);
     float* partial = (float*)workspace;
-    float4* coef = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
+    float4* coef2 = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(g.nblk, g.G / g.Gb);
-    hipLaunchKernelGGL(hbn_bwd_reduce_kernel, grid, dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y, gamma, beta, save_mean,
-                       save_invstd, partial, P, C, relu);
-    hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, save_invstd,
-                       dgamma, dbeta, coef, P, C, accumulate);
-    const int64_t nb = ceil_div(ceil_div(P, g.PL), 2);
-    dim3 grid2((unsigned)(nb < 4096 ? nb : 4096), g.G / g.Gb);
-    hipLaunchKernelGGL(hbn_bwd_apply_kernel, grid2, dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y, gamma, beta, save_mean,
-                       save_invstd, (const float4*)coef, (_Float16*)dx, (_Float16*)dres, P, C, relu);
+    hipLaunchKernelGGL(hbn_bwd_reduce_kernel, dim3(g.nblk, g.G / g.Gb), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
+                       (const float4*)coef, partial, P, C, relu);
+    hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, g.nblk, dgamma, dbeta, coef2,
+                       P, C, accumulate);
+    hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
+                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)dres, P, C, relu);
     return check_launch("hbn_train_bwd");
 }
 

@@ -336,19 +336,31 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
 }
 
 // dw[k][c][r][s] (fp32 master layout, c < Creal) (+)= scale * sum_split slab[split][k][(r*S+s)*C + c]
+// block = 32 consecutive slab elements x 8 slices of the split list (small layers are split hundreds of times: a serial sum
+// per element would leave a few thousand threads chasing dependent loads)
 __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int K, int C, int Creal, int RS,
                                                             int nsplit, float scale, int accumulate) {
+    __shared__ float red[8][32];
     const size_t per = (size_t)K * RS * C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < per; base += (size_t)gridDim.x * 32) {
+        const size_t i = base + el;
         float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * per + i];
-        const int c = (int)(i % C);
-        const int tap = (int)((i / C) % RS);
-        const int k = (int)(i / ((size_t)C * RS));
-        if (c < Creal) {
-            float* o = dw + ((size_t)k * Creal + c) * RS + tap;
-            *o = accumulate ? *o + s * scale : s * scale;
+        if (i < per)
+            for (int sp = sl; sp < nsplit; sp += 8) s += slab[sp * per + i];
+        red[sl][el] = s;
+        __syncthreads();
+        if (sl == 0 && i < per) {
+            s = red[0][el] + red[1][el] + red[2][el] + red[3][el] + red[4][el] + red[5][el] + red[6][el] + red[7][el];
+            const int c = (int)(i % C);
+            const int tap = (int)((i / C) % RS);
+            const int k = (int)(i / ((size_t)C * RS));
+            if (c < Creal) {
+                float* o = dw + ((size_t)k * Creal + c) * RS + tap;
+                *o = accumulate ? *o + s * scale : s * scale;
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -529,7 +541,7 @@ int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x,
     hipLaunchKernelGGL(hconv_wgrad_kernel, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, p);
     if (int32_t e = check_launch("hconv2d_wgrad")) return e;
     const size_t per = (size_t)d->K * d->R * d->S * d->C;
-    const unsigned blocks = (unsigned)(ceil_div((int64_t)per, 256) < 2048 ? ceil_div((int64_t)per, 256) : 2048);
+    const unsigned blocks = (unsigned)(ceil_div((int64_t)per, 32) < 8192 ? ceil_div((int64_t)per, 32) : 8192);
     hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, d->K, d->C, c_real,
                        d->R * d->S, splits, scale, d->accumulate);
     return check_launch("hconv2d_wgrad reduce");

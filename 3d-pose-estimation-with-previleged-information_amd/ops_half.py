@@ -190,22 +190,21 @@ class HBatchNormActFn(torch.autograd.Function):
         y = _empty(n, c, h, w, x.device)
         ws = workspace(x.device, L.p3d_hbn_workspace_bytes(c))
         if training:
-            mean = torch.empty(c, dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            check(L.p3d_hbn_train_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd),
+            coef = torch.empty((c, 4), dtype=torch.float32, device=x.device)
+            check(L.p3d_hbn_train_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(coef),
                                       n * h * w, c, momentum, eps, int(relu), _p(ws), ws.numel(), st), 'p3d_hbn_train_fwd')
-            ctx.save_for_backward(x, y if (relu and res is not None) else None, gamma, beta, mean, invstd)
+            ctx.save_for_backward(x, y if (relu and res is not None) else None, coef)
         else:
             check(L.p3d_hbn_eval_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), n * h * w, c, eps, int(relu),
                                      _p(ws), ws.numel(), st), 'p3d_hbn_eval_fwd')
-            ctx.save_for_backward(x, None, gamma, beta, None, None)
+            ctx.save_for_backward(x, None, None)
         ctx.cfg = (bool(relu), bool(training), res is not None)
         ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, y, coef = ctx.saved_tensors
         relu, training, has_res = ctx.cfg
         if not training:
             raise P3DError('fp16 BatchNorm backward with frozen statistics is not implemented (-half_acc with -do_freeze)')
@@ -222,7 +221,7 @@ class HBatchNormActFn(torch.autograd.Function):
         dgamma = g_sink if direct else torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = b_sink if direct else torch.empty_like(dgamma)
         ws = workspace(x.device, L.p3d_hbn_workspace_bytes(c))
-        check(L.p3d_hbn_train_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dres) if (dres is not None and relu) else None,
+        check(L.p3d_hbn_train_bwd(_p(dy), _p(x), _p(y), _p(coef), _p(dx), _p(dres) if (dres is not None and relu) else None,
                                   _p(dgamma), _p(dbeta), n * h * w, c, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_hbn_train_bwd')
         if direct:
             dgamma = dbeta = None

@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--model', default='resnet50')
     ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet'],
                     help='informational runs of BASELINE configs 4/5; the contract line is depthnet (config 2)')
+    ap.add_argument('--half', action='store_true', help='informational: the -half_acc (fp16 NHWC) path; the contract line is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     opt = ap.parse_args()
@@ -70,7 +71,7 @@ def main():
     device = torch.device('cuda', local_rank)
 
     extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv']}[opt.family]
-    args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra)
+    args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra + (['-half_acc'] if opt.half else []))
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model, _ = pkg.depth_main.create_model(args)
     model = model.to(device).train()
@@ -152,7 +153,7 @@ def main():
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam' % (opt.family, opt.model, opt.batch),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
@@ -168,7 +169,13 @@ def main():
                          'achieved_in_timed_region': round(achieved_ov, 2),
                          'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
-        if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet':
+        if opt.half:
+            out['roofline']['peak'] = 2500.0          # dense f16 MFMA peak (MI355X_MICROARCH.md)
+            out['roofline']['frac'] = round(achieved / 2500.0, 4)
+            out['roofline']['whole_step_frac'] = round(step_tflops / 2500.0, 4)
+            out['roofline']['kernel'] = 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)'
+            out['roofline']['traffic'] = None
+        if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -204,18 +204,19 @@ int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t
 int32_t p3d_weight_images_f16(const float* w, void* krsc, void* crsk /* may be NULL */, int32_t K, int32_t C, int32_t RS, int32_t Cpad,
                               void* stream);
 
-/* BatchNorm2d (+ residual + ReLU) on NHWC fp16: x, res, y, dy, dx, dres are [P = N*H*W][C] fp16; gamma, beta, running statistics,
- * saved statistics and dgamma / dbeta stay fp32 (they are the master parameters).  C/8 must divide 256 or be a multiple of it.
- * Semantics as p3d_bn_train_fwd / p3d_bn_train_bwd (y may be NULL in backward when relu != 0 and there was no residual). */
+/* BatchNorm2d (+ residual + ReLU) on NHWC fp16: x, res, y, dy, dx, dres are [P = N*H*W][C] fp16; gamma, beta, running statistics
+ * and dgamma / dbeta stay fp32 (they are the master parameters).  C/8 must divide 256 or be a multiple of it.
+ * Training forward writes coef [C][4] fp32 = {gamma*invstd, beta - mean*gamma*invstd, mean, invstd}: the caller keeps it for backward
+ * (it replaces save_mean / save_invstd of the fp32 entry points).  Backward: y may be NULL when relu != 0 and the layer had no
+ * residual (the mask is recomputed from x and coef). */
 size_t p3d_hbn_workspace_bytes(int32_t C);
 int32_t p3d_hbn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
-                          float* running_var, void* y, float* save_mean, float* save_invstd, int32_t P, int32_t C,
+                          float* running_var, void* y, float* coef, int32_t P, int32_t C,
                           float momentum, float eps, int32_t relu, void* workspace, size_t workspace_bytes, void* stream);
 int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, void* y, int32_t P, int32_t C, float eps, int32_t relu,
                          void* workspace, size_t workspace_bytes, void* stream);
-int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
-                          const float* save_mean, const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta,
+int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on NHWC fp16; idx [N][Ho][Wo][C] uint8 window codes as in p3d_maxpool3x3s2_fwd */
 int32_t p3d_hmaxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

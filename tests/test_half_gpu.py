@@ -132,12 +132,13 @@ def test_hbn_train_fwd_bwd(n, c, h, w, relu, with_res, pkg):
     rt = nhwc16(res) if with_res else None
     gt, bt, rmt, rvt = (torch.from_numpy(a.copy()).cuda() for a in (gamma, beta, rm, rv))
     yt = torch.empty_like(xt)
-    sm, si = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    coef = torch.empty(c, 4, device='cuda')
     ws = torch.empty(L.p3d_hbn_workspace_bytes(c), dtype=torch.uint8, device='cuda')
-    pkg._lib.check(L.p3d_hbn_train_fwd(p(xt), p(rt), p(gt), p(bt), p(rmt), p(rvt), p(yt), p(sm), p(si), P, c, 0.1, 1e-5, int(relu),
+    pkg._lib.check(L.p3d_hbn_train_fwd(p(xt), p(rt), p(gt), p(bt), p(rmt), p(rvt), p(yt), p(coef), P, c, 0.1, 1e-5, int(relu),
                                        p(ws), ws.numel(), st), 'hbn fwd')
     assert np.abs(nchw32(yt) - out_ref).max() < 2e-3 * max(1.0, np.abs(out_ref).max())
-    assert relerr(sm.cpu().numpy(), mean) < 1e-5 and relerr(si.cpu().numpy(), invstd) < 1e-5
+    cf = coef.cpu().numpy()
+    assert relerr(cf[:, 2], mean) < 1e-5 and relerr(cf[:, 3], invstd) < 1e-5 and relerr(cf[:, 0], invstd * gamma) < 1e-5
     assert relerr(rmt.cpu().numpy(), nrm) < 1e-5 and relerr(rvt.cpu().numpy(), nrv) < 1e-5
     # backward: the mask comes from the kernel's own fp16 output (or is recomputed from x when there is no residual)
     dy = r16(rng.standard_normal(x.shape))
@@ -149,7 +150,7 @@ def test_hbn_train_fwd_bwd(n, c, h, w, relu, with_res, pkg):
     drt = torch.empty_like(xt) if with_res else None
     dg, db = torch.ones(c, device='cuda'), torch.ones(c, device='cuda')
     y_arg = yt if (relu and with_res) else None
-    pkg._lib.check(L.p3d_hbn_train_bwd(p(dyt), p(xt), p(y_arg), p(gt), p(bt), p(sm), p(si), p(dxt), p(drt), p(dg), p(db), P, c, int(relu), 1,
+    pkg._lib.check(L.p3d_hbn_train_bwd(p(dyt), p(xt), p(y_arg), p(coef), p(dxt), p(drt), p(dg), p(db), P, c, int(relu), 1,
                                        p(ws), ws.numel(), st), 'hbn bwd')
     assert np.abs(nchw32(dxt) - dx_ref).max() < 3e-3 * max(1.0, np.abs(dx_ref).max())
     assert relerr(dg.cpu().numpy() - 1, dg_ref) < 2e-3 and relerr(db.cpu().numpy() - 1, db_ref) < 2e-3
