@@ -65,6 +65,7 @@ SIGNATURES = {
     'p3d_nchw_f32_to_nhwc_f16': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_nhwc_f16_to_nchw_f32': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_weight_images_f16': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_weight_images_f16_batched': (_i32, [_ptr, _ptr, _ptr, _i32, _ptr]),
     'p3d_hbn_workspace_bytes': (_sz, [_i32]),
     'p3d_hbn_train_fwd': (_i32, [_ptr] * 8 + [_i32, _i32, _f32, _f32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_eval_fwd': (_i32, [_ptr] * 7 + [_i32, _i32, _f32, _i32, _ptr, _sz, _ptr]),

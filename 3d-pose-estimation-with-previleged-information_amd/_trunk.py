@@ -63,7 +63,7 @@ class _ResidualBlock(nn.Module):
         if self.partial:                      # partial_depthnet.py:44-46: blocks receive an (x, veil) tuple
             return self.forward_partial(*x)
         # the block input fans out to conv1 and the shortcut: join the two input gradients inside conv1's dgrad kernel (ops.GradJoin)
-        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32) else None
+        join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1
         for i, (cname, bname) in enumerate(self._chain):

@@ -52,6 +52,7 @@ struct HGatherParams {
     int bmul;                 // B base coordinate: bmul * i + hadd[ph]  (+ hstep[ph] * ir for tap ir)
     int ncw;                  // classes along w (forward: 1)
     int tiles_m;
+    int accumulate;           // D += result (a dgrad joining the gradient of a second consumer of its input)
     int Hc[HMS], Wc[HMS];
     int r0[HMS], rstep[HMS], nr[HMS], hadd[HMS], hstep[HMS];
     int s0[HMS], sstep[HMS], ns[HMS], wadd[HMS], wstep[HMS];
@@ -195,6 +196,11 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
                     float v = acc[a][b][4 * g + e];
                     if (p.bias) v += p.bias[ch + e];
                     o[e] = (_Float16)v;
+                }
+                if (p.accumulate) {
+                    const h4 old = *reinterpret_cast<const h4*>(dst + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)((float)old[e] + acc[a][b][4 * g + e]);
                 }
                 *reinterpret_cast<h4*>(dst + ch) = o;
             }
@@ -408,6 +414,26 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
     }
 }
 
+// all convolutions of a network in ONE launch: table[i] = {offset of the fp32 master in `flat`, offset of the krsc image and of the
+// crsk image in `images` (halves; -1: none), K, C, RS, Cpad}; blockIdx.y = table row
+struct WeightImageJob { long long w_off, krsc_off, crsk_off; int K, C, RS, Cpad; };
+__global__ __launch_bounds__(256) void weight_images_batched_kernel(const float* __restrict__ flat, _Float16* __restrict__ images,
+                                                                    const WeightImageJob* __restrict__ table) {
+    const WeightImageJob jb = table[blockIdx.y];
+    const float* w = flat + jb.w_off;
+    _Float16* krsc = images + jb.krsc_off;
+    _Float16* crsk = jb.crsk_off >= 0 ? images + jb.crsk_off : nullptr;
+    const size_t total = (size_t)jb.K * jb.RS * jb.Cpad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % jb.Cpad);
+        const int tap = (int)((i / jb.Cpad) % jb.RS);
+        const int k = (int)(i / ((size_t)jb.Cpad * jb.RS));
+        const _Float16 v = c < jb.C ? (_Float16)w[((size_t)k * jb.C + c) * jb.RS + tap] : (_Float16)0.f;
+        krsc[i] = v;
+        if (crsk) crsk[((size_t)c * jb.RS + tap) * jb.K + k] = v;
+    }
+}
+
 static void fill_class_h(int par, int R, int stride, int pad, int dil, int* r0, int* step, int* n, int* off0, int* offstep) {
     *r0 = 0; *step = 1; *n = 0; *off0 = 0; *offstep = 0;
     int first = -1, second = -1;
@@ -478,6 +504,7 @@ int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_
     p.M = d->C; p.Kc = d->K; p.RSw = d->R * d->S; p.Sw = d->S;
     p.N = d->N; p.Hb = d->Ho; p.Wb = d->Wo; p.Hd = d->H; p.Wd = d->W;
     p.dmul = d->stride; p.bmul = 1; p.ncw = d->stride;
+    p.accumulate = d->accumulate;
     p.tiles_m = (int)ceil_div(d->C, 128);
     int max_cols = 0;
     for (int par = 0; par < d->stride; ++par) {
@@ -561,6 +588,15 @@ int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(nhwc_f16_to_nchw_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, N, C, HW, scale);
     return check_launch("nhwc_f16_to_nchw_f32");
+}
+
+/* table: njobs rows {int64 w_off, krsc_off, crsk_off (-1: none); int32 K, C, RS, Cpad} (40 B) in DEVICE memory, offsets in elements */
+int32_t p3d_weight_images_f16_batched(const float* flat, void* images, const void* table, int32_t njobs, void* stream) {
+    P3D_REQUIRE(flat && images && table && njobs > 0, "weight_images_f16_batched: bad argument");
+    static_assert(sizeof(WeightImageJob) == 40, "table row layout");
+    hipLaunchKernelGGL(weight_images_batched_kernel, dim3(64, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, flat, (_Float16*)images,
+                       (const WeightImageJob*)table);
+    return check_launch("weight_images_f16_batched");
 }
 
 int32_t p3d_weight_images_f16(const float* w, void* krsc, void* crsk, int32_t K, int32_t C, int32_t RS, int32_t Cpad, void* stream) {

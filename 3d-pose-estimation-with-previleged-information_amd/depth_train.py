@@ -103,7 +103,7 @@ class Trainer:
             # depth_train.py:73-83: the reference halves the model and keeps fp32 `copy_params` for Adam.  Here the parameters stay
             # fp32 (they are those copies, already flat inside FlatAdam) and every convolution gets fp16 weight images beside them.
             model._p3d_half = True
-            ops_half.refresh_weights(model)
+            ops_half.refresh_weights(model, self.optimizer.flat_p)
 
         self.depth = args.depth
         self.num_joints = args.num_joints
@@ -171,9 +171,10 @@ class Trainer:
             # static loss scaling (depth_train.py:413-449): gradients carry grad_scaling through the fp16 backward, the optimizer
             # divides it out, and a step whose gradients overflowed is skipped
             loss.backward(torch.full_like(loss, self.grad_scaling))
+            assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
             scale = self.reducer.finish()
             if self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True):
-                ops_half.refresh_weights(self.model)
+                ops_half.refresh_weights(self.model, self.optimizer.flat_p)
             else:
                 self.skipped_steps += 1
                 if self.verbose:

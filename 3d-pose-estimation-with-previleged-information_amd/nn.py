@@ -30,7 +30,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, join_put=None, join_take=None):
         if x.dtype == torch.float16:                        # -half_acc: NHWC fp16 kernels (ops_half.py)
-            return ops_half.conv2d(x, self, _one(self.stride), _one(self.padding), _one(self.dilation))
+            return ops_half.conv2d(x, self, _one(self.stride), _one(self.padding), _one(self.dilation), join_put, join_take)
         return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation),
                           join_put=join_put, join_take=join_take)
 
@@ -50,7 +50,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 self.num_batches_tracked.add_(1)
         if x.dtype == torch.float16:
-            return ops_half.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training, momentum, self.eps)
+            return ops_half.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training, momentum, self.eps,
+                                           res_join)
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, training,
                                   momentum, self.eps, res_join)
 

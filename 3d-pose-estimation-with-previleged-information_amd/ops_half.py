@@ -69,38 +69,85 @@ def to_float(x):
 
 
 class WeightImages:
-    """fp16 images of one convolution's fp32 master weight: krsc [K,R,S,Cpad] and crsk [Cpad,R,S,K]."""
+    """fp16 images of one convolution's fp32 master weight: krsc [K,R,S,Cpad] and crsk [Cpad,R,S,K] (views of the model's image
+    buffer when built by refresh_weights)."""
 
-    def __init__(self, weight, need_dgrad=True):
+    def __init__(self, weight, need_dgrad=True, krsc=None, crsk=None):
         k, c, r, s = weight.shape
         self.c_real, self.cpad = c, pad8(c)
-        self.krsc = torch.empty((k, r, s, self.cpad), dtype=torch.float16, device=weight.device)
-        self.crsk = torch.empty((self.cpad, r, s, k), dtype=torch.float16, device=weight.device) if need_dgrad else None
-        self.refresh(weight)
+        self.krsc = torch.empty((k, r, s, self.cpad), dtype=torch.float16, device=weight.device) if krsc is None else krsc
+        self.crsk = crsk if (crsk is not None or not need_dgrad) else torch.empty((self.cpad, r, s, k), dtype=torch.float16, device=weight.device)
 
     def refresh(self, weight):
         k, c, r, s = weight.shape
         check(lib().p3d_weight_images_f16(_p(weight.detach()), _p(self.krsc), _p(self.crsk), k, c, r * s, self.cpad, _stream()), 'p3d_weight_images_f16')
 
 
-def refresh_weights(model):
+class _ImagePlan:
+    """One fp16 buffer holding every weight image of a model and the device-side job table of the batched cast kernel."""
+
+    def __init__(self, model, flat):
+        import numpy as np
+        from .nn import Conv2d
+        convs = [m for m in model.modules() if isinstance(m, Conv2d)]
+        rows, total = [], 0
+        for m in convs:
+            k, c, r, s = m.weight.shape
+            cpad = pad8(c)
+            n = k * r * s * cpad
+            krsc_off = total
+            total += (n + 7) // 8 * 8
+            crsk_off = -1
+            if c >= 8:                                         # the stem (3 or 1 input channels) never needs an input gradient
+                crsk_off = total
+                total += (n + 7) // 8 * 8
+            w_off = (m.weight.data_ptr() - flat.data_ptr()) // 4
+            if not (0 <= w_off and w_off + m.weight.numel() <= flat.numel()):
+                raise P3DError('refresh_weights: a convolution weight does not live in the flat master buffer')
+            rows.append((w_off, krsc_off, crsk_off, k, c, r * s, cpad))
+        self.images = torch.empty(total, dtype=torch.float16, device=flat.device)
+        table = np.array(rows, dtype=[('w', '<i8'), ('a', '<i8'), ('b', '<i8'), ('K', '<i4'), ('C', '<i4'), ('RS', '<i4'), ('Cpad', '<i4')])
+        assert table.dtype.itemsize == 40
+        self.table = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).to(flat.device)
+        self.njobs = len(rows)
+        self.flat_ptr = flat.data_ptr()
+        for m, (w_off, ka, kb, k, c, rs, cpad) in zip(convs, rows):
+            r, s = m.weight.shape[2:]
+            n = k * rs * cpad
+            krsc = self.images[ka:ka + n].view(k, r, s, cpad)
+            crsk = self.images[kb:kb + n].view(cpad, r, s, k) if kb >= 0 else None
+            m._h_images = WeightImages(m.weight, need_dgrad=kb >= 0, krsc=krsc, crsk=crsk)
+
+    def run(self, flat):
+        check(lib().p3d_weight_images_f16_batched(_p(flat), _p(self.images), _p(self.table), self.njobs, _stream()), 'p3d_weight_images_f16_batched')
+
+
+def refresh_weights(model, flat=None):
     """(Re)build the fp16 weight images of every convolution of `model` from the fp32 masters: after construction, after
-    load_state_dict and after every optimizer step (the reference's `h_param.data.copy_(c_param.data)`, depth_train.py:448-449)."""
+    load_state_dict and after every optimizer step (the reference's `h_param.data.copy_(c_param.data)`, depth_train.py:448-449).
+    With `flat` (the FlatAdam parameter buffer the weights are views of) all images are cast by ONE kernel launch."""
     from .nn import Conv2d
+    if flat is not None:
+        ops._need_gpu(flat)
+        plan = getattr(model, '_h_plan', None)
+        if plan is None or plan.flat_ptr != flat.data_ptr():
+            plan = _ImagePlan(model, flat)
+            model._h_plan = plan
+        plan.run(flat)
+        return
     for m in model.modules():
         if isinstance(m, Conv2d):
             ops._need_gpu(m.weight)
             img = getattr(m, '_h_images', None)
             if img is None or img.krsc.device != m.weight.device:
-                m._h_images = WeightImages(m.weight, need_dgrad=m.weight.shape[1] >= 8)
-            else:
-                img.refresh(m.weight)
+                img = m._h_images = WeightImages(m.weight, need_dgrad=m.weight.shape[1] >= 8)
+            img.refresh(m.weight)
 
 
 class HConv2dFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, w, bias, images, stride, pad, dil):
+    def forward(ctx, x, w, bias, images, stride, pad, dil, join_put=None, join_take=None):
         _need_half(x)
         ops._need_gpu(w, bias)
         x = _cl(x)
@@ -116,6 +163,7 @@ class HConv2dFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, tuple(w.shape))
         ctx.params = (w, bias)
         ctx.images = images
+        ctx.joins = (join_put, join_take)
         return y
 
     @staticmethod
@@ -133,9 +181,18 @@ class HConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if images.crsk is None:
                 raise P3DError('hconv2d: this layer was built without a dgrad weight image')
-            dx = _empty(n, c, h, wd, x.device)
+            join_put, join_take = ctx.joins
+            joined = join_take.buf if join_take is not None else None
+            if joined is not None and joined.shape == x.shape and joined.dtype == torch.float16:
+                dx, join_take.buf = _cl(joined), None          # accumulate onto the shortcut's gradient (ops.GradJoin)
+                d.accumulate = 1
+            else:
+                dx = _empty(n, c, h, wd, x.device)
             with ops._Timed('dgrad', d):
                 check(L.p3d_hconv2d_dgrad(ctypes.byref(d), _p(dy), _p(images.crsk), _p(dx), st), 'p3d_hconv2d_dgrad')
+            d.accumulate = 0
+            if join_put is not None:
+                join_put.buf, dx = dx, None
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(w_param)
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device) if sink is None else sink
@@ -167,20 +224,20 @@ class HConv2dFn(torch.autograd.Function):
             if sink is not None:
                 db = None
                 _grad_done(b_param)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, module, stride, pad, dil):
+def conv2d(x, module, stride, pad, dil, join_put=None, join_take=None):
     images = getattr(module, '_h_images', None)
     if images is None:
         raise P3DError('fp16 convolution without weight images: call ops_half.refresh_weights(model) first')
-    return HConv2dFn.apply(x, module.weight, module.bias, images, stride, pad, dil)
+    return HConv2dFn.apply(x, module.weight, module.bias, images, stride, pad, dil, join_put, join_take)
 
 
 class HBatchNormActFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, res_join=None):
         _need_half(x, res)
         ops._need_gpu(gamma, beta, running_mean, running_var)
         x = _cl(x)
@@ -200,6 +257,7 @@ class HBatchNormActFn(torch.autograd.Function):
             ctx.save_for_backward(x, None, None)
         ctx.cfg = (bool(relu), bool(training), res is not None)
         ctx.params = (gamma, beta)
+        ctx.res_join = res_join
         return y
 
     @staticmethod
@@ -227,11 +285,13 @@ class HBatchNormActFn(torch.autograd.Function):
             dgamma = dbeta = None
             _grad_done(g_param)
             _grad_done(b_param)
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+        if ctx.res_join is not None and dres is not None and relu:     # (without ReLU dres aliases dy: never hand that out)
+            ctx.res_join.buf, dres = dres, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
-    return HBatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, res=None, relu=False, training=True, momentum=0.1, eps=1e-5, res_join=None):
+    return HBatchNormActFn.apply(x, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, res_join)
 
 
 class HMaxPoolFn(torch.autograd.Function):

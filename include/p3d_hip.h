@@ -191,6 +191,7 @@ int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour,
  * nn.Conv2d after model.half() (depthnet.py:16-33,65-89).
  * ------------------------------------------------------------------------------------------ */
 int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x_nhwc, const void* w_krsc, const float* bias, void* y_nhwc, void* stream);
+/* d->accumulate != 0: dx += result (joins the gradient another consumer of the same input already wrote) */
 int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, void* dx_nhwc, void* stream);
 size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 /* dw (fp32 master gradient [K][c_real][R][S]) = (d->accumulate ? dw : 0) + scale * wgrad; c_real <= d->C (stem: 3 of 8) */
@@ -203,6 +204,9 @@ int32_t p3d_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t N, int32_t
 int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, float scale, void* stream);
 int32_t p3d_weight_images_f16(const float* w, void* krsc, void* crsk /* may be NULL */, int32_t K, int32_t C, int32_t RS, int32_t Cpad,
                               void* stream);
+/* every convolution of a network in one launch: the masters live in one flat fp32 buffer (FlatAdam), the images in one fp16 buffer;
+ * table (device memory) has njobs rows {int64 w_off, krsc_off, crsk_off (-1: none); int32 K, C, RS, Cpad}, offsets in elements */
+int32_t p3d_weight_images_f16_batched(const float* flat, void* images, const void* table, int32_t njobs, void* stream);
 
 /* BatchNorm2d (+ residual + ReLU) on NHWC fp16: x, res, y, dy, dx, dres are [P = N*H*W][C] fp16; gamma, beta, running statistics
  * and dgamma / dbeta stay fp32 (they are the master parameters).  C/8 must divide 256 or be a multiple of it.
