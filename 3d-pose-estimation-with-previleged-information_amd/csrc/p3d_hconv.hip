@@ -419,18 +419,37 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
 struct WeightImageJob { long long w_off, krsc_off, crsk_off; int K, C, RS, Cpad; };
 __global__ __launch_bounds__(256) void weight_images_batched_kernel(const float* __restrict__ flat, _Float16* __restrict__ images,
                                                                     const WeightImageJob* __restrict__ table) {
+    // 32 (k) x 32 (c) tiles through LDS, one tap at a time: both images are written in 64-B runs (krsc along c, crsk along k)
+    __shared__ float tile[32][33];
     const WeightImageJob jb = table[blockIdx.y];
     const float* w = flat + jb.w_off;
     _Float16* krsc = images + jb.krsc_off;
     _Float16* crsk = jb.crsk_off >= 0 ? images + jb.crsk_off : nullptr;
-    const size_t total = (size_t)jb.K * jb.RS * jb.Cpad;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % jb.Cpad);
-        const int tap = (int)((i / jb.Cpad) % jb.RS);
-        const int k = (int)(i / ((size_t)jb.Cpad * jb.RS));
-        const _Float16 v = c < jb.C ? (_Float16)w[((size_t)k * jb.C + c) * jb.RS + tap] : (_Float16)0.f;
-        krsc[i] = v;
-        if (crsk) crsk[((size_t)c * jb.RS + tap) * jb.K + k] = v;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int tiles_c = (jb.Cpad + 31) / 32, tiles_k = (jb.K + 31) / 32;
+    for (int tile_id = blockIdx.x; tile_id < tiles_c * tiles_k; tile_id += gridDim.x) {
+        const int k0 = (tile_id / tiles_c) * 32, c0 = (tile_id % tiles_c) * 32;
+        for (int tap = 0; tap < jb.RS; ++tap) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + ty + 8 * r, c = c0 + tx;
+                tile[ty + 8 * r][tx] = (k < jb.K && c < jb.C) ? w[((size_t)k * jb.C + c) * jb.RS + tap] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + ty + 8 * r, c = c0 + tx;
+                if (k < jb.K && c < jb.Cpad) krsc[((size_t)k * jb.RS + tap) * jb.Cpad + c] = (_Float16)tile[ty + 8 * r][tx];
+            }
+            if (crsk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = c0 + ty + 8 * r, k = k0 + tx;
+                    if (k < jb.K && c < jb.Cpad) crsk[((size_t)c * jb.RS + tap) * jb.K + k] = (_Float16)tile[tx][ty + 8 * r];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -594,7 +613,7 @@ int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t
 int32_t p3d_weight_images_f16_batched(const float* flat, void* images, const void* table, int32_t njobs, void* stream) {
     P3D_REQUIRE(flat && images && table && njobs > 0, "weight_images_f16_batched: bad argument");
     static_assert(sizeof(WeightImageJob) == 40, "table row layout");
-    hipLaunchKernelGGL(weight_images_batched_kernel, dim3(64, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, flat, (_Float16*)images,
+    hipLaunchKernelGGL(weight_images_batched_kernel, dim3(128, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, flat, (_Float16*)images,
                        (const WeightImageJob*)table);
     return check_launch("weight_images_f16_batched");
 }
