@@ -64,7 +64,7 @@ def main():
     tj = os.path.join(ROOT, 'gpurun_out', 'traffic.json')
     if os.path.exists(tj):
         shutil.copy(tj, os.path.join(ROOT, 'profiles', '%s_traffic.json' % RND))
-    open(os.path.join(ROOT, 'profiles', '%s_tables.md' % RND), 'w').write('\n'.join(parts))
+    open(os.path.join(ROOT, 'gpurun_out', '%s_tables.md' % RND), 'w').write('\n'.join(parts))
     print('\n'.join(parts))
 
 
