@@ -44,3 +44,20 @@ def random_erase_(images255, rng):
     b, c, h, w = images255.shape
     rects, colour = draw_erase_rects(b, h, w, rng)
     return ops.augment_erase_(images255, torch.from_numpy(rects).to(images255.device), torch.from_numpy(colour).to(images255.device))
+
+
+class GpuAugment:
+    """What the reference's loader does to the colour image of a TRAINING sample after cropping (depth_datasets.py:210):
+    `transform(random_color(image) if colour else image)`, here for a whole batch on the GPU: the loader hands over raw 0..255
+    crops, this applies colour jitter (-colour), random erasing (-eraser) and ToTensor + Normalize, in place, three launches."""
+
+    def __init__(self, colour, eraser, seed=0):
+        self.colour, self.eraser = bool(colour), bool(eraser)
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+
+    def __call__(self, images255, train=True):
+        if train and self.colour:
+            random_color_(images255, self.rng)
+        if train and self.eraser:
+            random_erase_(images255, self.rng)
+        return ops.normalize_rgb_(images255)

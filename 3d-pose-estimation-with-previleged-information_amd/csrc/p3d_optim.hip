@@ -154,11 +154,26 @@ __global__ __launch_bounds__(256) void augment_erase_kernel(float* __restrict__ 
     }
 }
 
+// transforms.ToTensor() + transforms.Normalize(mean, std) (depth_datasets.py:91-93) on a planar batch holding 0..255 values, in place
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ img, int HW, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int c = blockIdx.y % 3;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = 1.f / (c == 0 ? s0 : (c == 1 ? s1 : s2));
+    float* p = img + (size_t)blockIdx.y * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) p[i] = (p[i] / 255.0f - mean) * inv;
+}
+
 }  // namespace p3d
 
 using namespace p3d;
 
 extern "C" {
+
+int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream) {
+    P3D_REQUIRE(img && mean3 && std3 && B > 0 && HW > 0, "normalize_rgb: bad argument");      // mean3 / std3 are HOST arrays of 3 floats
+    hipLaunchKernelGGL(normalize_kernel, dim3(32, 3 * B), dim3(256), 0, (hipStream_t)stream, img, HW, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
+                       std3[2]);
+    return check_launch("normalize_rgb");
+}
 
 int32_t p3d_l2norm_sq_accum(const float* g, int64_t n, double* accum, void* stream) {
     P3D_REQUIRE(g && accum && n > 0, "l2norm_sq_accum: bad argument");

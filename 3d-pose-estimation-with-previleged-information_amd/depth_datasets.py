@@ -34,12 +34,18 @@ class Dataset(data.Dataset):
         self.at_test = phase != 'train'
         self.do_teach = bool(getattr(args, 'do_teach', False)) and phase == 'train'
         self.stride, self.attention = args.stride, args.attention
+        # -colour / -eraser: the colour stream is handed over RAW (0..255 values); augmentation + ToTensor/Normalize run on the GPU
+        # in the trainer (augment.GpuAugment) instead of in the loader workers (depth_datasets.py:210)
+        self.raw_color = bool(args.colour or args.eraser)
 
     def __len__(self):
         return self.count
 
     def __getitem__(self, index):
         color, depth, cam, val = synth.make_batch(1, side=self.side_in, num_joints=self.num_joints, rank=0, step=index)
+        if self.raw_color:
+            raw = np.random.Generator(np.random.PCG64(7919 + index)).integers(0, 256, size=color[0].shape)
+            color = raw[None].astype(np.float32)
         items = [torch.from_numpy(color[0]), torch.from_numpy(depth[0]), torch.from_numpy(cam[0]), torch.from_numpy(val[0])]
         if self.at_test:
             items.append(torch.eye(3))

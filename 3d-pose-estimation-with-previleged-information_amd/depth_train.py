@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import dist as p3d_dist
-from . import ops, ops_half, utils
+from . import augment, ops, ops_half, utils
 from .optim import FlatAdam
 
 root_me = os.path.join(os.sep, 'globalwork', 'liu')      # depth_train.py:12; override with -metadata / $P3D_METADATA
@@ -91,6 +91,8 @@ class Trainer:
         self.do_freeze = args.do_freeze
         self.alpha_dest, self.alpha_init, self.alpha_span = args.alpha_dest, args.alpha_init, args.alpha_span
         self.teacher = None
+        # BASELINE config 5: colour / eraser augmentation + normalisation of the RGB stream on the GPU (augment.GpuAugment)
+        self.gpu_augment = augment.GpuAugment(args.colour, args.eraser) if (args.colour or args.eraser) else None
 
         metadata = _load_metadata(args)
         self.no_depth = metadata['no_depth'][args.data_name] if metadata else False
@@ -194,6 +196,8 @@ class Trainer:
         for i_batch, (color_image, depth_image, true_cam, true_val) in enumerate(data_loader):
             color_image = self.to(color_image, device) if (self.do_fusion or not self.depth_only) else None
             depth_image = self.to(depth_image, device) if (self.do_fusion or self.depth_only) else None
+            if self.gpu_augment is not None and color_image is not None:
+                color_image = self.gpu_augment(color_image.contiguous(), train=True)
             true_cam = true_cam.to(device, non_blocking=True)
             true_val = true_val.to(device, non_blocking=True)
             batch = true_cam.size(0)
@@ -242,6 +246,8 @@ class Trainer:
             color_image, depth_image, true_cam, true_val, color_br = items
             color_image = None if color_image is None else self.to(color_image, device)
             depth_image = None if depth_image is None else self.to(depth_image, device)
+            if self.gpu_augment is not None and color_image is not None:
+                color_image = self.gpu_augment(color_image.contiguous(), train=False)       # evaluation: ToTensor + Normalize only
             true_cam = true_cam.to(device)
             true_val = true_val.to(device)
             batch = true_cam.size(0)

@@ -589,3 +589,18 @@ def augment_erase_(img, rects, colour):
         raise P3DError('augment_erase: rects must be int32 and img contiguous')
     check(lib().p3d_augment_erase(_p(img), _p(rects.contiguous()), _p(colour.contiguous()), b, c, h, w, _stream()), 'p3d_augment_erase')
     return img
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)       # depth_datasets.py:78-79
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_rgb_(img, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """In place: transforms.ToTensor() + Normalize on a contiguous [B,3,H,W] fp32 device tensor holding 0..255 values."""
+    _need_gpu(img)
+    b, c, h, w = img.shape
+    if c != 3 or not img.is_contiguous():
+        raise P3DError('normalize_rgb: need a contiguous [B,3,H,W] image')
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib().p3d_normalize_rgb(_p(img), b, h * w, m3, s3, _stream()), 'p3d_normalize_rgb')
+    return img

@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--model', default='resnet50')
     ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet'],
                     help='informational runs of BASELINE configs 4/5; the contract line is depthnet (config 2)')
+    ap.add_argument('--augment', action='store_true', help='BASELINE config 5: colour + eraser augmentation and normalisation of a raw RGB batch on the GPU, inside the timed step')
     ap.add_argument('--half', action='store_true', help='informational: the -half_acc (fp16 NHWC) path; the contract line is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -71,7 +72,7 @@ def main():
     device = torch.device('cuda', local_rank)
 
     extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv']}[opt.family]
-    args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra + (['-half_acc'] if opt.half else []))
+    args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra + (['-half_acc'] if opt.half else []) + (['-colour', '-eraser'] if opt.augment else []))
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model, _ = pkg.depth_main.create_model(args)
     model = model.to(device).train()
@@ -86,6 +87,18 @@ def main():
         color = torch.from_numpy(c).to(device) if opt.family != 'partial_depthnet' else None
         depth = torch.from_numpy(d).to(device) if opt.family != 'depthnet' else None
         batches.append((color, depth, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
+
+    if opt.augment:
+        # the loader hands over raw 0..255 crops; every step augments + normalises a fresh copy on the GPU before the forward pass
+        raw = [(torch.rand(opt.batch, 3, 256, 256, device=device) * 255).floor_() for _ in range(nbuf)]
+        scratch = torch.empty_like(raw[0])
+        inner_step = trainer.train_step
+
+        def step_with_augmentation(color, depth, cam, val, _i=[0]):
+            scratch.copy_(raw[_i[0] % nbuf])
+            _i[0] += 1
+            return inner_step(trainer.gpu_augment(scratch, train=True), depth, cam, val)
+        trainer.train_step = step_with_augmentation
 
     def sync():
         if dist.is_initialized():
@@ -155,7 +168,7 @@ def main():
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
-                                   'RCCL grad all-reduce + clip + Adam' % (opt.family, opt.model, opt.batch),
+                                   'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,

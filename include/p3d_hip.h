@@ -181,6 +181,9 @@ int32_t p3d_distill_fwd_bwd(const float* teach, const float* student, const floa
 int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream);
 int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C,
                           int32_t H, int32_t W, void* stream);
+/* transforms.ToTensor() + Normalize(mean, std) of the loader (depth_datasets.py:78-79,91-93), in place on [B,3,H,W] holding 0..255:
+ * x = (x / 255 - mean[c]) / std[c]; mean3 / std3 are HOST pointers to 3 floats */
+int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp16 path of -half_acc (depth_train.py:73-83,413-449: model.half(), fp32 master copies, static loss scale).

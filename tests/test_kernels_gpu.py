@@ -263,3 +263,40 @@ def test_augment_colour_and_erase(pkg):
         want[i, :, max(y0, 0):y1, max(x0, 0):x1] = colour[i][:, None, None]
     got = host(ops.augment_erase_(dev(img), torch.from_numpy(rects).cuda(), dev(colour)))
     assert np.array_equal(got, want)
+
+
+def test_normalize_rgb_and_gpu_augment_pipeline(pkg):
+    """ToTensor + Normalize of the loader (depth_datasets.py:78-79,91-93) on the GPU, and the GpuAugment pipeline order."""
+    ops = pkg.ops
+    rng = np.random.default_rng(3)
+    img = np.floor(rng.random((2, 3, 16, 20)) * 256).astype(np.float32)
+    mean, std = np.array(ops.IMAGENET_MEAN, np.float32), np.array(ops.IMAGENET_STD, np.float32)
+    want = (img / np.float32(255) - mean[None, :, None, None]) / std[None, :, None, None]
+    got = host(ops.normalize_rgb_(dev(img)))
+    assert np.abs(got - want).max() < 2e-6
+    aug = pkg.augment.GpuAugment(colour=True, eraser=True, seed=5)
+    out = host(aug(dev(img), train=True))
+    # same draws, applied by hand: colour jitter -> erase -> normalise
+    rs = np.random.Generator(np.random.PCG64(5))
+    params = pkg.augment.draw_colour_params(2, rs)
+    rects, colour = pkg.augment.draw_erase_rects(2, 16, 20, rs)
+    step = ops.augment_colour_(dev(img), dev(params))
+    step = ops.augment_erase_(step, torch.from_numpy(rects).cuda(), dev(colour))
+    assert np.array_equal(out, host(ops.normalize_rgb_(step)))
+    assert np.array_equal(host(aug(dev(img), train=False)), got)                 # evaluation: normalisation only
+
+
+def test_fusion_training_with_gpu_augmentation(pkg):
+    """BASELINE config 5 wiring: fusionnet + -colour -eraser on the synthetic loader (raw 0..255 colour crops -> GPU augmentation)."""
+    args = pkg.opts.parse(['-model', 'resnet18', '-suffix', 't', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1',
+                           '-num_joints', '17', '-side_in', '128', '-do_fusion', '-colour', '-eraser', '-synthetic', '2', '-batch_size', '2',
+                           '-workers', '0'])
+    loader = pkg.depth_datasets.data_loader(args, 'train', pkg.utils.get_info())
+    color = next(iter(loader))[0]
+    assert float(color.max()) > 200 and float(color.min()) >= 0                   # raw crops, not normalised ones
+    model, _ = pkg.depth_main.create_model(args)
+    trainer = pkg.depth_train.Trainer(args, model.cuda(), pkg.utils.get_info())
+    trainer.verbose = False
+    assert trainer.gpu_augment is not None
+    rec = trainer.train(1, loader)
+    assert np.isfinite(rec['cam_train_loss']) and rec['cam_train_loss'] > 0
