@@ -73,8 +73,8 @@ class Trainer:
         if args.half_acc and (args.do_fusion or args.partial_conv or args.do_teach or args.skip_relu):
             raise NotImplementedError('-half_acc is implemented for the single-stream dense networks (depthnet / resnet); the fusion, '
                                       'partial-conv and distillation variants run in fp32')
-        if args.semi_teach:
-            raise NotImplementedError('-semi_teach needs the unlabelled PKU loader (depth_train.py:67-71,132-153): out of scope')
+        if args.semi_teach and not args.do_teach:
+            raise ValueError('-semi_teach adds unlabelled pairs to the distillation loss: it needs -do_teach')
         self.model = model
         self.data_info = data_info
         self.list_names = [name for name, param in model.named_parameters()]
@@ -91,12 +91,23 @@ class Trainer:
         self.do_freeze = args.do_freeze
         self.alpha_dest, self.alpha_init, self.alpha_span = args.alpha_dest, args.alpha_init, args.alpha_span
         self.teacher = None
+        self.semi_teach = bool(args.semi_teach)
+        self.semi_loader = self.semi_worker = None
         # BASELINE config 5: colour / eraser augmentation + normalisation of the RGB stream on the GPU (augment.GpuAugment)
         self.gpu_augment = augment.GpuAugment(args.colour, args.eraser) if (args.colour or args.eraser) else None
 
         metadata = _load_metadata(args)
         self.no_depth = metadata['no_depth'][args.data_name] if metadata else False
         self.thresh = metadata['thresholds'][args.data_name] if metadata else None
+
+        if self.semi_teach:
+            # depth_train.py:66-70: a second loader over the unlabelled `pku` image pairs, batch -semi_batch.  (The reference rewrites
+            # args.data_name / args.batch_size in place for this; a copy keeps the caller's namespace intact.)
+            import copy
+            semi_args = copy.copy(args)
+            semi_args.data_name, semi_args.batch_size = 'pku', args.semi_batch
+            self.semi_loader = get_loader(semi_args).data_loader(semi_args, 'train', data_info)
+            self.semi_worker = iter(self.semi_loader)
 
         self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
         self.reducer = p3d_dist.GradReducer(self.optimizer, reducer_bucket_bytes)
@@ -308,6 +319,22 @@ class Trainer:
         mode = 'bce' if self.bin_dist else ('sigmoid' if self.sigmoid else 'l2')
         return ops.distill_loss(teach_last, last_feat, atten_map, mode, weight, unit_grad)
 
+    def semi_train(self, device, epoch):
+        """depth_train.py:132-153: the distillation loss of one batch of unlabelled image pairs (no pose loss).
+        Returns (batch size, alpha-weighted loss for the graph, loss value)."""
+        try:
+            items = next(self.semi_worker)
+        except StopIteration:
+            self.semi_worker = iter(self.semi_loader)
+            items = next(self.semi_worker)
+        color_image, depth_image, true_cam, true_val, atten_map = items
+        color_image, depth_image, atten_map = (self.to(t, device) for t in (color_image, depth_image, atten_map))
+        with torch.no_grad():
+            teach_cam, teach_last = self.teach_infer(color_image, depth_image)
+        cam_feat, last_feat = self.vanilla_infer(color_image, 0, True)
+        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map.float(), self.get_dist_weight(epoch), unit_grad=True)
+        return true_cam.size(0), weighted, dist_loss
+
     def distill_step(self, epoch, color_image, depth_image, true_cam, true_val, atten_map):
         """One iteration of distill_train on device tensors; returns (cam_loss, dist_loss) as 0-d device tensors."""
         side_out = (self.side_in - 1) // self.stride + 1
@@ -322,6 +349,11 @@ class Trainer:
                                            count_override=count)
         self.last_spec_cam = spec_cam
         loss = weighted + cam_loss                      # dist_loss * alpha + cam_loss (depth_train.py:220)
+        self.last_semi = None
+        if self.semi_teach:                              # depth_train.py:222-230
+            semi_batch, semi_weighted, semi_loss = self.semi_train(color_image.device, epoch)
+            loss = loss + semi_weighted
+            self.last_semi = (semi_batch, semi_loss.detach())
         self.optimizer.zero_grad()
         loss.backward()
         assert ops.pending_joins() == 0
@@ -334,7 +366,7 @@ class Trainer:
             raise RuntimeError('distill_train: call set_teacher() first')
         n_batches = len(data_loader)
         cam_sum = dist_sum = 0.0
-        samples = 0
+        samples = dist_samples = 0
         if self.do_freeze:
             self.freeze_batchnorm()
         if self.verbose:
@@ -348,6 +380,13 @@ class Trainer:
             cam_sum += cam_value * batch
             dist_sum += dist_value * batch
             samples += batch
+            dist_samples += batch
+            message = '[=] train Epoch[{0}] Batch[{1}|{2}]  Cam Loss {3:.4f}  Dist Loss {4:.4f} '.format(epoch, i_batch, n_batches, cam_value, dist_value)
+            if self.last_semi is not None:               # the unlabelled pairs count towards the distillation average only
+                semi_batch, semi_loss = self.last_semi
+                dist_sum += semi_loss.item() * semi_batch
+                dist_samples += semi_batch
+                message += ' Semi Loss {:.4f}'.format(semi_loss.item())
             if self.verbose:
-                print('[=] train Epoch[{0}] Batch[{1}|{2}]  Cam Loss {3:.4f}  Dist Loss {4:.4f} '.format(epoch, i_batch, n_batches, cam_value, dist_value))
-        return dict(dist_train_loss=dist_sum / max(samples, 1), cam_train_loss=cam_sum / max(samples, 1))
+                print(message)
+        return dict(dist_train_loss=dist_sum / max(dist_samples, 1), cam_train_loss=cam_sum / max(samples, 1))

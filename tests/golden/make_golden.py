@@ -338,6 +338,50 @@ def gen_distill():
     print('distill.npz', rec)
 
 
+def gen_semi():
+    """One unmodified distill_train iteration with -semi_teach (depth_train.py:66-70,132-153,222-230).  The reference builds the
+    unlabelled loader through get_loader(args) (metadata.json -> dataset module -> files on disk); the harness substitutes a module
+    object whose data_loader() returns one synthetic batch, nothing in the reference is edited."""
+    import types
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'metadata.json'), 'w') as f:
+        json.dump(dict(loader=dict(h36m='depth_datasets', pku='depth_datasets'), no_depth=dict(h36m=False, pku=False),
+                       thresholds=dict(h36m=dict(solid=10, close=20, rough=150), pku=dict(solid=10, close=20, rough=150)), root=dict(h36m=tmp)), f)
+    args = ref_args('resnet18', 128, ['-do_teach', '-do_fusion', '-semi_teach', '-semi_batch', '2'])
+    import depth_train, depth_main, depthnet, fusionnet, utils
+    depth_train.root_me = tmp
+
+    def make(rank, seed0):
+        c, d, tc, tv = synth.make_batch(2, side=128, rank=rank, step=0)
+        att = np.stack([utils.get_attention(128, 16, np.random.Generator(np.random.PCG64(seed0 + i)).uniform(0, 128, size=(17, 2)), True)
+                        for i in range(2)]).astype(np.float32)
+        return tuple(torch.from_numpy(x) for x in (c, d, tc, tv, att)), att
+    semi_batch, semi_att = make(12, 100)
+    orig = depth_train.get_loader
+    depth_train.get_loader = lambda a: types.SimpleNamespace(data_loader=lambda a2, phase, info: [semi_batch])
+    student = depthnet.resnet18(args, False)
+    teacher = fusionnet.resnet18(args, False)
+    load_det_weights(student, seed=0)
+    load_det_weights(teacher, seed=1)
+    tr = depth_train.Trainer(args, student, depth_main.get_info())
+    depth_train.get_loader = orig
+    tr.set_teacher(teacher)
+    batch, att = make(11, 0)
+    tr.model.train()
+    tr.adapt_learn_rate(1)
+    rec = tr.distill_train(1, [batch], torch.device('cpu'))
+    sd = {k: tnp(v) for k, v in student.state_dict().items()}
+    names = tr.list_names
+    rs = np.random.Generator(np.random.PCG64(5))
+    idx = np.array([rs.integers(0, sd[n].size, size=4) for n in names])
+    np.savez_compressed(os.path.join(HERE, 'distill_semi.npz'), record=np.array(json.dumps({k: float(v) for k, v in rec.items()})),
+                        att=att, semi_att=semi_att, names=np.array(json.dumps(names)),
+                        param_norms=np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names]), sample_idx=idx,
+                        param_samples=np.array([sd[n].reshape(-1)[idx[i]] for i, n in enumerate(names)]),
+                        buffer_norms=np.array([np.linalg.norm(sd[k].astype(np.float64)) for k in sd if k not in names]))
+    print('distill_semi.npz', rec)
+
+
 def gen_legacy_resnet():
     """resnet.py forward only (train.Trainer cannot be constructed: it reads args.thresh_* that opts.py lacks)."""
     args = ref_args('resnet18', 256, ['-joint_space'])
@@ -381,7 +425,7 @@ def gen_state_keys():
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval', 'distill'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
@@ -395,5 +439,7 @@ if __name__ == '__main__':
             gen_eval()
         elif t == 'distill':
             gen_distill()
+        elif t == 'semi':
+            gen_semi()
         else:
             gen_step(t)
