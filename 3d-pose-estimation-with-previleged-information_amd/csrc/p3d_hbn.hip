@@ -285,6 +285,21 @@ __global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const _Float16* __res
     }
 }
 
+// channel concat of two NHWC tensors (torch.cat((x, y), dim=1) of fusionnet.py:138) and its backward (split): 16-B chunks
+__global__ __launch_bounds__(256) void hconcat_kernel(_Float16* __restrict__ a, _Float16* __restrict__ b, _Float16* __restrict__ cat, size_t P, int Ga, int Gb,
+                                                      int split) {
+    const int G = Ga + Gb;
+    const size_t total = P * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int g = (int)(i % G);
+        const size_t p = i / G;
+        h8* part = reinterpret_cast<h8*>(g < Ga ? a + (p * Ga + g) * 8 : b + (p * Gb + (g - Ga)) * 8);
+        h8* whole = reinterpret_cast<h8*>(cat + i * 8);
+        if (split) *part = *whole;
+        else *whole = *part;
+    }
+}
+
 static bool hbn_shape_ok(int C) { return C >= 8 && C % 8 == 0 && ((C / 8) <= 256 ? 256 % (C / 8) == 0 : (C / 8) % 256 == 0); }
 
 }  // namespace p3d
@@ -352,6 +367,15 @@ int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const fl
     hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
                        (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)dres, P, C, relu);
     return check_launch("hbn_train_bwd");
+}
+
+/* split == 0: cat[P][Ca+Cb] = concat(a[P][Ca], b[P][Cb]);  split != 0: a, b = the two channel windows of cat (backward of the concat) */
+int32_t p3d_hconcat(void* a, void* b, void* cat, int64_t P, int32_t Ca, int32_t Cb, int32_t split, void* stream) {
+    P3D_REQUIRE(a && b && cat && P > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0, "hconcat: bad argument");
+    const int64_t total = P * ((Ca + Cb) / 8);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(hconcat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (_Float16*)a, (_Float16*)b, (_Float16*)cat, (size_t)P, Ca / 8, Cb / 8, split);
+    return check_launch("hconcat");
 }
 
 int32_t p3d_hmaxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -23,6 +23,9 @@ class Fusion(nn.Module):
         self.bn = BatchNorm2d(inplanes)
 
     def forward(self, x, y):
+        if x.dtype == torch.float16:                      # -half_acc: NHWC concat kernel + the ordinary fp16 1x1 convolution
+            from . import ops_half
+            return self.bn(self.conv(ops_half.concat(x, y)), relu=True)
         return self.bn(ops.conv_cat1x1(x, y, self.conv.weight), relu=True)     # fusionnet.py:138-140
 
 
@@ -52,15 +55,15 @@ class ResNet(TrunkBase):
         self.regressor = Conv2d(512 * block.expansion, args.depth * args.num_joints, 3, padding=1)
 
     def forward(self, x, y):
-        x = stem(self.conv1, self.bn1, self.maxpool, x)
-        y = stem(self.conv2, self.bn2, self.maxpool, y)
+        x = stem(self.conv1, self.bn1, self.maxpool, self._half_in(x))
+        y = stem(self.conv2, self.bn2, self.maxpool, self._half_in(y))
         x = self.layer2(self.layer1(x))
         y = self.layer6(self.layer5(y))
         x = self.fusion(x, y)
         m = self.layer3(x)
         n = self.layer4(ops.relu(m) if self.skip_relu else m)
         z = self.regressor(ops.relu(n) if self.skip_relu else n)
-        return z, m if self.early_dist else n
+        return self._half_out(z, m if self.early_dist else n)
 
 
 def manual_update(model_dict, toy_dict):

@@ -321,3 +321,32 @@ class HMaxPoolFn(torch.autograd.Function):
 
 def maxpool3x3s2(x):
     return HMaxPoolFn.apply(x)
+
+
+class HConcatFn(torch.autograd.Function):
+    """torch.cat((x, y), dim=1) of the Fusion block (fusionnet.py:138) on NHWC fp16 tensors."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        _need_half(x, y)
+        x, y = _cl(x), _cl(y)
+        n, ca, h, w = x.shape
+        cb = y.shape[1]
+        if y.shape[0] != n or y.shape[2:] != x.shape[2:]:
+            raise P3DError('hconcat: shapes %s and %s do not match' % (tuple(x.shape), tuple(y.shape)))
+        out = _empty(n, ca + cb, h, w, x.device)
+        check(lib().p3d_hconcat(_p(x), _p(y), _p(out), n * h * w, ca, cb, 0, _stream()), 'p3d_hconcat')
+        ctx.dims = (n, ca, cb, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, ca, cb, h, w = ctx.dims
+        dout = _cl(dout)
+        dx, dy = _empty(n, ca, h, w, dout.device), _empty(n, cb, h, w, dout.device)
+        check(lib().p3d_hconcat(_p(dx), _p(dy), _p(dout), n * h * w, ca, cb, 1, _stream()), 'p3d_hconcat')
+        return dx, dy
+
+
+def concat(x, y):
+    return HConcatFn.apply(x, y)

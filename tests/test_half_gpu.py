@@ -199,15 +199,16 @@ def test_hmaxpool(shape, pkg):
     assert np.abs(nchw32(dxt) - want).max() < 2e-3 * max(1.0, np.abs(want).max())
 
 
-def test_half_train_step_matches_reference_half(pkg):
-    """Two -half_acc iterations against what the reference's own fp16 path (model.half() on torch's CPU half kernels, fp32
+@pytest.mark.parametrize('case', ['half_r18_b2', 'half_fusion_r18_b2'])
+def test_half_train_step_matches_reference_half(case, pkg):
+    """-half_acc iterations against what the reference's own fp16 path (model.half() on torch's CPU half kernels, fp32
     copy_params, loss scale 32; depth_train.py:73-83,413-449) produced for the same weights and batches.  The two fp16
     implementations round at different places, so the bars are the fp16 noise measured between the reference's own fp32 and
     fp16 runs (loss 3e-5, joints 4e-4, clip norm 6e-4, per-tensor gradient norms: median 2e-3, worst 5e-2)."""
     import json
     from conftest import golden_path
     from test_step_gpu import build
-    g = np.load(golden_path('step_half_r18_b2.npz'))
+    g = np.load(golden_path('step_%s.npz' % case))
     meta = json.loads(str(g['meta']))
     assert '-half_acc' in meta['extra']
     args, model, trainer = build(pkg, meta)
@@ -216,7 +217,8 @@ def test_half_train_step_matches_reference_half(pkg):
     trainer.adapt_learn_rate(1)
     for it in range(meta['iters']):
         c, d, tc, tv = pkg.synth.make_batch(meta['batch'], side=meta['side'], rank=0, step=it, invalid_frac=meta['invalid_frac'])
-        loss = float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+        depth = torch.from_numpy(d).cuda() if '-do_fusion' in meta['extra'] else None
+        loss = float(trainer.train_step(torch.from_numpy(c).cuda(), depth, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
         assert abs(loss - g['losses'][it]) < 1e-3 * abs(g['losses'][it]), (it, loss, g['losses'][it])
         spec_sel = trainer.last_spec_cam.cpu().numpy().reshape(-1, 3)[tv.reshape(-1)]
         ref_sel = g['spec_sel_%d' % it]
