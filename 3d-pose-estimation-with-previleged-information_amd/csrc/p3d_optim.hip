@@ -162,11 +162,56 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ img,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) p[i] = (p[i] / 255.0f - mean) * inv;
 }
 
+// Crop re-projection of the loader (depth_datasets.get_input_image -> cameralib.reproject_image_fast, cameralib.py:667-711):
+// dst(x, y) = bilinear sample of src at H * (x, y, 1) / w, constant border 0 (cv2.remap INTER_LINEAR, BORDER_CONSTANT).
+// src: [B][Hs][Ws][C] interleaved (as decoded from file), uint8 (T = uint8_t) or fp32 (depth maps); dst: planar [B][C][Ho][Wo] fp32.
+// uint8 sources are rounded to the nearest integer like cv2's uint8 output; one thread per output pixel, all channels.
+template <typename T>
+__global__ __launch_bounds__(256) void warp_crops_kernel(const T* __restrict__ src, const float* __restrict__ hom, float* __restrict__ dst, int Hs, int Ws,
+                                                         int C, int Ho, int Wo) {
+    const int b = blockIdx.y;
+    const float* h = hom + b * 9;
+    const T* img = src + (size_t)b * Hs * Ws * C;
+    float* out = dst + (size_t)b * C * Ho * Wo;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Ho * Wo; i += gridDim.x * blockDim.x) {
+        const float x = (float)(i % Wo), y = (float)(i / Wo);
+        const float w = h[6] * x + h[7] * y + h[8];
+        const float sx = (h[0] * x + h[1] * y + h[2]) / w, sy = (h[3] * x + h[4] * y + h[5]) / w;
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        const bool finite = sx == sx && sy == sy && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            if (finite) {
+                const bool xl = (unsigned)x0 < (unsigned)Ws, xr = (unsigned)(x0 + 1) < (unsigned)Ws;
+                const bool yt = (unsigned)y0 < (unsigned)Hs, yb = (unsigned)(y0 + 1) < (unsigned)Hs;
+                const float p00 = (xl && yt) ? (float)img[((size_t)y0 * Ws + x0) * C + c] : 0.f;
+                const float p01 = (xr && yt) ? (float)img[((size_t)y0 * Ws + x0 + 1) * C + c] : 0.f;
+                const float p10 = (xl && yb) ? (float)img[((size_t)(y0 + 1) * Ws + x0) * C + c] : 0.f;
+                const float p11 = (xr && yb) ? (float)img[((size_t)(y0 + 1) * Ws + x0 + 1) * C + c] : 0.f;
+                v = (p00 * (1.f - ax) + p01 * ax) * (1.f - ay) + (p10 * (1.f - ax) + p11 * ax) * ay;
+                if (sizeof(T) == 1) v = rintf(v);
+            }
+            out[(size_t)c * Ho * Wo + i] = v;
+        }
+    }
+}
+
 }  // namespace p3d
 
 using namespace p3d;
 
 extern "C" {
+
+int32_t p3d_warp_crops(const void* src, int32_t src_is_u8, const float* homography, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                       int32_t Ho, int32_t Wo, void* stream) {
+    P3D_REQUIRE(src && homography && dst && B > 0 && Hs > 0 && Ws > 0 && C > 0 && Ho > 0 && Wo > 0, "warp_crops: bad argument");
+    dim3 grid((unsigned)(ceil_div((int64_t)Ho * Wo, 256) < 256 ? ceil_div((int64_t)Ho * Wo, 256) : 256), (unsigned)B);
+    if (src_is_u8) hipLaunchKernelGGL(warp_crops_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, homography, dst, Hs, Ws, C, Ho, Wo);
+    else hipLaunchKernelGGL(warp_crops_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, homography, dst, Hs, Ws, C, Ho, Wo);
+    return check_launch("warp_crops");
+}
 
 int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream) {
     P3D_REQUIRE(img && mean3 && std3 && B > 0 && HW > 0, "normalize_rgb: bad argument");      // mean3 / std3 are HOST arrays of 3 floats

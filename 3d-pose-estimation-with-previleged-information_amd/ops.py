@@ -604,3 +604,19 @@ def normalize_rgb_(img, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     check(lib().p3d_normalize_rgb(_p(img), b, h * w, m3, s3, _stream()), 'p3d_normalize_rgb')
     return img
+
+
+def warp_crops(frames, homography, out_hw):
+    """Batch of crop re-projections (depth_datasets.py:153-193): frames [B,Hs,Ws,C] uint8 or fp32 (interleaved, as decoded),
+    homography [B,3,3] fp32 mapping crop pixels to frame pixels -> [B,C,Ho,Wo] fp32 (0..255 values for uint8 sources)."""
+    if not frames.is_cuda or frames.dtype not in (torch.uint8, torch.float32) or frames.dim() != 4:
+        raise P3DError('warp_crops: frames must be a [B,Hs,Ws,C] uint8 / fp32 tensor on the HIP device')
+    _need_gpu(homography)
+    frames, homography = frames.contiguous(), homography.contiguous()
+    b, hs, ws, c = frames.shape
+    if tuple(homography.shape) != (b, 3, 3):
+        raise P3DError('warp_crops: homography must be [B,3,3]')
+    ho, wo = out_hw
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=frames.device)
+    check(lib().p3d_warp_crops(_p(frames), int(frames.dtype == torch.uint8), _p(homography), _p(out), b, hs, ws, c, ho, wo, _stream()), 'p3d_warp_crops')
+    return out

@@ -181,6 +181,11 @@ int32_t p3d_distill_fwd_bwd(const float* teach, const float* student, const floa
 int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream);
 int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C,
                           int32_t H, int32_t W, void* stream);
+/* Crop re-projection of the loader (depth_datasets.py:153-193 -> cameralib.reproject_image_fast, cameralib.py:667-711) for a batch:
+ * dst[b][c][y][x] = bilinear sample of src[b] ([Hs][Ws][C] interleaved, uint8 if src_is_u8 else fp32) at homography[b] * (x, y, 1),
+ * constant border 0; uint8 sources are rounded like cv2's uint8 output.  homography: [B][3][3] fp32 (device), new image -> old image. */
+int32_t p3d_warp_crops(const void* src, int32_t src_is_u8, const float* homography, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                       int32_t Ho, int32_t Wo, void* stream);
 /* transforms.ToTensor() + Normalize(mean, std) of the loader (depth_datasets.py:78-79,91-93), in place on [B,3,H,W] holding 0..255:
  * x = (x / 255 - mean[c]) / std[c]; mean3 / std3 are HOST pointers to 3 floats */
 int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream);

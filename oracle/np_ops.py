@@ -411,3 +411,35 @@ def erase_rect(image_shape_hw, area_frac, aspect, start_frac):
     start = np.round(start).astype(int)
     end = np.round(end).astype(int)
     return int(start[1]), int(start[0]), int(end[1]), int(end[0])
+
+
+def crop_homography(old_intrinsics, old_rotation, new_intrinsics, new_rotation):
+    """cameralib.reproject_image_fast (cameralib.py:672-674): pixel of the NEW image -> pixel of the OLD image."""
+    old_matrix = np.asarray(old_intrinsics, np.float64) @ np.asarray(old_rotation, np.float64)
+    new_matrix = np.asarray(new_intrinsics, np.float64) @ np.asarray(new_rotation, np.float64)
+    return (old_matrix @ np.linalg.inv(new_matrix)).astype(np.float32)
+
+
+def warp_crop(image_hwc, homography, out_hw):
+    """Restatement of the remap of cameralib.reproject_image_fast (cameralib.py:692-706): float32 coordinates as the reference
+    computes them, bilinear interpolation with constant border 0.  cv2 itself is absent here and quantises the sample position to
+    1/32 px with 15-bit weights; this plain bilinear form is the documented definition -> parity with cv2 is UNPINNED."""
+    ho, wo = out_hw
+    y, x = np.mgrid[:ho, :wo].astype(np.float32)
+    coords = np.asarray(homography, np.float32) @ np.stack([x, y, np.ones_like(x)], 0).reshape(3, -1)
+    sx, sy = (coords[0] / coords[2]).astype(np.float32), (coords[1] / coords[2]).astype(np.float32)
+    img = np.asarray(image_hwc)
+    hs, ws = img.shape[:2]
+    img = img.reshape(hs, ws, -1).astype(np.float32)
+    fx, fy = np.floor(sx), np.floor(sy)
+    ax, ay = (sx - fx)[:, None], (sy - fy)[:, None]
+    x0, y0 = fx.astype(np.int64), fy.astype(np.int64)
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < ws) & (yy >= 0) & (yy < hs)
+        v = img[np.clip(yy, 0, hs - 1), np.clip(xx, 0, ws - 1)]
+        return np.where(ok[:, None], v, np.float32(0))
+    out = (tap(y0, x0) * (1 - ax) + tap(y0, x0 + 1) * ax) * (1 - ay) + (tap(y0 + 1, x0) * (1 - ax) + tap(y0 + 1, x0 + 1) * ax) * ay
+    if np.asarray(image_hwc).dtype == np.uint8:
+        out = np.rint(out)
+    return out.reshape(ho, wo, -1).transpose(2, 0, 1).astype(np.float32)

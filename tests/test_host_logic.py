@@ -176,3 +176,22 @@ def test_gradient_exchange_world2_gloo(pkg, tmp_path):
         flat = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in net.parameters()])
         total = flat if total is None else total + flat
     assert torch.allclose(r0['flat'], total, rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_crop_warp_properties():
+    """The numpy restatement of cameralib.reproject_image_fast's remap: identity, integer shift with zero border, half-pixel mean."""
+    from oracle import np_ops as ref
+    rng = np.random.default_rng(1)
+    img = (rng.random((9, 11, 3)) * 255).astype(np.uint8)
+    eye = np.eye(3, dtype=np.float32)
+    assert np.array_equal(ref.warp_crop(img, eye, (9, 11)), img.transpose(2, 0, 1).astype(np.float32))
+    shift = np.array([[1, 0, 2], [0, 1, -1], [0, 0, 1]], np.float32)          # crop pixel (x, y) reads frame pixel (x + 2, y - 1)
+    out = ref.warp_crop(img, shift, (9, 11))
+    assert np.array_equal(out[:, 1:, :9], img.transpose(2, 0, 1)[:, :8, 2:].astype(np.float32))
+    assert not out[:, 0].any() and not out[:, :, 9:].any()                    # outside the frame: border value 0
+    half = np.array([[1, 0, 0.5], [0, 1, 0], [0, 0, 1]], np.float32)
+    f = img[..., :1].astype(np.float32)
+    got = ref.warp_crop(f, half, (9, 10))
+    assert np.allclose(got[0], 0.5 * (f[:, :10, 0] + f[:, 1:11, 0]))
+    k = np.array([[100.0, 0, 50], [0, 100.0, 40], [0, 0, 1]])
+    assert np.allclose(ref.crop_homography(k, np.eye(3), k, np.eye(3)), np.eye(3), atol=1e-6)
