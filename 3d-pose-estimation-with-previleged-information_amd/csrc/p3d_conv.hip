@@ -51,6 +51,9 @@ struct IgemmParams {
     int N, C, H, W, K, R, S, stride, pad, dil, Ho, Wo;
     int ldw;                // c_total*R*S : stride between filters in w
     int woff;               // c_offset*R*S
+    size_t a_bytes;         // extent of the weight tensor / image (buffer range check)
+    int wcs, wts;           // weight element (k, c, tap) sits at k*ldw + woff + c*wcs + tap*wts: KCRS (wcs = R*S, wts = 1) or the
+                            // tap-major image [tap][K][C] (ldw = C, wcs = 1, wts = K*C) that large 3x3 weights are re-laid into per call
     int M, Ncols, Kd;
     int kchunk;             // WGRAD: K extent per split (multiple of BK); FWD: K-steps per split (0 = no split)
     int accumulate;
@@ -162,11 +165,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     else nfirst = k_begin / HoWo;
     __amdgpu_buffer_rsrc_t rA, rB, rM;
     if constexpr (MODE == MODE_FWD) {
-        rA = make_rsrc(p.A, (size_t)p.K * p.ldw * 4);
+        rA = make_rsrc(p.A, p.a_bytes);
         rB = make_rsrc(p.B + (size_t)nfirst * p.C * HW, (size_t)(p.N - nfirst) * p.C * HW * 4);
         rM = make_rsrc(MASKED && p.mask_in ? p.mask_in + (size_t)nfirst * HW : nullptr, MASKED && p.mask_in ? (size_t)(p.N - nfirst) * HW * 4 : 0);
     } else if constexpr (MODE == MODE_DGRAD) {
-        rA = make_rsrc(p.A, (size_t)p.K * p.ldw * 4);
+        rA = make_rsrc(p.A, p.a_bytes);
         rB = make_rsrc(p.B + (size_t)nfirst * p.K * HoWo, (size_t)(p.N - nfirst) * p.K * HoWo * 4);
         rM = make_rsrc(MASKED && p.mult ? p.mult + (size_t)nfirst * HoWo : nullptr, MASKED && p.mult ? (size_t)(p.N - nfirst) * HoWo * 4 : 0);
     } else {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int m = m0 + t / BK + K_ROWS * i;
-            a_voff[i] = m < p.M ? (m * p.ldw + (t % BK) * RS) * 4 : OOB;
+            a_voff[i] = m < p.M ? (m * p.ldw + (t % BK) * p.wcs) * 4 : OOB;
         }
         b_base = ((cb_n * p.C + t / BN) * HW) * 4;
     }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int i = 0; i < A_PER; ++i) {
             const int e = t + 256 * i;
             const int m = m0 + e % BM;
-            a_voff[i] = m < p.M ? ((e / BM) * p.ldw + m * RS) * 4 : OOB;
+            a_voff[i] = m < p.M ? ((e / BM) * p.ldw + m * p.wcs) * 4 : OOB;
         }
         b_base = ((cb_n * p.K + t / BN) * HoWo) * 4;
     }
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     auto ld_prologue = [&](int kt) {
         if constexpr (MODE == MODE_FWD && TAPM) {
             const int r = ld_tp / p.S, s = ld_tp - r * p.S;
-            st_a_soff = (p.woff + ld_c0 * RS + ld_tp) * 4;
+            st_a_soff = (p.woff + ld_c0 * p.wcs + ld_tp * p.wts) * 4;
             st_a_bad = (chan_pad && ld_c0 + t % BK >= chan_lim) ? OOB : 0;
             const int hi = cb_a + r * p.dil, wi = cb_b + s * p.dil;
             const bool okp = col_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int ir = ld_tp / cls_ns, is = ld_tp - ir * cls_ns;
             const int r = p.r0[ph] + p.rstep[ph] * ir, s = p.s0[pw] + p.sstep[pw] * is;
             const int ho = cb_a + p.offr0[ph] - ir * p.offrstep[ph], wo = cb_b + p.offs0[pw] - is * p.offsstep[pw];
-            st_a_soff = (ld_c0 * p.ldw + p.woff + r * p.S + s) * 4;
+            st_a_soff = (ld_c0 * p.ldw + p.woff + (r * p.S + s) * p.wts) * 4;
             const bool okp = col_ok && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
             const int pix = ho * p.Wo + wo;
             st_b_voff = (b_base + pix * 4) | (okp ? 0 : OOB);
@@ -778,6 +781,8 @@ static IgemmParams base_params(const p3d_conv_desc* d) {
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.Ho = d->Ho; p.Wo = d->Wo;
     p.ldw = d->c_total * d->R * d->S;
     p.woff = d->c_offset * d->R * d->S;
+    p.wcs = d->R * d->S; p.wts = 1;
+    p.a_bytes = (size_t)d->K * p.ldw * sizeof(float);
     p.accumulate = d->accumulate;
     return p;
 }
@@ -930,6 +935,31 @@ extern "C" {
 // Forward split-K: a launch of <= 400 long-K blocks leaves CUs with 1 or 2 blocks and no tail to even them out (ResNet-50's
 // 2048->272 regressor: 384 blocks x 1152 K-steps).  Splitting the K-steps 2-3 ways gives ~3 equal blocks per CU; the partial
 // outputs go to slabs in the workspace and one streaming pass sums them and adds the bias.
+// wT[tap][k][c] = w[k][c][tap]: a thread owns one (k, c) pair -> reads R*S consecutive floats, writes coalesced along c
+__global__ __launch_bounds__(256) void weight_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ wT, int K, int C, int RS) {
+    const size_t KC = (size_t)K * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < KC; i += (size_t)gridDim.x * 256)
+        for (int tap = 0; tap < RS; ++tap) wT[(size_t)tap * KC + i] = w[i * RS + tap];
+}
+
+// Large multi-tap weights (>= 2 MB: the 256- and 512-channel 3x3 layers, the 20 MB regressor) do not stay in L2 across the column tiles of a launch, and in KCRS
+// a K-step touches every 9th float of them: each of the 9 tap passes of the K loop re-fetches the whole tensor's cache lines from
+// MALL / HBM.  Such weights are re-laid tap-major into the call's workspace first (one streaming pass, ~2x|w| bytes); forward and
+// dgrad then read them with unit stride (forward: 64-B runs along c, dgrad: 256-B runs along c).
+static size_t weight_image_bytes(const p3d_conv_desc* d) {
+    static const double min_mb = [] { const char* e = getenv("P3D_WT_MIN_MB"); return e ? atof(e) : 2.0; }();
+    const size_t bytes = (size_t)d->K * d->C * d->R * d->S * sizeof(float);
+    if (d->R * d->S == 1 || d->C < 16 || d->c_total != d->C || d->c_offset != 0 || (double)bytes < min_mb * 1048576.0) return 0;
+    return (bytes + 255) & ~(size_t)255;
+}
+static void use_weight_image(IgemmParams& p, const p3d_conv_desc* d, const float* w, float* image, hipStream_t st) {
+    const int64_t kc = (int64_t)d->K * d->C;
+    hipLaunchKernelGGL(weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, image, d->K, d->C,
+                       d->R * d->S);
+    p.A = image; p.ldw = d->C; p.woff = 0; p.wcs = 1; p.wts = d->K * d->C;
+    p.a_bytes = (size_t)d->K * d->C * d->R * d->S * sizeof(float);
+}
+
 struct FwdPlan { int cfg; bool tapm; int splits; int kchunk; };
 
 static FwdPlan plan_fwd(const p3d_conv_desc* d, bool masked, bool allow_split) {
@@ -964,7 +994,7 @@ static FwdPlan plan_fwd(const p3d_conv_desc* d, bool masked, bool allow_split) {
 size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     const FwdPlan pl = plan_fwd(d, false, true);
-    return pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0;
+    return weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
 }
 
 int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -977,6 +1007,11 @@ int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, c
     const bool masked = mask_in || mult;
     FwdPlan pl = plan_fwd(d, masked, true);
     const size_t ysize = (size_t)d->N * d->K * d->Ho * d->Wo;
+    const size_t wimg = weight_image_bytes(d);
+    if (wimg && pl.tapm && workspace && workspace_bytes >= wimg) {      // tap-major weight image at the head of the workspace
+        use_weight_image(p, d, w, (float*)workspace, (hipStream_t)stream);
+        workspace = (char*)workspace + wimg; workspace_bytes -= wimg;
+    }
     if (pl.splits > 1 && (!workspace || workspace_bytes < pl.splits * ysize * sizeof(float))) pl = plan_fwd(d, masked, false);   // no scratch: unsplit
     p.cpad = (int)ceil_div(d->C, kCfgs[pl.cfg].bk) * kCfgs[pl.cfg].bk;
     if (pl.splits > 1) {
@@ -1026,7 +1061,7 @@ size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     if (d->stride == 1) {
         const FwdPlan pl = plan_dgrad1(d, false);
-        return pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0;
+        return weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
     }
     const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
     return (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
@@ -1058,6 +1093,11 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
     if (st == 1) {
         const FwdPlan pl = plan_dgrad1(d, masked);
         const size_t xsize = (size_t)d->N * d->C * d->H * d->W;
+        const size_t wimg = weight_image_bytes(d);
+        if (wimg && workspace && workspace_bytes >= wimg) {
+            use_weight_image(p, d, w, (float*)workspace, (hipStream_t)stream);
+            workspace = (char*)workspace + wimg; workspace_bytes -= wimg;
+        }
         if (pl.splits > 1 && workspace && workspace_bytes >= pl.splits * xsize * sizeof(float)) {
             p.cpad = (int)ceil_div(d->K, kCfgs[pl.cfg].bk) * kCfgs[pl.cfg].bk;
             p.Cout = (float*)workspace; p.accumulate = 0; p.kchunk = pl.kchunk; p.cls_stride = xsize;
