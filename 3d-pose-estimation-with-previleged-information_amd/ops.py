@@ -80,7 +80,7 @@ _side_workspaces = {}
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
-        st = torch.cuda.Stream(device=device, priority=int(os.environ.get('P3D_SIDE_PRIO', '0')))
+        st = torch.cuda.Stream(device=device)
         _side_streams[device] = st
     return st
 
