@@ -32,6 +32,8 @@ SIGNATURES = {
     'p3d_last_error': (ctypes.c_char_p, []),
     'p3d_conv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_fwd_workspace_bytes': (_sz, [_desc]),
+    'p3d_conv2d_bn_eval_fwd_workspace_bytes': (_sz, [_desc]),
+    'p3d_conv2d_bn_eval_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i32, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_dgrad_workspace_bytes': (_sz, [_desc]),
     'p3d_conv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_wgrad_workspace_bytes': (_sz, [_desc]),

@@ -63,6 +63,8 @@ class _ResidualBlock(nn.Module):
         if self.partial:                      # partial_depthnet.py:44-46: blocks receive an (x, veil) tuple
             return self.forward_partial(*x)
         # the block input fans out to conv1 and the shortcut: join the two input gradients inside conv1's dgrad kernel (ops.GradJoin)
+        if ops.can_fuse_eval(x, self.conv1, self.bn1):
+            return self._forward_inference(x)
         join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1
@@ -73,6 +75,16 @@ class _ResidualBlock(nn.Module):
             else:
                 res, res_join = self._shortcut(x, join)
                 out = getattr(self, bname)(out, res=res, relu=not self.skip_relu, res_join=res_join)
+        return out
+
+    def _forward_inference(self, x):
+        """model.eval() under no_grad: every conv + BN (+ shortcut add + ReLU) pair of the block is one fused kernel."""
+        res = x if self.downsample is None else ops.conv_bn_eval(x, self.downsample[0], self.downsample[1])
+        out = x
+        last = len(self._chain) - 1
+        for i, (cname, bname) in enumerate(self._chain):
+            conv, bn = getattr(self, cname), getattr(self, bname)
+            out = ops.conv_bn_eval(out, conv, bn, relu=True) if i < last else ops.conv_bn_eval(out, conv, bn, res=res, relu=not self.skip_relu)
         return out
 
     def forward_partial(self, x, veil):
@@ -171,5 +183,7 @@ class TrunkBase(nn.Module):
 
 
 def stem(conv, bn, pool, x):
-    """conv -> BN+ReLU (one kernel) -> maxpool."""
+    """conv -> BN+ReLU (one kernel) -> maxpool; at inference conv + BN + ReLU are one kernel."""
+    if ops.can_fuse_eval(x, conv, bn):
+        return pool(ops.conv_bn_eval(x, conv, bn, relu=True))
     return pool(bn(conv(x), relu=True))

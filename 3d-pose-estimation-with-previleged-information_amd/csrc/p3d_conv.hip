@@ -46,6 +46,10 @@ struct IgemmParams {
     const float* B;
     float* Cout;
     const float* bias;
+    const float* ep_scale;  // FWD epilogue of the fused inference path: y = act(conv * ep_scale[k] + ep_shift[k] + ep_res), or null
+    const float* ep_shift;
+    const float* ep_res;
+    int ep_relu;
     const float* mask_in;   // [N,1,H,W] or null
     const float* mult;      // [N,1,Ho,Wo] or null
     int N, C, H, W, K, R, S, stride, pad, dil, Ho, Wo;
@@ -518,51 +522,85 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    size_t cbase[TN];
+    float cscale[TN];
+    bool cok[TN];
+    size_t rstride = 0;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int col = n0 + wn * (TN * 32) + ni * 32 + li;
-        if (col >= ncols) continue;
-        size_t base;
-        size_t rstride;
-        float scale = 1.f;
+        cok[ni] = col < ncols;
+        cscale[ni] = 1.f;
+        cbase[ni] = 0;
+        if (!cok[ni]) continue;
         if constexpr (MODE == MODE_FWD) {
             const int n = col / HoWo, pp = col - n * HoWo;
-            base = (size_t)n * p.K * HoWo + pp + (size_t)blockIdx.y * p.cls_stride;      // cls_stride = |y| when split-K slabs are in use, else 0
+            cbase[ni] = (size_t)n * p.K * HoWo + pp + (size_t)blockIdx.y * p.cls_stride;      // cls_stride = |y| when split-K slabs are in use, else 0
             rstride = HoWo;
-            if constexpr (MASKED) { if (p.mult) scale = p.mult[(size_t)n * HoWo + pp]; }
+            if constexpr (MASKED) { if (p.mult) cscale[ni] = p.mult[(size_t)n * HoWo + pp]; }
         } else if constexpr (MODE == MODE_DGRAD) {
             const int hw = Hc * Wc;
             const int n = col / hw, pix = col - n * hw;
             if (p.staged) {      // class-major staging buffer [cls][N][C][Hc][Wc]: full-line stores; interleaved into dx afterwards
-                base = (size_t)blockIdx.y * p.cls_stride + (size_t)n * p.C * hw + pix;
+                cbase[ni] = (size_t)blockIdx.y * p.cls_stride + (size_t)n * p.C * hw + pix;
                 rstride = hw;
             } else {
-                base = (size_t)n * p.C * HW + pix + (size_t)blockIdx.y * p.cls_stride;      // (+ slab offset under split-K, else 0)
+                cbase[ni] = (size_t)n * p.C * HW + pix + (size_t)blockIdx.y * p.cls_stride;      // (+ slab offset under split-K, else 0)
                 rstride = HW;
-                if constexpr (MASKED) { if (p.mask_in) scale = p.mask_in[(size_t)n * HW + pix]; }
+                if constexpr (MASKED) { if (p.mask_in) cscale[ni] = p.mask_in[(size_t)n * HW + pix]; }
             }
         } else {
-            base = (size_t)blockIdx.y * p.M * p.Ncols + col;
+            cbase[ni] = (size_t)blockIdx.y * p.M * p.Ncols + col;
             rstride = p.Ncols;
         }
+    }
+    if constexpr (MODE == MODE_FWD) rstride = HoWo;
+    else if constexpr (MODE == MODE_DGRAD) rstride = p.staged ? (size_t)Hc * Wc : (size_t)HW;
+    else rstride = p.Ncols;
+    const bool fused_act = MODE == MODE_FWD && p.ep_scale != nullptr;
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+    for (int mi = 0; mi < TM; ++mi) {
+        // the values this block adds to (residual of the fused inference epilogue, or the tensor it accumulates onto) are fetched for a
+        // whole 32-row slice first, so their latency is paid once per slice instead of once per element
+        float prev[16][TN];
+        const bool want_prev = (MODE == MODE_FWD && fused_act && p.ep_res != nullptr) || (MODE != MODE_WGRAD && p.accumulate);
+        if (want_prev) {
+            const float* src = (MODE == MODE_FWD && fused_act && p.ep_res != nullptr) ? p.ep_res : p.Cout;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                if (row < p.M) {
-                    float v = acc[mi][ni][reg];
-                    if constexpr (MASKED) v *= scale;
-                    const size_t idx = base + (size_t)row * rstride;
-                    if constexpr (MODE == MODE_FWD) {
-                        // with a partial-conv multiplier: ((raw - b)*mult + b)*mask_out, mask_out == (mult > 0)  (partial_conv.py:48-51)
-                        if (p.bias) v = (MASKED && p.mult && !(scale > 0.f)) ? 0.f : v + p.bias[row];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) prev[reg][ni] = (row < p.M && cok[ni]) ? src[cbase[ni] + (size_t)row * rstride] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (row >= p.M) continue;
+            float rbias = 0.f, rsc = 1.f, rsh = 0.f;                 // per-row constants: one load per row, not per element
+            if constexpr (MODE == MODE_FWD) {
+                if (p.bias) rbias = p.bias[row];
+                if (fused_act) { rsc = p.ep_scale[row]; rsh = p.ep_shift[row]; }
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (!cok[ni]) continue;
+                float v = acc[mi][ni][reg];
+                if constexpr (MASKED) v *= cscale[ni];
+                const size_t idx = cbase[ni] + (size_t)row * rstride;
+                if constexpr (MODE == MODE_FWD) {
+                    // with a partial-conv multiplier: ((raw - b)*mult + b)*mask_out, mask_out == (mult > 0)  (partial_conv.py:48-51)
+                    if (p.bias) v = (MASKED && p.mult && !(cscale[ni] > 0.f)) ? 0.f : v + rbias;
+                    if (fused_act) {                           // BatchNorm with frozen statistics (+ residual, ReLU) folded into the conv
+                        v = fmaf(v, rsc, rsh);
+                        if (p.ep_res) v += prev[reg][ni];
+                        if (p.ep_relu) v = fmaxf(v, 0.f);
                     }
-                    if constexpr (MODE != MODE_WGRAD) {
-                        if (p.accumulate) v += p.Cout[idx];
-                    }
-                    p.Cout[idx] = v;
                 }
+                if constexpr (MODE != MODE_WGRAD) {
+                    if (p.accumulate) v += prev[reg][ni];
+                }
+                p.Cout[idx] = v;
             }
         }
     }
@@ -590,7 +628,9 @@ __global__ __launch_bounds__(256) void dgrad_interleave_kernel(const float* __re
 
 // y[n][k][p] (=|+=) sum_z slab[z][n][k][p] + bias[k]   (split-K forward)
 __global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict__ slab, float* __restrict__ y, const float* __restrict__ bias,
-                                                         size_t total, int K, int HoWo, int splits, int accumulate) {
+                                                         size_t total, int K, int HoWo, int splits, int accumulate,
+                                                         const float* __restrict__ ep_scale = nullptr, const float* __restrict__ ep_shift = nullptr,
+                                                         const float* __restrict__ ep_res = nullptr, int ep_relu = 0) {
     if ((HoWo & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(slab)) & 15) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(slab);
         float4* y4 = reinterpret_cast<float4*>(y);
@@ -599,6 +639,13 @@ __global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict
             float4 a = s4[i];
             for (int z = 1; z < splits; ++z) { const float4 b = s4[(size_t)z * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
             if (bias) { const float b = bias[((i << 2) / HoWo) % K]; a.x += b; a.y += b; a.z += b; a.w += b; }
+            if (ep_scale) {
+                const int k = (int)(((i << 2) / HoWo) % K);
+                const float sc = ep_scale[k], sh = ep_shift[k];
+                a.x = fmaf(a.x, sc, sh); a.y = fmaf(a.y, sc, sh); a.z = fmaf(a.z, sc, sh); a.w = fmaf(a.w, sc, sh);
+                if (ep_res) { const float4 r = reinterpret_cast<const float4*>(ep_res)[i]; a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+                if (ep_relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            }
             if (accumulate) { const float4 o = y4[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
             y4[i] = a;
         }
@@ -608,6 +655,12 @@ __global__ __launch_bounds__(256) void fwd_reduce_kernel(const float* __restrict
         float a = 0.f;
         for (int z = 0; z < splits; ++z) a += slab[(size_t)z * total + i];
         if (bias) a += bias[(i / HoWo) % K];
+        if (ep_scale) {
+            const int k = (int)((i / HoWo) % K);
+            a = fmaf(a, ep_scale[k], ep_shift[k]);
+            if (ep_res) a += ep_res[i];
+            if (ep_relu) a = fmaxf(a, 0.f);
+        }
         y[i] = accumulate ? y[i] + a : a;
     }
 }
@@ -997,12 +1050,14 @@ size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
     return weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
 }
 
-int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
-                       const float* mask_in, const float* mult, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask_in, const float* mult,
+                               float* y, void* workspace, size_t workspace_bytes, void* stream, const float* ep_scale, const float* ep_shift,
+                               const float* ep_res, int ep_relu) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
+    p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
     p.M = d->K; p.Ncols = d->N * d->Ho * d->Wo; p.Kd = d->C * d->R * d->S;
     const bool masked = mask_in || mult;
     FwdPlan pl = plan_fwd(d, masked, true);
@@ -1015,17 +1070,51 @@ int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, c
     if (pl.splits > 1 && (!workspace || workspace_bytes < pl.splits * ysize * sizeof(float))) pl = plan_fwd(d, masked, false);   // no scratch: unsplit
     p.cpad = (int)ceil_div(d->C, kCfgs[pl.cfg].bk) * kCfgs[pl.cfg].bk;
     if (pl.splits > 1) {
-        p.Cout = (float*)workspace; p.bias = nullptr; p.accumulate = 0;
+        p.Cout = (float*)workspace; p.bias = nullptr; p.accumulate = 0; p.ep_scale = nullptr;      // the epilogue runs in the reduce pass
         p.kchunk = pl.kchunk; p.cls_stride = ysize;
         launch_igemm<MODE_FWD>(pl.cfg, true, false, p, pl.splits, (hipStream_t)stream);
         if (int32_t e = check_launch("conv2d_fwd")) return e;
         const unsigned blocks = (unsigned)(ceil_div((int64_t)ysize, 1024) < 4096 ? ceil_div((int64_t)ysize, 1024) : 4096);
         hipLaunchKernelGGL(fwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, y, bias, ysize, d->K,
-                           d->Ho * d->Wo, pl.splits, d->accumulate);
+                           d->Ho * d->Wo, pl.splits, d->accumulate, ep_scale, ep_shift, ep_res, ep_relu);
         return check_launch("conv2d_fwd reduce");
     }
     launch_igemm<MODE_FWD>(pl.cfg, pl.tapm, masked, p, 1, (hipStream_t)stream);
     return check_launch("conv2d_fwd");
+}
+
+int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
+                       const float* mask_in, const float* mult, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_fwd_impl(d, x, w, bias, mask_in, mult, y, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, 0);
+}
+
+// coef[0..K) = gamma / sqrt(var + eps), coef[K..2K) = beta - mean * coef[k]   (the constants of p3d_bn_eval_fwd)
+__global__ __launch_bounds__(256) void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                                           const float* __restrict__ rv, float* __restrict__ coef, int K, float eps) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float sc = gamma[k] / sqrtf(rv[k] + eps);
+    coef[k] = sc;
+    coef[K + k] = beta[k] - rm[k] * sc;
+}
+
+size_t p3d_conv2d_bn_eval_fwd_workspace_bytes(const p3d_conv_desc* d) {
+    if (validate(d)) return 0;
+    return (((size_t)2 * d->K * sizeof(float) + 255) & ~(size_t)255) + p3d_conv2d_fwd_workspace_bytes(d);
+}
+
+int32_t p3d_conv2d_bn_eval_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* gamma, const float* beta,
+                               const float* running_mean, const float* running_var, float eps, const float* res, int32_t relu, float* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (int32_t e = validate(d)) return e;
+    P3D_REQUIRE(gamma && beta && running_mean && running_var, "conv2d_bn_eval_fwd: null BatchNorm tensor");
+    P3D_REQUIRE(!d->accumulate, "conv2d_bn_eval_fwd: accumulate is not meaningful with a fused activation");
+    const size_t head = ((size_t)2 * d->K * sizeof(float) + 255) & ~(size_t)255;
+    if (!workspace || workspace_bytes < head) { set_error("conv2d_bn_eval_fwd: workspace too small"); return P3D_EWORKSPACE; }
+    float* coef = (float*)workspace;
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((unsigned)ceil_div(d->K, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var,
+                       coef, d->K, eps);
+    return conv2d_fwd_impl(d, x, w, nullptr, nullptr, nullptr, y, (char*)workspace + head, workspace_bytes - head, stream, coef, coef + d->K, res, relu);
 }
 
 // stride-1 dgrad split-K, same reasoning as the forward one (few long blocks: 256 -> 256 3x3 at 16x16 is 256 blocks x 144 K-steps)

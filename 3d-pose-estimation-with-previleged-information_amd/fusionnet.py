@@ -26,7 +26,7 @@ class Fusion(nn.Module):
         if x.dtype == torch.float16:                      # -half_acc: NHWC concat kernel + the ordinary fp16 1x1 convolution
             from . import ops_half
             return self.bn(self.conv(ops_half.concat(x, y)), relu=True)
-        return self.bn(ops.conv_cat1x1(x, y, self.conv.weight), relu=True)     # fusionnet.py:138-140
+        return self.bn(ops.conv_cat1x1(x, y, self.conv.weight), relu=True)     # fusionnet.py:138-140 (two channel windows: not folded at inference)
 
 
 class ResNet(TrunkBase):

@@ -620,3 +620,25 @@ def warp_crops(frames, homography, out_hw):
     out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=frames.device)
     check(lib().p3d_warp_crops(_p(frames), int(frames.dtype == torch.uint8), _p(homography), _p(out), b, hs, ws, c, ho, wo, _stream()), 'p3d_warp_crops')
     return out
+
+
+def conv_bn_eval(x, conv, bn, res=None, relu=False):
+    """Inference only (no autograd): conv (no bias) + BatchNorm with frozen statistics (+ residual, + ReLU) as one kernel launch
+    (model.eval() forward of a residual block, depthnet.py:42-56,98-116)."""
+    from .nn import _one
+    _need_gpu(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res)
+    x = x.contiguous()
+    res = None if res is None else res.contiguous()
+    d = _desc(x.shape, conv.weight.shape, _one(conv.stride), _one(conv.padding), _one(conv.dilation))
+    y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = workspace(x.device, L.p3d_conv2d_bn_eval_fwd_workspace_bytes(ctypes.byref(d)))
+    check(L.p3d_conv2d_bn_eval_fwd(ctypes.byref(d), _p(x), _p(conv.weight.detach()), _p(bn.weight.detach()), _p(bn.bias.detach()), _p(bn.running_mean),
+                                   _p(bn.running_var), bn.eps, _p(res), int(relu), _p(y), _p(ws), ws.numel(), _stream()), 'p3d_conv2d_bn_eval_fwd')
+    return y
+
+
+def can_fuse_eval(x, conv, bn):
+    """The fused inference kernel applies when nothing needs a gradient, BN uses its running statistics and the conv is plain."""
+    return (not torch.is_grad_enabled() and not bn.training and x.dtype == torch.float32 and conv.bias is None
+            and type(conv).__name__ == 'Conv2d' and bn.track_running_stats)

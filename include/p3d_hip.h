@@ -67,6 +67,13 @@ size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d);
 /* dx = dgrad(dy * mult) * mask_in  (autograd of the expression above w.r.t. x).  Stride-2 convolutions are
  * computed as four dense parity-class GEMMs staged in `workspace`; a stride-1 launch of few long blocks is split over K into
  * slabs there (optional: without workspace it runs unsplit).  Query the size; 0 when none is used. */
+/* Inference: nn.Conv2d (no bias) + nn.BatchNorm2d in eval mode (+ residual add, + ReLU) of a residual block (depthnet.py:42-56,
+ * 98-116 under model.eval(), depth_train.py:611) as ONE kernel: y = act((conv(x, w) - mean) * gamma / sqrt(var + eps) + beta + res).
+ * res may be NULL; the BatchNorm constants are folded into per-channel scale / shift at the head of the workspace. */
+size_t p3d_conv2d_bn_eval_fwd_workspace_bytes(const p3d_conv_desc* d);
+int32_t p3d_conv2d_bn_eval_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* gamma, const float* beta,
+                               const float* running_mean, const float* running_var, float eps, const float* res, int32_t relu,
+                               float* y, void* workspace, size_t workspace_bytes, void* stream);
 size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d);
 int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
                          const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream);

@@ -37,7 +37,8 @@ def test_workspace_queries_are_host_only(pkg):
     lib = pkg._lib.lib()
     d = pkg.ops._desc((64, 256, 16, 16), (256, 256, 3, 3), 1, 1, 1)
     assert lib.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d)) >= 256 * 256 * 9 * 4
-    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)) in (0, 3 * 64 * 256 * 16 * 16 * 4)     # stride 1: optional split-K slabs
+    slabs, image = 3 * 64 * 256 * 16 * 16 * 4, 256 * 256 * 9 * 4             # stride 1: optional split-K slabs + optional tap-major weight image
+    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)) in (0, slabs, image, slabs + image)
     d1 = pkg.ops._desc((64, 64, 64, 64), (256, 64, 1, 1), 1, 0, 1)
     assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d1)) == 0                              # thousands of blocks: never split
     d2 = pkg.ops._desc((4, 128, 64, 64), (128, 128, 3, 3), 2, 1, 1)

@@ -329,3 +329,28 @@ def test_warp_crops(dtype, chan, pkg):
     else:
         assert diff.max() < 1e-3 * 255
     assert (want == 0).mean() > 0.02 and (want > 0).mean() > 0.5        # the case crosses the frame border and the interior
+
+
+@pytest.mark.parametrize('case', [(2, 64, 16, 16, 128, 1, 1, 0, 1, True, True), (2, 32, 20, 20, 64, 3, 1, 1, 1, False, True),
+                                  (3, 24, 33, 31, 72, 3, 2, 1, 1, False, False), (4, 256, 16, 16, 256, 3, 1, 1, 1, True, True),
+                                  (2, 3, 64, 64, 64, 7, 2, 3, 1, False, True)])
+def test_conv_bn_eval_fused(case, pkg):
+    """Inference kernel conv + frozen BatchNorm (+ residual + ReLU) against the oracle's conv followed by bn_eval (incl. the split-K shape)."""
+    n, c, h, w, k, ks, st, pad, dil, with_res, relu = case
+    rng = np.random.default_rng(n * 100 + c)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((k, c, ks, ks)) / np.sqrt(c * ks * ks)).astype(np.float32)
+    gamma, beta = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32), (0.3 * rng.standard_normal(k)).astype(np.float32)
+    rm, rv = (0.2 * rng.standard_normal(k)).astype(np.float32), (0.5 + rng.random(k)).astype(np.float32)
+    y = ref.bn_eval_fwd(ref.conv2d_fwd(x, wt, None, st, pad, dil), gamma, beta, rm, rv)
+    res = rng.standard_normal(y.shape).astype(np.float32) if with_res else None
+    want = y + (res if with_res else 0)
+    want = np.maximum(want, 0) if relu else want
+    conv = pkg.nn.Conv2d(c, k, ks, stride=st, padding=pad, dilation=dil, bias=False).cuda()
+    bn = pkg.nn.BatchNorm2d(k).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(dev(wt)); bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta)); bn.running_mean.copy_(dev(rm)); bn.running_var.copy_(dev(rv))
+        assert pkg.ops.can_fuse_eval(dev(x), conv, bn)
+        got = host(pkg.ops.conv_bn_eval(dev(x), conv, bn, res=None if res is None else dev(res), relu=relu))
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+    assert not pkg.ops.can_fuse_eval(dev(x), conv, bn)                           # with autograd on, the unfused path runs
