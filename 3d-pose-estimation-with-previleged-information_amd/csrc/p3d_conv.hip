@@ -522,88 +522,119 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-    size_t cbase[TN];
+    // The block's output window is a buffer resource based at its slab / class / first image, so an element's address is
+    //   voffset (per lane, fixed: column + the half-wave's 4-row offset) + soffset (wave-uniform: row * row stride)
+    // and a store costs no per-element address arithmetic (64 stores per thread: with 64-bit index math the epilogue of a short-K
+    // 1x1 layer took as long as its K loop).  Lanes / rows outside the tensor carry the out-of-range bit and are dropped.
+    size_t out_off, out_span;
+    int rstride;
+    if constexpr (MODE == MODE_FWD) {
+        rstride = HoWo;
+        out_off = (size_t)blockIdx.y * p.cls_stride + (size_t)nfirst * p.K * HoWo;            // cls_stride = |y| under split-K, else 0
+        out_span = (size_t)(p.N - nfirst) * p.K * HoWo * 4;
+    } else if constexpr (MODE == MODE_DGRAD) {
+        rstride = p.staged ? Hc * Wc : HW;      // staged: class-major buffer [cls][N][C][Hc][Wc], interleaved into dx afterwards
+        out_off = (size_t)blockIdx.y * p.cls_stride + (size_t)nfirst * p.C * rstride;         // (slab offset under stride-1 split-K)
+        out_span = (size_t)(p.N - nfirst) * p.C * rstride * 4;
+    } else {
+        rstride = p.Ncols;
+        out_off = (size_t)blockIdx.y * p.M * p.Ncols;
+        out_span = (size_t)p.M * p.Ncols * 4;
+    }
+    const __amdgpu_buffer_rsrc_t rO = make_rsrc(p.Cout + out_off, out_span);
+    const bool fused_act = MODE == MODE_FWD && p.ep_scale != nullptr;
+    const bool res_prev = MODE == MODE_FWD && fused_act && p.ep_res != nullptr;
+    const bool want_prev = res_prev || (MODE != MODE_WGRAD && p.accumulate);
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(want_prev ? (res_prev ? p.ep_res : p.Cout) + out_off : nullptr, want_prev ? out_span : 0);
+
+    int cvoff[TN];
     float cscale[TN];
-    bool cok[TN];
-    size_t rstride = 0;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int col = n0 + wn * (TN * 32) + ni * 32 + li;
-        cok[ni] = col < ncols;
         cscale[ni] = 1.f;
-        cbase[ni] = 0;
-        if (!cok[ni]) continue;
+        cvoff[ni] = OOB;
+        if (col >= ncols) continue;
         if constexpr (MODE == MODE_FWD) {
             const int n = col / HoWo, pp = col - n * HoWo;
-            cbase[ni] = (size_t)n * p.K * HoWo + pp + (size_t)blockIdx.y * p.cls_stride;      // cls_stride = |y| when split-K slabs are in use, else 0
-            rstride = HoWo;
+            cvoff[ni] = ((n - nfirst) * p.K * HoWo + pp + 4 * kh * rstride) * 4;
             if constexpr (MASKED) { if (p.mult) cscale[ni] = p.mult[(size_t)n * HoWo + pp]; }
         } else if constexpr (MODE == MODE_DGRAD) {
             const int hw = Hc * Wc;
             const int n = col / hw, pix = col - n * hw;
-            if (p.staged) {      // class-major staging buffer [cls][N][C][Hc][Wc]: full-line stores; interleaved into dx afterwards
-                cbase[ni] = (size_t)blockIdx.y * p.cls_stride + (size_t)n * p.C * hw + pix;
-                rstride = hw;
-            } else {
-                cbase[ni] = (size_t)n * p.C * HW + pix + (size_t)blockIdx.y * p.cls_stride;      // (+ slab offset under split-K, else 0)
-                rstride = HW;
-                if constexpr (MASKED) { if (p.mask_in) cscale[ni] = p.mask_in[(size_t)n * HW + pix]; }
-            }
+            cvoff[ni] = ((n - nfirst) * p.C * rstride + pix + 4 * kh * rstride) * 4;
+            if constexpr (MASKED) { if (!p.staged && p.mask_in) cscale[ni] = p.mask_in[(size_t)n * HW + pix]; }
         } else {
-            cbase[ni] = (size_t)blockIdx.y * p.M * p.Ncols + col;
-            rstride = p.Ncols;
+            cvoff[ni] = (col + 4 * kh * rstride) * 4;
         }
     }
-    if constexpr (MODE == MODE_FWD) rstride = HoWo;
-    else if constexpr (MODE == MODE_DGRAD) rstride = p.staged ? (size_t)Hc * Wc : (size_t)HW;
-    else rstride = p.Ncols;
-    const bool fused_act = MODE == MODE_FWD && p.ep_scale != nullptr;
+    const int row_u0 = __builtin_amdgcn_readfirstlane(m0 + wm * (TM * 32));
+    const bool rows_all = m0 + BM <= p.M;                       // uniform: no row of this tile is past the tensor
+    if (!MASKED && !want_prev && !fused_act && !(MODE == MODE_FWD && p.bias)) {
+        // plain result (every wgrad slab, most forward and dgrad launches): nothing but the stores
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        // the values this block adds to (residual of the fused inference epilogue, or the tensor it accumulates onto) are fetched for a
-        // whole 32-row slice first, so their latency is paid once per slice instead of once per element
-        float prev[16][TN];
-        const bool want_prev = (MODE == MODE_FWD && fused_act && p.ep_res != nullptr) || (MODE != MODE_WGRAD && p.accumulate);
-        if (want_prev) {
-            const float* src = (MODE == MODE_FWD && fused_act && p.ep_res != nullptr) ? p.ep_res : p.Cout;
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const int row_u = row_u0 + mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                const int bad = (rows_all || row_u + 4 * kh < p.M) ? 0 : OOB;
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) prev[reg][ni] = (row < p.M && cok[ni]) ? src[cbase[ni] + (size_t)row * rstride] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-            if (row >= p.M) continue;
-            float rbias = 0.f, rsc = 1.f, rsh = 0.f;                 // per-row constants: one load per row, not per element
-            if constexpr (MODE == MODE_FWD) {
-                if (p.bias) rbias = p.bias[row];
-                if (fused_act) { rsc = p.ep_scale[row]; rsh = p.ep_shift[row]; }
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                if (!cok[ni]) continue;
-                float v = acc[mi][ni][reg];
-                if constexpr (MASKED) v *= cscale[ni];
-                const size_t idx = cbase[ni] + (size_t)row * rstride;
-                if constexpr (MODE == MODE_FWD) {
-                    // with a partial-conv multiplier: ((raw - b)*mult + b)*mask_out, mask_out == (mult > 0)  (partial_conv.py:48-51)
-                    if (p.bias) v = (MASKED && p.mult && !(cscale[ni] > 0.f)) ? 0.f : v + rbias;
-                    if (fused_act) {                           // BatchNorm with frozen statistics (+ residual, ReLU) folded into the conv
-                        v = fmaf(v, rsc, rsh);
-                        if (p.ep_res) v += prev[reg][ni];
-                        if (p.ep_relu) v = fmaxf(v, 0.f);
-                    }
+                for (int ni = 0; ni < TN; ++ni) {
+                    const float v = acc[mi][ni][reg];          // (__builtin_bit_cast straight on the vector element stores element 0: ROCm 7.2 clang)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rO, cvoff[ni] | bad, row_u * rstride * 4, 0);
                 }
-                if constexpr (MODE != MODE_WGRAD) {
-                    if (p.accumulate) v += prev[reg][ni];
-                }
-                p.Cout[idx] = v;
             }
-        }
+        return;
     }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // the values this block adds to (residual of the fused inference epilogue, or the tensor it accumulates onto) and the
+            // per-row constants are fetched for four rows at a time: their latency is paid once per group, not once per element,
+            // and the group is small enough not to cost the kernel an occupancy step
+            float prev[4][TN], rbias[4], rsc[4], rsh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row_u = row_u0 + mi * 32 + e + 8 * g;
+                const int row = row_u + 4 * kh;
+                const int rsafe = row < p.M ? row : p.M - 1;        // clamp instead of branching: the element is dropped at the store
+                rbias[e] = 0.f; rsc[e] = 1.f; rsh[e] = 0.f;
+                if constexpr (MODE == MODE_FWD) {
+                    if (p.bias) rbias[e] = p.bias[rsafe];
+                    if (fused_act) { rsc[e] = p.ep_scale[rsafe]; rsh[e] = p.ep_shift[rsafe]; }
+                }
+                if (want_prev) {
+                    const int bad = (rows_all || row < p.M) ? 0 : OOB;
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        prev[e][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rP, cvoff[ni] | bad, row_u * rstride * 4, 0));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row_u = row_u0 + mi * 32 + e + 8 * g;
+                const int bad = (rows_all || row_u + 4 * kh < p.M) ? 0 : OOB;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    float v = acc[mi][ni][4 * g + e];
+                    if constexpr (MASKED) v *= cscale[ni];
+                    if constexpr (MODE == MODE_FWD) {
+                        // with a partial-conv multiplier: ((raw - b)*mult + b)*mask_out, mask_out == (mult > 0)  (partial_conv.py:48-51)
+                        if (p.bias) v = (MASKED && p.mult && !(cscale[ni] > 0.f)) ? 0.f : v + rbias[e];
+                        if (fused_act) {                       // BatchNorm with frozen statistics (+ residual, ReLU) folded into the conv
+                            v = fmaf(v, rsc[e], rsh[e]);
+                            if (p.ep_res) v += prev[e][ni];
+                            if (p.ep_relu) v = fmaxf(v, 0.f);
+                        }
+                    }
+                    if constexpr (MODE != MODE_WGRAD) {
+                        if (p.accumulate) v += prev[e][ni];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rO, cvoff[ni] | bad, row_u * rstride * 4, 0);
+                }
+            }
+        }
 }
 
 // dx[n][c][hi][wi] (=|+=) stage[cls(hi,wi)][n][c][hi/s][wi/s] * mask_in ; classes no tap reaches contribute 0
