@@ -979,6 +979,10 @@ static WgradPlan plan_wgrad(const p3d_conv_desc* d, bool masked) {
         if (!tm && d->R * d->S > 1) cost *= 1.3;          // generic per-element tap decode is slower
         if (cost < best * 0.999) { best = cost; cfg = i; tapm = tm; }
     }
+    {   // weight tensors of at most four 128x128 tiles (layer1, the stems): 64x64 tiles need a quarter of the splits -> less slab traffic
+        const int64_t t128 = ceil_div(M, 128) * ceil_div(Ncols, 128);
+        if (!masked && forced_cfg() < 0 && t128 <= 4 && d->C % 64 == 0) { cfg = 5; tapm = true; }
+    }
     const int bk = kCfgs[cfg].bk;
     const int64_t tiles = ceil_div(M, kCfgs[cfg].bm) * ceil_div(Ncols, kCfgs[cfg].bn);
     int64_t splits = ceil_div(1024, tiles);
