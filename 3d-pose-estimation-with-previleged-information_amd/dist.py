@@ -21,6 +21,11 @@ import torch.distributed as dist
 DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
 
 
+def env_ranks():
+    """(rank, world, local_rank) as torchrun exports them, without joining anything."""
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
 def init_from_env(backend=None):
     """Join the process group torchrun describes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -104,13 +109,26 @@ class GradReducer:
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         self._launched[b] = True
-        if self.opt.flat_g.is_cuda:
+        bucket = self.opt.flat_g[start:end]
+        side = None
+        if bucket.is_cuda:
             from . import ops
-            ops.join_side_stream(self.opt.flat_g.device)       # weight gradients are written on the side stream (ops.WGRAD_STREAM)
+            if ops.WGRAD_STREAM and not os.environ.get('P3D_REDUCE_JOIN_MAIN'):
+                # Weight gradients are written on the wgrad stream, BN / bias gradients on the launch stream.  The collective is issued
+                # FROM the wgrad stream after that stream has been ordered behind the launch stream's current position: RCCL's stream
+                # then waits for both, and the launch stream (the dy -> BN-backward -> dgrad critical path) is never stalled.
+                side = ops._side_stream(bucket.device)
+                side.wait_stream(torch.cuda.current_stream(bucket.device))
+            else:
+                ops.join_side_stream(bucket.device)
         if os.environ.get('P3D_REDUCE_BLOCKING'):                     # debugging aid
-            dist.all_reduce(self.opt.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             return
-        self._handles.append(dist.all_reduce(self.opt.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if side is not None:
+            with torch.cuda.stream(side):
+                self._handles.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._handles.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after backward: launches any bucket whose hooks did not all fire (unused parameters), waits for

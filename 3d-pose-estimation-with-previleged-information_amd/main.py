@@ -62,7 +62,7 @@ def main(argv=None):
     from . import opts
     args = opts.parse(argv)
     assert args.do_track <= args.joint_space                                              # main.py:73
-    rank, world, local_rank = p3d_dist.init_from_env()
+    rank, world, local_rank = p3d_dist.env_ranks()        # the group is joined after the model / optimizer buffers exist (see depth_main.main)
     torch.cuda.set_device(local_rank)
     model, state = create_model(args)
     data_info = get_info()
@@ -77,6 +77,11 @@ def main(argv=None):
     logger = log.Logger(args, state)
     trainer = train.Trainer(args, model, data_info)
     trainer.verbose = rank == 0
+    if world > 1 or p3d_dist.FORCE_GROUP:
+        p3d_dist.init_from_env()
+        trainer.reducer.remove()
+        trainer.reducer = p3d_dist.GradReducer(trainer.optimizer)
+        trainer.world = trainer.reducer.world
     if args.test_only or args.val_only:
         return trainer.test(0, _test_tuples(test_loader))
     for epoch in range(logger.state['epoch'] + 1, args.n_epochs + 1):

@@ -65,7 +65,9 @@ def main():
     import torch.distributed as dist
     pkg = importlib.import_module(PKG_NAME)
     ops = pkg.ops
-    rank, world, local_rank = pkg.dist.init_from_env()
+    # The process group is joined only AFTER the model, the optimizer buffers and one step's worth of activations have been allocated
+    # (Trainer.warm_memory): memory first allocated once an RCCL communicator exists is slower for the kernels.
+    world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     if world != opt.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 under torch.distributed.run)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -99,6 +101,12 @@ def main():
             _i[0] += 1
             return inner_step(trainer.gpu_augment(scratch, train=True), depth, cam, val)
         trainer.train_step = step_with_augmentation
+
+    if world > 1 or pkg.dist.FORCE_GROUP:
+        if not os.environ.get('P3D_EARLY_GROUP'):
+            trainer.warm_memory(*batches[0])
+        pkg.dist.init_from_env()
+        trainer.attach_reducer()
 
     def sync():
         if dist.is_initialized():

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Is the training step GPU-bound?  Host time to ENQUEUE K steps (no synchronisation) vs wall time until the GPU has finished them."""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module('3d-pose-estimation-with-previleged-information_amd')
+import bench  # noqa: E402
+
+late = bool(os.environ.get('P3D_LATE_INIT'))
+rank, world, local_rank = (0, 1, 0) if late else pkg.dist.init_from_env()
+torch.cuda.set_device(local_rank)
+args = pkg.opts.parse(['-model', 'resnet50'] + bench.FLAGS + (['-half_acc'] if '--half' in sys.argv else []))
+model = pkg.depth_main.create_model(args)[0].cuda().train()
+tr = pkg.depth_train.Trainer(args, model, pkg.utils.get_info())
+tr.verbose = False
+tr.adapt_learn_rate(1)
+c, d, tc, tv = pkg.synth.make_batch(64, side=256, rank=0, step=0)
+b = [torch.from_numpy(a).cuda() for a in (c, tc, tv)]
+for _ in range(5):
+    tr.train_step(b[0], None, b[1], b[2])
+torch.cuda.synchronize()
+if late:
+    pkg.dist.init_from_env()
+    for _ in range(3):
+        tr.train_step(b[0], None, b[1], b[2])
+    torch.cuda.synchronize()
+K = 20
+t0 = time.perf_counter()
+for _ in range(K):
+    tr.train_step(b[0], None, b[1], b[2])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('world %d  dist %s: host enqueue %.2f ms/step, wall %.2f ms/step' % (world, torch.distributed.is_initialized(), (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
