@@ -94,3 +94,24 @@ def test_legacy_resnet_forward(pkg):
     z_cam, z_mat = z_cam.cpu().numpy(), z_mat.cpu().numpy()
     assert np.abs(z_cam[0, :, 3, 5] - g['z_cam_slice']).max() < 1e-3 * np.abs(g['z_cam_slice']).max()
     assert np.abs(z_mat[1, :, 7, 2] - g['z_mat_slice']).max() < 1e-3 * np.abs(g['z_mat_slice']).max()
+
+
+def test_training_is_bitwise_reproducible(pkg):
+    """Two runs of the same two steps give bit-identical parameters, BatchNorm statistics and loss: split-K slabs, BN partial sums and the
+    gradient norm are combined in a fixed order (no floating-point atomics), and the second HIP stream only changes WHEN kernels run."""
+    g = np.load(golden_path('step_depth_r18_b2.npz'))
+    meta = json.loads(str(g['meta']))
+    outs = []
+    for run in range(2):
+        args, model, trainer = build(pkg, meta)
+        model.train()
+        trainer.adapt_learn_rate(1)
+        losses = []
+        for it in range(2):
+            c, d, tc, tv = pkg.synth.make_batch(4, side=meta['side'], rank=0, step=it)
+            losses.append(float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda())))
+        torch.cuda.synchronize()
+        outs.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
