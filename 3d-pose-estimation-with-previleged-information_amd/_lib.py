@@ -55,6 +55,7 @@ SIGNATURES = {
     'p3d_pose_loss_fwd_bwd': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _f32, _i32, _f32, _ptr, _ptr]),
     'p3d_l2norm_sq_accum': (_i32, [_ptr, _i64, _ptr, _ptr]),
     'p3d_adam_step': (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _ptr, _f32, _ptr]),
+    'p3d_adam_step_dev': (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _f32, _ptr, _f32, _i32, _ptr, _ptr]),
     'p3d_distill_workspace_bytes': (_sz, [_i32]),
     'p3d_distill_fwd_bwd': (_i32, [_ptr] * 5 + [_i32, _i32, _i32, _i32, _f32, _ptr, _sz, _ptr]),
     'p3d_augment_colour': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr]),

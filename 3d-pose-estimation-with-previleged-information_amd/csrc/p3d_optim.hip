@@ -84,6 +84,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Device-resident variant for -half_acc (depth_train.py:431-446): the step counter, the overflow test and the skip decision live on the
+// GPU, so the host never reads the gradient norm back.  state[0] = number of optimizer steps taken, state[1] = steps skipped.
+struct AdamDev { float lr_over_bc1, inv_sqrt_bc2, coef; int skip; };
+
+__global__ void adam_prepare_kernel(const double* __restrict__ norm_sq, int* __restrict__ state, AdamDev* __restrict__ out, float lr, float beta1,
+                                    float beta2, float max_norm, float grad_scale, int skip_nonfinite) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ns = norm_sq ? *norm_sq : 0.0;
+    if (skip_nonfinite && !isfinite(ns)) {                    // an fp16 gradient overflowed: leave weights, moments and the counter alone
+        out->skip = 1;
+        state[1] += 1;
+        return;
+    }
+    const int step = ++state[0];
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out->lr_over_bc1 = (float)((double)lr / bc1);
+    out->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    float coef = grad_scale;
+    if (norm_sq != nullptr && max_norm > 0.f) {
+        const float total = (float)sqrt(ns) * grad_scale;
+        coef = fminf(max_norm / (total + 1e-6f), 1.f) * grad_scale;
+    }
+    out->coef = coef;
+    out->skip = 0;
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       size_t n, AdamArgs a, const AdamDev* __restrict__ h) {
+    if (h->skip) return;
+    a.lr_over_bc1 = h->lr_over_bc1;
+    a.inv_sqrt_bc2 = h->inv_sqrt_bc2;
+    const float coef = h->coef;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) adam_one(p[i], g[i], m[i], v[i], a, coef);
+}
+
 // ---------------------------------------------------------------------------------------------
 // colour augmentation on planar float images holding 0..255 values (the reference works on HWC uint8).
 // OpenCV float conventions: H in [0,360), S and V in [0,1].
@@ -248,6 +284,20 @@ int32_t p3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, f
     else
         hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, a, norm_sq);
     return check_launch("adam_step");
+}
+
+int32_t p3d_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int32_t* state, float max_norm, const double* norm_sq, float grad_scale,
+                          int32_t skip_nonfinite, void* scratch16, void* stream) {
+    P3D_REQUIRE(p && g && m && v && n > 0 && state && scratch16, "adam_step_dev: bad argument");
+    static_assert(sizeof(AdamDev) == 16, "scratch layout");
+    AdamArgs a = {};
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.max_norm = max_norm; a.grad_scale = grad_scale;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, norm_sq, state, (AdamDev*)scratch16, lr, beta1, beta2, max_norm,
+                       grad_scale, skip_nonfinite);
+    const unsigned blocks = (unsigned)(ceil_div(n, 1024) < 2048 ? ceil_div(n, 1024) : 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, a, (const AdamDev*)scratch16);
+    return check_launch("adam_step_dev");
 }
 
 int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream) {

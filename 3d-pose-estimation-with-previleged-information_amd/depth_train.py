@@ -82,7 +82,6 @@ class Trainer:
 
         self.half_acc = bool(args.half_acc)
         self.grad_scaling = args.grad_scaling
-        self.skipped_steps = 0
         self.depth_only = args.depth_only
         self.do_fusion = args.do_fusion
         self.do_teach = args.do_teach
@@ -137,6 +136,11 @@ class Trainer:
         self.sync_every = 1                                 # read the loss back every k iterations (reference: every one)
         self.last_spec_cam = None
 
+    @property
+    def skipped_steps(self):
+        """-half_acc: optimizer steps dropped because a gradient overflowed (device counter; reading it synchronises)."""
+        return self.optimizer.steps_skipped()
+
     # ---- process-group ordering ----------------------------------------------------------------
     def warm_memory(self, color_image, depth_image, true_cam, true_val):
         """One forward + backward WITHOUT an optimizer step and with the BatchNorm buffers restored afterwards: it only makes the
@@ -144,11 +148,13 @@ class Trainer:
         after an RCCL communicator exists is measurably slower for the kernels (+4 % step time on MI355X / ROCm 7.2), so a launcher
         calls this BEFORE dist.init_from_env() and attach_reducer() after it (bench.py, depth_main.main)."""
         saved = {k: v.clone() for k, v in self.model.state_dict().items() if 'running_' in k or 'num_batches_tracked' in k}
-        step, self.optimizer.clip_and_step = self.optimizer.clip_and_step, (lambda *a, **k: True)
+        opt = self.optimizer
+        keep = (opt.clip_and_step, opt.clip_and_step_dev)
+        opt.clip_and_step = opt.clip_and_step_dev = (lambda *a, **k: True)
         try:
             self.train_step(color_image, depth_image, true_cam, true_val)
         finally:
-            self.optimizer.clip_and_step = step
+            opt.clip_and_step, opt.clip_and_step_dev = keep
         self.optimizer.zero_grad()
         with torch.no_grad():
             state = self.model.state_dict()
@@ -211,12 +217,9 @@ class Trainer:
             loss.backward(torch.full_like(loss, self.grad_scaling))
             assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
             scale = self.reducer.finish()
-            if self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True):
-                ops_half.refresh_weights(self.model, self.optimizer.flat_p)
-            else:
-                self.skipped_steps += 1
-                if self.verbose:
-                    print('update step skipped')
+            # overflow test, skip decision and step counter stay on the device (FlatAdam.clip_and_step_dev): no host read-back per step
+            self.optimizer.clip_and_step_dev(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True)
+            ops_half.refresh_weights(self.model, self.optimizer.flat_p)          # (a skipped step re-casts unchanged weights)
             return loss.detach()
         loss.backward()
         assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'

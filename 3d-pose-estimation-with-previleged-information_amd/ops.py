@@ -571,6 +571,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.
                               _p(norm_sq), float(grad_scale), _stream()), 'p3d_adam_step')
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, weight_decay, state, max_norm, norm_sq, grad_scale, skip_nonfinite, scratch):
+    """Adam with the step counter / overflow skip on the device (state: int32[2] = steps taken, steps skipped)."""
+    check(lib().p3d_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, _p(state), float(max_norm),
+                                  _p(norm_sq), float(grad_scale), int(skip_nonfinite), _p(scratch), _stream()), 'p3d_adam_step_dev')
+
+
 def augment_colour_(img, params):
     """In place on img [B,3,H,W] holding 0..255 values; params [B,4] (augment_colour.py:48-67)."""
     _need_gpu(img, params)

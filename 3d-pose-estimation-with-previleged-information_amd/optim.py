@@ -56,6 +56,8 @@ class FlatAdam:
         self.param_groups = [dict(lr=lr), dict(lr=lr)]
         self.step_count = 0
         self.norm_sq = torch.zeros(1, dtype=torch.float64, device=device)
+        self.dev_state = None            # int32[2] on the device (steps taken, steps skipped) once clip_and_step_dev has been used
+        self._dev_scratch = None
 
     def slices(self):
         """(name, offset, numel) per parameter, in registration order."""
@@ -82,6 +84,25 @@ class FlatAdam:
                       self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
         return True
 
+    def clip_and_step_dev(self, max_norm, grad_scale=1.0, skip_nonfinite=True):
+        """clip + Adam with the step counter and the overflow-skip decision on the device (-half_acc, depth_train.py:431-446):
+        nothing is read back, so the host keeps running ahead of the GPU.  `steps_taken()` / `steps_skipped()` synchronise."""
+        if self.dev_state is None:
+            self.dev_state = torch.tensor([self.step_count, 0], dtype=torch.int32, device=self.flat_p.device)
+            self._dev_scratch = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
+        self.norm_sq.zero_()
+        ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
+        ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0], self.betas[1],
+                          self.eps, self.weight_decay, self.dev_state, max_norm or 0.0, self.norm_sq, grad_scale, skip_nonfinite, self._dev_scratch)
+
+    def steps_taken(self):
+        if self.dev_state is not None:
+            self.step_count = int(self.dev_state[0].item())
+        return self.step_count
+
+    def steps_skipped(self):
+        return int(self.dev_state[1].item()) if self.dev_state is not None else 0
+
     def step(self):
         self.clip_and_step(0.0)
 
@@ -90,9 +111,10 @@ class FlatAdam:
         return float(self.norm_sq.item()) ** 0.5 * grad_scale
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names, offsets=self.offsets)
+        return dict(step=self.steps_taken(), exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.names, offsets=self.offsets)
 
     def load_state_dict(self, state):
         self.step_count = int(state['step'])
+        self.dev_state = None
         self.exp_avg.copy_(state['exp_avg'])
         self.exp_avg_sq.copy_(state['exp_avg_sq'])

@@ -168,6 +168,14 @@ int32_t p3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, f
                       float eps, float weight_decay, int32_t step, float max_norm, const double* norm_sq,
                       float grad_scale, void* stream);
 
+/* The same update with the step counter and the -half_acc overflow rule (depth_train.py:431-446) resident on the device:
+ * state[0] = optimizer steps taken (incremented by this call unless it skips), state[1] = steps skipped; with skip_nonfinite != 0
+ * a non-finite *norm_sq leaves weights, moments and state[0] untouched and increments state[1].  No host read-back anywhere.
+ * scratch16: 16 bytes of device memory for the constants handed from the one-thread prepare kernel to the update kernel. */
+int32_t p3d_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int32_t* state, float max_norm, const double* norm_sq,
+                          float grad_scale, int32_t skip_nonfinite, void* scratch16, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Feature distillation loss, teacher -> student: Trainer.distill (depth_train.py:115-129).
  * teach, student [B,C,H,W]; atten [B,1,H,W].  mode 0: mean_b ||(t-s)*a||_2;  1: the same on sigmoid(t)-sigmoid(s) (-sigmoid);
