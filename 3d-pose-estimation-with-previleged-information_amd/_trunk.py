@@ -135,7 +135,10 @@ def normal_fan_out_(module):
 def _tick_batchnorm(module, inputs):
     """Forward pre-hook of the whole network: one multi-tensor add bumps `num_batches_tracked` of every BatchNorm2d in training
     mode (53 one-element launches per ResNet-50 step otherwise); each layer then skips its own increment for this call."""
-    layers = [m for m in module.modules() if isinstance(m, BatchNorm2d) and m.training and m.num_batches_tracked.is_cuda]
+    cache = module.__dict__.get('_bn_layers')
+    if cache is None:                                   # (the module tree of these networks is fixed after construction)
+        cache = module.__dict__['_bn_layers'] = [m for m in module.modules() if isinstance(m, BatchNorm2d)]
+    layers = [m for m in cache if m.training and m.num_batches_tracked.is_cuda]
     if layers:
         torch._foreach_add_([m.num_batches_tracked for m in layers], 1)
         for m in layers:

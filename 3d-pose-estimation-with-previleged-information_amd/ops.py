@@ -29,7 +29,8 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of the current HIP stream of the current device (the C fast path: this runs once per kernel launch)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 _workspaces = {}
