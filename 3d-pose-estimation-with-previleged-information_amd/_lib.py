@@ -62,10 +62,11 @@ SIGNATURES = {
     'p3d_augment_erase': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_normalize_rgb': (_i32, [_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _ptr]),
-    'p3d_hconv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    'p3d_hconv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_hconv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_hscale_pixels': (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
+    'p3d_hconv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'p3d_hconv2d_wgrad_workspace_bytes': (_sz, [_desc]),
-    'p3d_hconv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _i32, _f32, _ptr, _sz, _ptr]),
+    'p3d_hconv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _i32, _f32, _ptr, _sz, _ptr]),
     'p3d_hconv2d_bgrad': (_i32, [_ptr, _i32, _i32, _ptr, _f32, _i32, _ptr]),
     'p3d_nchw_f32_to_nhwc_f16': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_nhwc_f16_to_nchw_f32': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _f32, _ptr]),

@@ -53,6 +53,8 @@ struct HGatherParams {
     int ncw;                  // classes along w (forward: 1)
     int tiles_m;
     int accumulate;           // D += result (a dgrad joining the gradient of a second consumer of its input)
+    const float* bmask;       // partial conv: {0,1} mask over the pixels of B ([N][Hb][Wb]); a masked pixel contributes 0.  or null
+    const float* dscale;      // partial conv: per-pixel factor of the result ([N][Hd][Wd]): mult (forward) / mask_in (dgrad).  or null
     int Hc[HMS], Wc[HMS];
     int r0[HMS], rstep[HMS], nr[HMS], hadd[HMS], hstep[HMS];
     int s0[HMS], sstep[HMS], ns[HMS], wadd[HMS], wstep[HMS];
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
     const int nk = (nchunks + CH - 1) / CH;
 
     const i32x4 rA = hmake_rsrc(p.A, p.a_bytes), rB = hmake_rsrc(p.B, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rMask = __builtin_amdgcn_make_buffer_rsrc((void*)p.bmask, 0, p.bmask ? p.N * p.Hb * p.Wb * 4 : 0, 0x00020000);
 
     // ---- this thread's tile rows: weight row / pixel (t / CH) + RSTEP * i, chunk j = t % CH of every K-step ----
     const int j = t % CH, row0 = t / CH;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
     int ir = tl / ns, is = tl - ir * ns;
 
     f32x4 ra[PER], rb[PER];
+    float rm[PER];
     auto fetch = [&]() {
         const bool live = tl < ntaps;
         const int wtap = (p.r0[ph] + p.rstep[ph] * ir) * p.Sw + p.s0[pw] + p.sstep[pw] * is;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             const bool ok = live && b_img[i] >= 0 && (unsigned)hb < (unsigned)p.Hb && (unsigned)wb < (unsigned)p.Wb;
             const int off = ((b_img[i] + hb * p.Wb + wb) * p.Kc + c8 * 8) * 2;
             rb[i] = hbuf_load16(rB, ok ? off : HOOB, 0, 0);
+            if (p.bmask) rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rMask, ok ? (b_img[i] + hb * p.Wb + wb) * 4 : HOOB, 0, 0));
         }
         c8 += CH;                                              // advance to the next K-step
         while (c8 >= C8) {
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             *reinterpret_cast<f32x4*>(As + (size_t)(buf * BM + row0 + RSTEP * i) * ROWB + j * 16) = ra[i];
+            if (p.bmask && rm[i] == 0.f) rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};          // x * mask with a {0,1} mask: keep or drop the pixel
             *reinterpret_cast<f32x4*>(Bs + (size_t)(buf * BN + row0 + RSTEP * i) * ROWB + j * 16) = rb[i];
         }
     };
@@ -183,7 +189,9 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
         if (n >= ncols) continue;
         const int img = n / (Hc * Wc), rem = n - img * (Hc * Wc);
         const int ii = rem / Wc, jj = rem - ii * Wc;
-        _Float16* dst = p.D + ((size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw) * p.M;
+        const size_t dpix = (size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw;
+        _Float16* dst = p.D + dpix * p.M;
+        const float dsc = p.dscale ? p.dscale[dpix] : 1.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -193,14 +201,14 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
                 h4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[a][b][4 * g + e];
+                    float v = acc[a][b][4 * g + e] * dsc;
                     if (p.bias) v += p.bias[ch + e];
                     o[e] = (_Float16)v;
                 }
                 if (p.accumulate) {
                     const h4 old = *reinterpret_cast<const h4*>(dst + ch);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)((float)old[e] + acc[a][b][4 * g + e]);
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)((float)old[e] + acc[a][b][4 * g + e] * dsc);
                 }
                 *reinterpret_cast<h4*>(dst + ch) = o;
             }
@@ -212,6 +220,7 @@ struct HWgradParams {
     const _Float16* dy;       // [N][Ho][Wo][K]
     const _Float16* x;        // [N][H][W][C]
     float* slab;              // [splits][K][RS * C]
+    const float* xmask;       // partial conv: {0,1} mask over the pixels of x ([N][H][W]), or null (dy comes pre-scaled by mult)
     size_t dy_bytes, x_bytes;
     int N, C, H, W, K, R, S, stride, pad, dil, Ho, Wo;
     int kchunk;               // pixels per split (multiple of 32)
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
     const int nk = (k_end - k_begin + BKP - 1) / BKP;
 
     const i32x4 rA = hmake_rsrc(p.dy, p.dy_bytes), rB = hmake_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rMask = __builtin_amdgcn_make_buffer_rsrc((void*)p.xmask, 0, p.xmask ? p.N * p.H * p.W * 4 : 0, 0x00020000);
 
     // this thread: chunk t & 15 of pixel rows (t >> 4) and (t >> 4) + 16 of every K-step
     const int ch = t & 15, prow = t >> 4;
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
         ho[i] = rem / p.Wo; wo[i] = rem - ho[i] * p.Wo;
     }
     f32x4 ra[2], rb[2];
+    float rm[2];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -266,6 +277,7 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
             const int hi = ho[i] * p.stride - p.pad + tr * p.dil, wi = wo[i] * p.stride - p.pad + ts * p.dil;
             const bool ok = live && b_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             rb[i] = hbuf_load16(rB, ok ? (((img[i] * p.H + hi) * p.W + wi) * p.C + c8 * 8) * 2 : HOOB, 0, 0);
+            if (p.xmask) rm[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rMask, ok ? ((img[i] * p.H + hi) * p.W + wi) * 4 : HOOB, 0, 0));
             wo[i] += BKP;                                       // the pixel this slot holds in the next K-step
             while (wo[i] >= p.Wo) { wo[i] -= p.Wo; if (++ho[i] == p.Ho) { ho[i] = 0; ++img[i]; } }
         }
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
         for (int i = 0; i < 2; ++i) {
             const int row = prow + 16 * i;
             *reinterpret_cast<f32x4*>(As + buf * BKP * 256 + tr_off(row, ch)) = ra[i];
+            if (p.xmask && rm[i] == 0.f) rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(Bs + buf * BKP * 256 + tr_off(row, ch)) = rb[i];
         }
     };
@@ -367,6 +380,20 @@ __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restr
             }
         }
         __syncthreads();
+    }
+}
+
+// dst[p][c] = src[p][c] * scale[p]  (dy * mult of a partial conv's backward: done once, read by dgrad and wgrad), fp32 arithmetic
+__global__ __launch_bounds__(256) void hscale_pixels_kernel(const _Float16* __restrict__ src, const float* __restrict__ scale, _Float16* __restrict__ dst,
+                                                            size_t P, int G) {
+    const size_t total = P * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float sc = scale[i / G];
+        const h8 v = *reinterpret_cast<const h8*>(src + i * 8);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)v[e] * sc);
+        *reinterpret_cast<h8*>(dst + i * 8) = o;
     }
 }
 
@@ -496,11 +523,13 @@ using namespace p3d;
 
 extern "C" {
 
-int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krsc, const float* bias, void* y, void* stream) {
+int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krsc, const float* bias, const float* mask_in, const float* mult, void* y,
+                        void* stream) {
     if (int32_t e = hvalidate(d, "hconv2d_fwd")) return e;
     P3D_REQUIRE(x && w_krsc && y, "hconv2d_fwd: null tensor");
     HGatherParams p = {};
     p.A = (const _Float16*)w_krsc; p.B = (const _Float16*)x; p.D = (_Float16*)y; p.bias = bias;
+    p.bmask = mask_in; p.dscale = mult;
     p.a_bytes = (size_t)d->K * d->R * d->S * d->C * 2; p.b_bytes = (size_t)d->N * d->H * d->W * d->C * 2;
     p.M = d->K; p.Kc = d->C; p.RSw = d->R * d->S; p.Sw = d->S;
     p.N = d->N; p.Hb = d->H; p.Wb = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
@@ -514,11 +543,12 @@ int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krs
 }
 
 /* dx[n][hi][wi][c] = sum_{k,r,s} dy[n][ho][wo][k] * w[k][r][s][c]; w_crsk is the [C][R][S][K] weight image */
-int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_crsk, void* dx, void* stream) {
+int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_crsk, const float* mask_in, void* dx, void* stream) {
     if (int32_t e = hvalidate(d, "hconv2d_dgrad")) return e;
     P3D_REQUIRE(dy && w_crsk && dx, "hconv2d_dgrad: null tensor");
     HGatherParams p = {};
     p.A = (const _Float16*)w_crsk; p.B = (const _Float16*)dy; p.D = (_Float16*)dx; p.bias = nullptr;
+    p.bmask = nullptr; p.dscale = mask_in;
     p.a_bytes = (size_t)d->K * d->R * d->S * d->C * 2; p.b_bytes = (size_t)d->N * d->Ho * d->Wo * d->K * 2;
     p.M = d->C; p.Kc = d->K; p.RSw = d->R * d->S; p.Sw = d->S;
     p.N = d->N; p.Hb = d->Ho; p.Wb = d->Wo; p.Hd = d->H; p.Wd = d->W;
@@ -565,7 +595,7 @@ size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d) {
 
 /* dw (fp32, [K][c_real][R][S], the master gradient) (+)= scale * conv_wgrad(dy, x).  d->C is the padded channel count of x;
  * c_real <= d->C the channels that exist in the master weight (stem: 3 of 8). */
-int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x, float* dw, int32_t c_real, float scale,
+int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x, const float* mask_in, float* dw, int32_t c_real, float scale,
                           void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = hvalidate(d, "hconv2d_wgrad")) return e;
     P3D_REQUIRE(dy && x && dw && c_real > 0 && c_real <= d->C, "hconv2d_wgrad: bad argument");
@@ -577,7 +607,7 @@ int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x,
         return P3D_EWORKSPACE;
     }
     HWgradParams p = {};
-    p.dy = (const _Float16*)dy; p.x = (const _Float16*)x; p.slab = (float*)workspace;
+    p.dy = (const _Float16*)dy; p.x = (const _Float16*)x; p.slab = (float*)workspace; p.xmask = mask_in;
     p.dy_bytes = (size_t)d->N * d->Ho * d->Wo * d->K * 2; p.x_bytes = (size_t)d->N * d->H * d->W * d->C * 2;
     p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.K = d->K; p.R = d->R; p.S = d->S;
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -591,6 +621,14 @@ int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x,
     hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw, d->K, d->C, c_real,
                        d->R * d->S, splits, scale, d->accumulate);
     return check_launch("hconv2d_wgrad reduce");
+}
+
+int32_t p3d_hscale_pixels(const void* src, const float* scale, void* dst, int64_t P, int32_t C, void* stream) {
+    P3D_REQUIRE(src && scale && dst && P > 0 && C > 0 && C % 8 == 0, "hscale_pixels: bad argument");
+    const int64_t total = P * (C / 8);
+    const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(hscale_pixels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, scale, (_Float16*)dst, (size_t)P, C / 8);
+    return check_launch("hscale_pixels");
 }
 
 int32_t p3d_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t N, int32_t C, int32_t HW, int32_t Cpad, float scale, void* stream) {

@@ -70,9 +70,9 @@ def to_test_worker(test_loader, no_depth, depth_only, do_fusion=False):
 class Trainer:
 
     def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
-        if args.half_acc and (args.partial_conv or args.do_teach or args.skip_relu):
-            raise NotImplementedError('-half_acc is implemented for the dense networks (depthnet / resnet / fusionnet); the partial-conv '
-                                      'and distillation variants run in fp32')
+        if args.half_acc and (args.do_teach or args.skip_relu):
+            raise NotImplementedError('-half_acc is implemented for the training paths of depthnet / resnet / fusionnet / partial_depthnet; '
+                                      'distillation runs in fp32')
         if args.semi_teach and not args.do_teach:
             raise ValueError('-semi_teach adds unlabelled pairs to the distillation loss: it needs -do_teach')
         self.model = model

@@ -147,9 +147,9 @@ def refresh_weights(model, flat=None):
 class HConv2dFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, w, bias, images, stride, pad, dil, join_put=None, join_take=None):
+    def forward(ctx, x, w, bias, images, stride, pad, dil, join_put=None, join_take=None, mask_in=None, mult=None):
         _need_half(x)
-        ops._need_gpu(w, bias)
+        ops._need_gpu(w, bias, mask_in, mult)
         x = _cl(x)
         n, c, h, wd = x.shape
         k, _, r, s = w.shape
@@ -158,8 +158,8 @@ class HConv2dFn(torch.autograd.Function):
         d = _desc((n, c, h, wd), (k, c, r, s), stride, pad, dil)
         y = _empty(n, k, d.Ho, d.Wo, x.device)
         with ops._Timed('fwd', d):
-            check(lib().p3d_hconv2d_fwd(ctypes.byref(d), _p(x), _p(images.krsc), _p(bias), _p(y), _stream()), 'p3d_hconv2d_fwd')
-        ctx.save_for_backward(x)
+            check(lib().p3d_hconv2d_fwd(ctypes.byref(d), _p(x), _p(images.krsc), _p(bias), _p(mask_in), _p(mult), _p(y), _stream()), 'p3d_hconv2d_fwd')
+        ctx.save_for_backward(x, mask_in, mult)
         ctx.cfg = (stride, pad, dil, tuple(w.shape))
         ctx.params = (w, bias)
         ctx.images = images
@@ -168,7 +168,7 @@ class HConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, mask_in, mult = ctx.saved_tensors
         stride, pad, dil, wshape = ctx.cfg
         w_param, b_param = ctx.params
         images = ctx.images
@@ -178,6 +178,10 @@ class HConv2dFn(torch.autograd.Function):
         d = _desc((n, c, h, wd), (k, c, r, s), stride, pad, dil)
         L, st = lib(), _stream()
         dx = dw = db = None
+        if mult is not None:                                 # partial conv: dy * mult once, read by dgrad and wgrad (partial_conv.py:53)
+            scaled = torch.empty_like(dy, memory_format=CL)
+            check(L.p3d_hscale_pixels(_p(dy), _p(mult), _p(scaled), n * d.Ho * d.Wo, k, st), 'p3d_hscale_pixels')
+            dy = scaled
         if ctx.needs_input_grad[0]:
             if images.crsk is None:
                 raise P3DError('hconv2d: this layer was built without a dgrad weight image')
@@ -189,7 +193,7 @@ class HConv2dFn(torch.autograd.Function):
             else:
                 dx = _empty(n, c, h, wd, x.device)
             with ops._Timed('dgrad', d):
-                check(L.p3d_hconv2d_dgrad(ctypes.byref(d), _p(dy), _p(images.crsk), _p(dx), st), 'p3d_hconv2d_dgrad')
+                check(L.p3d_hconv2d_dgrad(ctypes.byref(d), _p(dy), _p(images.crsk), _p(mask_in), _p(dx), st), 'p3d_hconv2d_dgrad')
             d.accumulate = 0
             if join_put is not None:
                 join_put.buf, dx = dx, None
@@ -205,14 +209,15 @@ class HConv2dFn(torch.autograd.Function):
                 ws = ops._side_workspace(x.device, nbytes)
                 with torch.cuda.stream(side):
                     with ops._Timed('wgrad', d):
-                        check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), _stream()),
+                        check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mask_in), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), _stream()),
                               'p3d_hconv2d_wgrad')
-                dy.record_stream(side)
-                x.record_stream(side)
+                for t in (dy, x, mask_in):
+                    if t is not None:
+                        t.record_stream(side)
             else:
                 ws = workspace(x.device, nbytes)
                 with ops._Timed('wgrad', d):
-                    check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), st), 'p3d_hconv2d_wgrad')
+                    check(L.p3d_hconv2d_wgrad(ctypes.byref(d), _p(dy), _p(x), _p(mask_in), _p(dw), images.c_real, 1.0, _p(ws), ws.numel(), st), 'p3d_hconv2d_wgrad')
             d.accumulate = 0
             if sink is not None:
                 dw = None
@@ -224,14 +229,14 @@ class HConv2dFn(torch.autograd.Function):
             if sink is not None:
                 db = None
                 _grad_done(b_param)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, module, stride, pad, dil, join_put=None, join_take=None):
+def conv2d(x, module, stride, pad, dil, join_put=None, join_take=None, mask_in=None, mult=None):
     images = getattr(module, '_h_images', None)
     if images is None:
         raise P3DError('fp16 convolution without weight images: call ops_half.refresh_weights(model) first')
-    return HConv2dFn.apply(x, module.weight, module.bias, images, stride, pad, dil, join_put, join_take)
+    return HConv2dFn.apply(x, module.weight, module.bias, images, stride, pad, dil, join_put, join_take, mask_in, mult)
 
 
 class HBatchNormActFn(torch.autograd.Function):

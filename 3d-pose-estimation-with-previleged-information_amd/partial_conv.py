@@ -29,7 +29,11 @@ class PartialConv(Conv2d):
             mult, mask_out = ops.mask_count(mask_in, k, stride, pad, dil)    # partial_conv.py:35-43
         if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled():
             raise ops.P3DError('PartialConv with a trainable bias: backward is not implemented (no reference network uses it)')
-        output = ops.conv2d(input, self.weight, self.bias, stride, pad, dil, mask_in=mask_in, mult=mult, join_put=join_put, join_take=join_take)
+        if input.dtype == torch.float16:                                    # -half_acc: masks stay fp32 [B,1,H,W], activations NHWC fp16
+            from . import ops_half
+            output = ops_half.conv2d(input, self, stride, pad, dil, join_put, join_take, mask_in=mask_in.contiguous(), mult=mult)
+        else:
+            output = ops.conv2d(input, self.weight, self.bias, stride, pad, dil, mask_in=mask_in, mult=mult, join_put=join_put, join_take=join_take)
         if self.return_mask:
             return output, mask_out
         return output

@@ -34,8 +34,8 @@ class ResNet(TrunkBase):
 
     def forward(self, x):
         with torch.no_grad():
-            veil = ops.nonzero_mask(x)
-        x, veil = self.conv1(x, veil)
+            veil = ops.nonzero_mask(x)                       # fp32 [B,1,H,W] in both precisions
+        x, veil = self.conv1(self._half_in(x), veil)
         x = self.maxpool(self.bn1(x, relu=True))
         with torch.no_grad():
             veil = self.maxpool(veil)
@@ -44,7 +44,7 @@ class ResNet(TrunkBase):
         x = self.layer3(x)
         x = self.layer4(x)
         z = self.regressor(x)
-        return z, x
+        return self._half_out(z, x)
 
 
 def build_resnet(block, layers, args, pretrain):

@@ -213,12 +213,17 @@ int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3,
  * The descriptor is the fp32 one; d->C is the (padded) channel count of x.  Replaces the cuDNN half kernels behind
  * nn.Conv2d after model.half() (depthnet.py:16-33,65-89).
  * ------------------------------------------------------------------------------------------ */
-int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x_nhwc, const void* w_krsc, const float* bias, void* y_nhwc, void* stream);
+/* Partial conv (partial_conv.py:32-57): mask_in [N][H][W] fp32 {0,1} drops masked input pixels in the operand fetch, mult [N][Ho][Wo]
+ * scales the result; both may be NULL.  Backward: the caller scales dy by mult once (p3d_hscale_pixels) and passes that tensor to
+ * dgrad (mask_in then multiplies dx) and wgrad (mask_in masks x). */
+int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x_nhwc, const void* w_krsc, const float* bias, const float* mask_in,
+                        const float* mult, void* y_nhwc, void* stream);
+int32_t p3d_hscale_pixels(const void* src_nhwc, const float* scale, void* dst_nhwc, int64_t P, int32_t C, void* stream);
 /* d->accumulate != 0: dx += result (joins the gradient another consumer of the same input already wrote) */
-int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, void* dx_nhwc, void* stream);
+int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, const float* mask_in, void* dx_nhwc, void* stream);
 size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 /* dw (fp32 master gradient [K][c_real][R][S]) = (d->accumulate ? dw : 0) + scale * wgrad; c_real <= d->C (stem: 3 of 8) */
-int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* x_nhwc, float* dw, int32_t c_real, float scale,
+int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* x_nhwc, const float* mask_in, float* dw, int32_t c_real, float scale,
                           void* workspace, size_t workspace_bytes, void* stream);
 /* db[K] (fp32) = (accumulate ? db : 0) + scale * sum over the P pixels of dy[P][K] */
 int32_t p3d_hconv2d_bgrad(const void* dy_nhwc, int32_t P, int32_t K, float* db, float scale, int32_t accumulate, void* stream);

@@ -145,6 +145,7 @@ STEP_CASES = {
     # -half_acc: model.half() + fp32 copy_params + static loss scale (depth_train.py:73-83,413-449), on the CPU half kernels of torch
     'half_r18_b2': ('depthnet', 'resnet18', 256, 2, 2, 0.0, ['-half_acc']),
     'half_fusion_r18_b2': ('fusionnet', 'resnet18', 256, 2, 1, 0.0, ['-do_fusion', '-half_acc']),
+    'half_partial_r18_b2': ('partial_depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only', '-partial_conv', '-half_acc']),
 }
 
 

@@ -73,12 +73,12 @@ def test_hconv_fwd_dgrad_wgrad(case, pkg):
     assert np.array_equal(crsk.float().cpu().numpy()[:c], wt.transpose(1, 2, 3, 0))
     bt = torch.from_numpy(bias).cuda()
     y = torch.empty(n, d.Ho, d.Wo, k, dtype=torch.float16, device='cuda')
-    pkg._lib.check(L.p3d_hconv2d_fwd(ctypes.byref(d), p(xt), p(krsc), p(bt), p(y), stream), 'fwd')
+    pkg._lib.check(L.p3d_hconv2d_fwd(ctypes.byref(d), p(xt), p(krsc), p(bt), None, None, p(y), stream), 'fwd')
     assert relerr(nchw32(y), y_ref) < 1.5e-3
     # dgrad
     dx_ref = ref.conv2d_dgrad(dy, wt, x.shape, st, pad, dil)
     dx = torch.full((n, h, w, cpad), float('nan'), dtype=torch.float16, device='cuda')
-    pkg._lib.check(L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dyt), p(crsk), p(dx), stream), 'dgrad')
+    pkg._lib.check(L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dyt), p(crsk), None, p(dx), stream), 'dgrad')
     got = nchw32(dx)
     assert np.isfinite(got).all()
     assert relerr(got[:, :c], dx_ref) < 1.5e-3
@@ -89,11 +89,50 @@ def test_hconv_fwd_dgrad_wgrad(case, pkg):
     dw = torch.from_numpy(base.copy()).cuda()
     ws = torch.empty(max(L.p3d_hconv2d_wgrad_workspace_bytes(ctypes.byref(d)), 16), dtype=torch.uint8, device='cuda')
     d.accumulate = 1
-    pkg._lib.check(L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dyt), p(xt), p(dw), c, 0.5, p(ws), ws.numel(), stream), 'wgrad')
+    pkg._lib.check(L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dyt), p(xt), None, p(dw), c, 0.5, p(ws), ws.numel(), stream), 'wgrad')
     assert relerr(dw.cpu().numpy() - base, 0.5 * dw_ref) < 2e-4
     d.accumulate = 0
-    pkg._lib.check(L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dyt), p(xt), p(dw), c, 1.0, p(ws), ws.numel(), stream), 'wgrad')
+    pkg._lib.check(L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dyt), p(xt), None, p(dw), c, 1.0, p(ws), ws.numel(), stream), 'wgrad')
     assert relerr(dw.cpu().numpy(), dw_ref) < 2e-5
+
+
+@pytest.mark.parametrize('case', [(2, 16, 20, 20, 64, 3, 1, 1, 1), (2, 8, 33, 31, 72, 3, 2, 1, 1), (2, 64, 16, 16, 128, 1, 1, 0, 1), (1, 1, 65, 63, 64, 7, 2, 3, 1)])
+def test_hconv_partial(case, pkg):
+    """Partial conv on the fp16 kernels (mask in the operand fetch, mult in the epilogue, pre-scaled dy in backward) against the
+    oracle's partial_conv_fwd / partial_conv_bwd on fp16-rounded operands."""
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    n, c, h, w, k, ks, st, pad, dil = case
+    rng = np.random.default_rng(n * 1000 + c * 10 + ks)
+    x = r16(rng.standard_normal((n, c, h, w)))
+    mask = (rng.random((n, 1, h, w)) > 0.4).astype(np.float32)
+    mask[0, 0, :6, :6] = 0                                             # an all-masked window
+    wt = r16(rng.standard_normal((k, c, ks, ks)) / np.sqrt(c * ks * ks))
+    cpad = (c + 7) // 8 * 8
+    y_ref, mask_out, mult = ref.partial_conv_fwd(x, mask, wt, None, st, pad, dil)
+    d = ops._desc((n, cpad, h, w), (k, cpad, ks, ks), st, pad, dil)
+    stream, p = ops._stream(), ops._p
+    xt = nhwc16(x, cpad)
+    krsc = torch.empty(k, ks, ks, cpad, dtype=torch.float16, device='cuda')
+    crsk = torch.empty(cpad, ks, ks, k, dtype=torch.float16, device='cuda')
+    pkg._lib.check(L.p3d_weight_images_f16(p(torch.from_numpy(wt).cuda()), p(krsc), p(crsk), k, c, ks * ks, cpad, stream), 'images')
+    mt, mu = torch.from_numpy(mask).cuda(), torch.from_numpy(np.ascontiguousarray(mult, dtype=np.float32)).cuda()
+    y = torch.empty(n, d.Ho, d.Wo, k, dtype=torch.float16, device='cuda')
+    pkg._lib.check(L.p3d_hconv2d_fwd(ctypes.byref(d), p(xt), p(krsc), None, p(mt), p(mu), p(y), stream), 'fwd')
+    assert relerr(nchw32(y), y_ref) < 2e-3
+    dy = r16(rng.standard_normal(y_ref.shape))
+    dx_ref, dw_ref = ref.partial_conv_bwd(dy, x, mask, wt, mult, st, pad, dil)[:2]
+    dyt = nhwc16(dy)
+    scaled = torch.empty_like(dyt)
+    pkg._lib.check(L.p3d_hscale_pixels(p(dyt), p(mu), p(scaled), n * d.Ho * d.Wo, k, stream), 'scale')
+    if c >= 8:
+        dx = torch.empty(n, h, w, cpad, dtype=torch.float16, device='cuda')
+        pkg._lib.check(L.p3d_hconv2d_dgrad(ctypes.byref(d), p(scaled), p(crsk), p(mt), p(dx), stream), 'dgrad')
+        assert relerr(nchw32(dx, c), dx_ref) < 3e-3
+    dw = torch.zeros(k, c, ks, ks, device='cuda')
+    ws = torch.empty(max(L.p3d_hconv2d_wgrad_workspace_bytes(ctypes.byref(d)), 16), dtype=torch.uint8, device='cuda')
+    pkg._lib.check(L.p3d_hconv2d_wgrad(ctypes.byref(d), p(scaled), p(xt), p(mt), p(dw), c, 1.0, p(ws), ws.numel(), stream), 'wgrad')
+    assert relerr(dw.cpu().numpy(), dw_ref) < 3e-3                     # dy * mult is rounded to fp16 once
 
 
 def test_layout_converters(pkg):
@@ -199,7 +238,7 @@ def test_hmaxpool(shape, pkg):
     assert np.abs(nchw32(dxt) - want).max() < 2e-3 * max(1.0, np.abs(want).max())
 
 
-@pytest.mark.parametrize('case', ['half_r18_b2', 'half_fusion_r18_b2'])
+@pytest.mark.parametrize('case', ['half_r18_b2', 'half_fusion_r18_b2', 'half_partial_r18_b2'])
 def test_half_train_step_matches_reference_half(case, pkg):
     """-half_acc iterations against what the reference's own fp16 path (model.half() on torch's CPU half kernels, fp32
     copy_params, loss scale 32; depth_train.py:73-83,413-449) produced for the same weights and batches.  The two fp16
@@ -217,7 +256,7 @@ def test_half_train_step_matches_reference_half(case, pkg):
     trainer.adapt_learn_rate(1)
     for it in range(meta['iters']):
         c, d, tc, tv = pkg.synth.make_batch(meta['batch'], side=meta['side'], rank=0, step=it, invalid_frac=meta['invalid_frac'])
-        depth = torch.from_numpy(d).cuda() if '-do_fusion' in meta['extra'] else None
+        depth = torch.from_numpy(d).cuda() if ('-do_fusion' in meta['extra'] or '-depth_only' in meta['extra']) else None
         loss = float(trainer.train_step(torch.from_numpy(c).cuda(), depth, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
         assert abs(loss - g['losses'][it]) < 1e-3 * abs(g['losses'][it]), (it, loss, g['losses'][it])
         spec_sel = trainer.last_spec_cam.cpu().numpy().reshape(-1, 3)[tv.reshape(-1)]

@@ -43,9 +43,9 @@ def main():
         st_ = ops._stream()
         p = ops._p
         gflop = 2.0 * a.batch * k * d.Ho * d.Wo * c * ks * ks / 1e9
-        t_f = timeit(lambda: L.p3d_hconv2d_fwd(ctypes.byref(d), p(x), p(w), None, p(y), st_), a.iters)
-        t_d = timeit(lambda: L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dy), p(wt), p(dx), st_), a.iters) if c > 4 else 0.0
-        t_w = timeit(lambda: L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dy), p(x), p(dw), c, 1.0, p(ws), ws.numel(), st_), a.iters)
+        t_f = timeit(lambda: L.p3d_hconv2d_fwd(ctypes.byref(d), p(x), p(w), None, None, None, p(y), st_), a.iters)
+        t_d = timeit(lambda: L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dy), p(wt), None, p(dx), st_), a.iters) if c > 4 else 0.0
+        t_w = timeit(lambda: L.p3d_hconv2d_wgrad(ctypes.byref(d), p(dy), p(x), None, p(dw), c, 1.0, p(ws), ws.numel(), st_), a.iters)
         print('%-34s %8.1f | %8.3f %6.0f | %8.3f %6.0f | %8.3f %6.0f' % (tag, gflop, t_f, gflop / t_f, t_d, gflop / t_d if t_d else 0, t_w, gflop / t_w))
         tot['fwd'] += t_f * cnt
         tot['dgrad'] += t_d * cnt
