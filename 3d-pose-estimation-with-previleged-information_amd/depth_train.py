@@ -70,9 +70,8 @@ def to_test_worker(test_loader, no_depth, depth_only, do_fusion=False):
 class Trainer:
 
     def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
-        if args.half_acc and (args.do_teach or args.skip_relu):
-            raise NotImplementedError('-half_acc is implemented for the training paths of depthnet / resnet / fusionnet / partial_depthnet; '
-                                      'distillation runs in fp32')
+        if args.half_acc and (args.skip_relu or (args.do_teach and args.do_freeze)):
+            raise NotImplementedError('-half_acc: -skip_relu and frozen-BatchNorm distillation (-do_freeze) are not implemented in fp16')
         if args.semi_teach and not args.do_teach:
             raise ValueError('-semi_teach adds unlabelled pairs to the distillation loss: it needs -do_teach')
         self.model = model
@@ -210,6 +209,11 @@ class Trainer:
         loss, spec_cam = ops.pose_loss(relat_cam, true_cam, true_val, self.data_info.key_index, self.loss_div,
                                        self.criterion, count_override=count)
         self.last_spec_cam = spec_cam
+        self._backward_and_step(loss)
+        return loss.detach()
+
+    def _backward_and_step(self, loss):
+        """zero_grad -> backward -> gradient exchange -> clip -> Adam (depth_train.py:413-456), in fp32 or with the -half_acc rules."""
         self.optimizer.zero_grad()
         if self.half_acc:
             # static loss scaling (depth_train.py:413-449): gradients carry grad_scaling through the fp16 backward, the optimizer
@@ -220,12 +224,11 @@ class Trainer:
             # overflow test, skip decision and step counter stay on the device (FlatAdam.clip_and_step_dev): no host read-back per step
             self.optimizer.clip_and_step_dev(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True)
             ops_half.refresh_weights(self.model, self.optimizer.flat_p)          # (a skipped step re-casts unchanged weights)
-            return loss.detach()
+            return
         loss.backward()
         assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
         scale = self.reducer.finish()
         self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
-        return loss.detach()
 
     def _run_epoch(self, epoch, data_loader, device):
         n_batches = len(data_loader)
@@ -328,6 +331,9 @@ class Trainer:
     # ---- distillation: the "privileged information" training (depth_train.py:107-129,161-283,641-647,682-691) --------
     def set_teacher(self, teacher):
         self.teacher = teacher
+        if self.half_acc:                                    # depth_train.py:107-108: the teacher runs in fp16 too
+            teacher._p3d_half = True
+            ops_half.refresh_weights(teacher)
 
     def get_dist_weight(self, epoch):
         alphas = np.linspace(self.alpha_init, self.alpha_dest, self.alpha_span)
@@ -360,7 +366,8 @@ class Trainer:
         with torch.no_grad():
             teach_cam, teach_last = self.teach_infer(color_image, depth_image)
         cam_feat, last_feat = self.vanilla_infer(color_image, 0, True)
-        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map.float(), self.get_dist_weight(epoch), unit_grad=True)
+        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map.float(), self.get_dist_weight(epoch),
+                                           unit_grad=not self.half_acc)
         return true_cam.size(0), weighted, dist_loss
 
     def distill_step(self, epoch, color_image, depth_image, true_cam, true_val, atten_map):
@@ -369,7 +376,8 @@ class Trainer:
         with torch.no_grad():
             teach_cam, teach_last = self.teach_infer(color_image, depth_image)
         cam_feat, last_feat = self.vanilla_infer(color_image, 0, True)
-        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map, self.get_dist_weight(epoch), unit_grad=True)
+        weighted, dist_loss = self.distill(true_cam.size(0), teach_last, last_feat, atten_map, self.get_dist_weight(epoch),
+                                           unit_grad=not self.half_acc)      # (under loss scaling the incoming gradient is not 1)
         heat_cam = utils.to_heatmap(cam_feat, self.depth, self.num_joints, side_out, side_out)
         relat_cam = utils.decode(heat_cam, self.depth_range)
         count = p3d_dist.global_valid_divisor(true_val) if self.world > 1 else None
@@ -382,11 +390,7 @@ class Trainer:
             semi_batch, semi_weighted, semi_loss = self.semi_train(color_image.device, epoch)
             loss = loss + semi_weighted
             self.last_semi = (semi_batch, semi_loss.detach())
-        self.optimizer.zero_grad()
-        loss.backward()
-        assert ops.pending_joins() == 0
-        scale = self.reducer.finish()
-        self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
+        self._backward_and_step(loss)
         return cam_loss.detach(), dist_loss.detach()
 
     def distill_train(self, epoch, data_loader, device):

@@ -384,6 +384,36 @@ def gen_semi():
     print('distill_semi.npz', rec)
 
 
+def gen_half_distill():
+    """One distill_train iteration under -half_acc (teacher.half(), student.half(), fp32 copy_params; depth_train.py:107-108,232-270)."""
+    import functools
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'metadata.json'), 'w') as f:
+        json.dump(dict(loader=dict(h36m='depth_datasets'), no_depth=dict(h36m=False), thresholds=dict(h36m=dict(solid=10, close=20, rough=150)),
+                       root=dict(h36m=tmp)), f)
+    args = ref_args('resnet18', 128, ['-do_teach', '-do_fusion', '-half_acc'])
+    import depth_train, depth_main, depthnet, fusionnet, utils
+    depth_train.root_me = tmp
+    student = depthnet.resnet18(args, False)
+    teacher = fusionnet.resnet18(args, False)
+    load_det_weights(student, seed=0)
+    load_det_weights(teacher, seed=1)
+    tr = depth_train.Trainer(args, student, depth_main.get_info())
+    tr.optimizer.zero_grad = functools.partial(tr.optimizer.zero_grad, set_to_none=False)      # see gen_step
+    tr.set_teacher(teacher)
+    c, d, tc, tv = synth.make_batch(2, side=128, rank=11, step=0)
+    att = np.stack([utils.get_attention(128, 16, np.random.Generator(np.random.PCG64(i)).uniform(0, 128, size=(17, 2)), True) for i in range(2)]).astype(np.float32)
+    batch = tuple(torch.from_numpy(x) for x in (c, d, tc, tv, att))
+    tr.model.train()
+    tr.adapt_learn_rate(1)
+    rec = tr.distill_train(1, [batch], torch.device('cpu'))
+    sd = {k: tnp(v).astype(np.float32) for k, v in student.state_dict().items()}
+    names = tr.list_names
+    np.savez_compressed(os.path.join(HERE, 'distill_half.npz'), record=np.array(json.dumps({k: float(v) for k, v in rec.items()})), att=att,
+                        names=np.array(json.dumps(names)), param_norms=np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names]))
+    print('distill_half.npz', rec)
+
+
 def gen_legacy_resnet():
     """resnet.py forward only (train.Trainer cannot be constructed: it reads args.thresh_* that opts.py lacks)."""
     args = ref_args('resnet18', 256, ['-joint_space'])
@@ -443,5 +473,7 @@ if __name__ == '__main__':
             gen_distill()
         elif t == 'semi':
             gen_semi()
+        elif t == 'half_distill':
+            gen_half_distill()
         else:
             gen_step(t)

@@ -312,3 +312,32 @@ def test_half_eval_forward(pkg):
         z32, _ = model32(x)
     assert z16.dtype == torch.float32 and z16.shape == z32.shape
     assert (z16 - z32).abs().max() < 2e-2 * z32.abs().max()
+
+
+def test_half_distillation_step_matches_reference_half(pkg):
+    """-do_teach under -half_acc: fp16 teacher (fusionnet) and student (depthnet), fp32 feature-distillation loss on the converted
+    feature maps, loss-scaled backward; against one distill_train iteration of the reference's own fp16 path."""
+    import json
+    from conftest import golden_path
+    g = np.load(golden_path('distill_half.npz'))
+    args = pkg.opts.parse(['-model', 'resnet18', '-suffix', 't', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1',
+                           '-num_joints', '17', '-side_in', '128', '-do_teach', '-do_fusion', '-half_acc'])
+    student = pkg.depthnet.resnet18(args, False)
+    teacher = pkg.fusionnet.resnet18(args, False)
+    for net, seed in ((student, 0), (teacher, 1)):
+        det = pkg.synth.det_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in det.items()})
+    trainer = pkg.depth_train.Trainer(args, student.cuda(), pkg.utils.get_info())
+    trainer.set_teacher(teacher.cuda())
+    assert teacher._p3d_half and student._p3d_half
+    trainer.verbose = False
+    c, d, tc, tv = pkg.synth.make_batch(2, side=128, rank=11, step=0)
+    record = trainer.train(1, [tuple(torch.from_numpy(x) for x in (c, d, tc, tv, g['att']))])
+    want = json.loads(str(g['record']))
+    assert record['cam_train_loss'] == pytest.approx(want['cam_train_loss'], rel=2e-3)
+    assert record['dist_train_loss'] == pytest.approx(want['dist_train_loss'], rel=5e-3)
+    assert trainer.skipped_steps == 0 and trainer.optimizer.steps_taken() == 1
+    names = json.loads(str(g['names']))
+    sd = {k: v.detach().cpu().numpy() for k, v in student.state_dict().items()}
+    pn = np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names])
+    assert np.abs(pn - g['param_norms']).max() < 1e-3 * g['param_norms'].max()
