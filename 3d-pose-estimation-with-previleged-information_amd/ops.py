@@ -206,6 +206,8 @@ class Conv2dFn(torch.autograd.Function):
         L = lib()
         st = _stream()
         dx = dw = db = None
+        # dy is complete at this point of the launch stream: the wgrad stream waits for THIS event, not for the dgrad launched below
+        dy_ready = torch.cuda.current_stream().record_event() if (WGRAD_STREAM and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[0]:
             joined = join_take.buf if join_take is not None else None
             if joined is not None and joined.shape == x.shape:
@@ -228,7 +230,7 @@ class Conv2dFn(torch.autograd.Function):
             if WGRAD_STREAM and sink is not None:
                 side = _side_stream(x.device)
                 _queue_join()
-                side.wait_stream(torch.cuda.current_stream())          # dy (and the zeroed gradient buffer) are ready
+                side.wait_event(dy_ready)                               # dy (and the zeroed gradient buffer) are ready
                 ws = _side_workspace(x.device, nbytes)
                 with torch.cuda.stream(side):
                     with _Timed('wgrad', d):
