@@ -60,7 +60,7 @@ def main():
         if b:
             r = b['roofline']
             parts.append('bench line of this run (under the profiler): %.1f crops/s, %.2f ms/step; roofline.achieved %.1f TFLOP/s (conv ms/step %s), '
-                         'achieved_in_timed_region %.1f\n' % (b['value'], b['ms_per_step'], r['achieved'], json.dumps(r['conv_ms_per_step']), r['achieved_in_timed_region']))
+                         'achieved_in_timed_region %s\n' % (b['value'], b['ms_per_step'], r['achieved'], json.dumps(r['conv_ms_per_step']), r['achieved_in_timed_region']))
     tj = os.path.join(ROOT, 'gpurun_out', 'traffic.json')
     if os.path.exists(tj):
         shutil.copy(tj, os.path.join(ROOT, 'profiles', '%s_traffic.json' % RND))
