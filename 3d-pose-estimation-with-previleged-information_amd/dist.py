@@ -113,7 +113,7 @@ class GradReducer:
         side = None
         if bucket.is_cuda:
             from . import ops
-            if ops.WGRAD_STREAM and not os.environ.get('P3D_REDUCE_JOIN_MAIN'):
+            if ops.WGRAD_STREAM:
                 # Weight gradients are written on the wgrad stream, BN / bias gradients on the launch stream.  The collective is issued
                 # FROM the wgrad stream after that stream has been ordered behind the launch stream's current position: RCCL's stream
                 # then waits for both, and the launch stream (the dy -> BN-backward -> dgrad critical path) is never stalled.

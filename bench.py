@@ -103,8 +103,7 @@ def main():
         trainer.train_step = step_with_augmentation
 
     if world > 1 or pkg.dist.FORCE_GROUP:
-        if not os.environ.get('P3D_EARLY_GROUP'):
-            trainer.warm_memory(*batches[0])
+        trainer.warm_memory(*batches[0])
         pkg.dist.init_from_env()
         trainer.attach_reducer()
 
