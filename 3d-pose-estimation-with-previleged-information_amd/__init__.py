@@ -14,6 +14,6 @@ def __getattr__(name):
     import importlib
     if name in ('ops', 'nn', 'optim', 'dist', 'utils', 'opts', 'depthnet', 'resnet', 'fusionnet', 'partial_conv',
                 'partial_depthnet', 'depth_train', 'depth_main', 'depth_datasets', 'datasets', 'joint_settings', '_lib', 'log', 'train', 'main',
-                'augment'):
+                'augment', 'graphed', 'ops_half'):
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

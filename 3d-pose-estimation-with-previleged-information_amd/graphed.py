@@ -1,0 +1,74 @@
+"""Whole-step HIP-graph capture (opt-in, single process): one `hipGraphLaunch` per training step instead of ~600 kernel launches.
+
+Measured on MI355X / ROCm 7.2 (tools/graph_try.py, ResNet-50 bs 64): the fp32 step replays in 43.1 ms against 43.6 ms eager (+1 %),
+the fp16 step in 17.9 ms against 16.0 ms eager (SLOWER: the runtime launches the ~600 kernel nodes of the graph one by one with a
+dependency barrier each, which costs more than the stream launches it replaces).  So this stays an opt-in experiment; it documents
+that the step IS capturable and keeps the property tested.  What makes the step capturable: no host read-back anywhere (loss, overflow test and Adam step counter stay on the device), caller-owned workspaces,
+parameters / gradients / moments at fixed addresses (FlatAdam), and the second (wgrad) stream forks from and joins the capturing
+stream inside the step.  Values that are baked into the captured launches -- the learning rate and, for the fp32 optimizer, the
+host-side step count -- are handled by re-capturing when the learning rate changes and by using the device-side step counter
+(`FlatAdam.clip_and_step_dev`) for both precisions.
+
+Not used under torch.distributed (the bucket hooks are Python callbacks that a replay does not run).
+"""
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    """Wraps Trainer.train_step for fixed-shape batches: `step(color, depth, true_cam, true_val)` copies the batch into static
+    buffers and replays the captured graph; returns the static loss tensor (device, valid until the next call)."""
+
+    def __init__(self, trainer, warmup=3):
+        if trainer.world != 1 or trainer.reducer.active:
+            raise RuntimeError('GraphedStep: whole-step capture is single-process only')
+        self.trainer = trainer
+        self.warmup = warmup
+        self.graph = None
+        self.static = None
+        self.loss = None
+        self._lr = None
+        self._shapes = None
+
+    def _capture(self, batch):
+        tr = self.trainer
+        self.static = tuple(None if t is None else t.clone() for t in batch)
+        run = self._run
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up on a side stream, as the PyTorch capture recipe asks
+            for _ in range(self.warmup):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        profile, ops.PROFILE = ops.PROFILE, None           # timing events cannot be recorded inside a capture
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = run()
+        ops.PROFILE = profile
+        self._lr = tr.optimizer.param_groups[0]['lr']
+        self._shapes = tuple(None if t is None else tuple(t.shape) for t in batch)
+
+    def _run(self):
+        tr = self.trainer
+        keep = tr.optimizer.clip_and_step
+        # the host-counted fp32 optimizer call would bake its step number into the graph: route it to the device-side counter
+        tr.optimizer.clip_and_step = lambda max_norm, grad_scale=1.0: tr.optimizer.clip_and_step_dev(max_norm, grad_scale, skip_nonfinite=False)
+        try:
+            return tr.train_step(*self.static)
+        finally:
+            tr.optimizer.clip_and_step = keep
+
+    def step(self, color_image, depth_image, true_cam, true_val):
+        batch = (color_image, depth_image, true_cam, true_val)
+        shapes = tuple(None if t is None else tuple(t.shape) for t in batch)
+        if self.graph is None or shapes != self._shapes or self.trainer.optimizer.param_groups[0]['lr'] != self._lr:
+            self._capture(batch)                           # eager warm-up steps train on this batch; the capture pass only records
+            self.graph.replay()
+            return self.loss
+        for dst, src in zip(self.static, batch):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -115,3 +115,35 @@ def test_training_is_bitwise_reproducible(pkg):
     assert outs[0][0] == outs[1][0]
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_whole_step_graph_capture_matches_eager(pkg):
+    """graphed.GraphedStep: the captured + replayed training step (device-side Adam counter, two streams inside the capture) produces
+    the same parameters as the eager step on the same batches."""
+    g = np.load(golden_path('step_depth_r18_b2.npz'))
+    meta = json.loads(str(g['meta']))
+    batches = []
+    for it in range(3):
+        c, d, tc, tv = pkg.synth.make_batch(2, side=meta['side'], rank=0, step=it)
+        batches.append((torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+    order = [0, 0, 0, 0, 1, 2]                     # GraphedStep's first call trains 4 times on its batch (3 eager warm-up steps + the first replay)
+    args, model, trainer = build(pkg, meta)
+    model.train()
+    trainer.adapt_learn_rate(1)
+    for i in order:
+        keep = trainer.optimizer.clip_and_step
+        trainer.optimizer.clip_and_step = lambda m, grad_scale=1.0: trainer.optimizer.clip_and_step_dev(m, grad_scale, skip_nonfinite=False)
+        loss_eager = trainer.train_step(*batches[i])
+        trainer.optimizer.clip_and_step = keep
+    eager = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    args, model2, trainer2 = build(pkg, meta)
+    model2.train()
+    trainer2.adapt_learn_rate(1)
+    graphed = pkg.graphed.GraphedStep(trainer2)
+    for i in (0, 1, 2):
+        loss_graph = graphed.step(*batches[i])
+    torch.cuda.synchronize()
+    assert trainer2.optimizer.steps_taken() == 6 == trainer.optimizer.steps_taken()
+    assert float(loss_graph) == pytest.approx(float(loss_eager), rel=1e-6)
+    for k, v in model2.state_dict().items():
+        assert torch.allclose(v.detach().cpu().float(), eager[k].float(), rtol=1e-5, atol=1e-7), k
