@@ -68,6 +68,8 @@ def main():
     # The process group is joined only AFTER the model, the optimizer buffers and one step's worth of activations have been allocated
     # (Trainer.warm_memory): memory first allocated once an RCCL communicator exists is slower for the kernels.
     world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('P3D_BENCH_SHARE_GPU'):      # rehearsal of the N > 1 flow on a one-GPU box (with P3D_DIST_BACKEND=gloo): all ranks on cuda:0
+        local_rank = 0
     if world != opt.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 under torch.distributed.run)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
