@@ -1,0 +1,34 @@
+"""bench.py prints exactly one JSON line with the contract's keys (driver contract + the `roofline` / `cpu_baseline` objects)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_schema():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--cpu-steps', '1'],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    for key, kind in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int), ('ms_per_step', float),
+                      ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str), ('config', dict), ('roofline', dict),
+                      ('cpu_baseline', dict)):
+        assert isinstance(line[key], kind), key
+    assert 'vs_baseline' in line and line['vs_baseline'] is None          # BASELINE.md publishes no number for this metric
+    assert line['unit'] == 'crops/s' and line['n_gpus'] == 1 and line['steps'] == 3 and line['warmup'] == 1
+    assert line['scaling'] == 'weak' and line['dtype'] == 'f32' and line['data'] == 'synthetic' and line['higher_is_better'] is True
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    assert line['value'] == pytest.approx(64 * 3 / (line['ms_per_step'] * 3 / 1e3), rel=1e-3)
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], abs=1e-3) and 0.2 < r['frac'] < 1.0
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = line['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['unit'] == 'crops/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
