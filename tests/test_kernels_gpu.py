@@ -107,7 +107,9 @@ def test_conv_cat_equals_conv_of_concat(pkg):
 
 
 BN_CASES = [(4, 64, 16, 16, True, True), (3, 10, 17, 17, True, False), (2, 130, 8, 8, False, True), (5, 7, 5, 3, False, False),
-            (64, 16, 32, 32, True, True)]
+            (64, 16, 32, 32, True, True),
+            # the 16x16-stage shapes: a 64 KB channel slab with the recomputed mask, relu + residual, plain
+            (64, 256, 16, 16, True, False), (8, 128, 16, 16, True, True), (3, 256, 4, 4, False, False)]
 
 
 @pytest.mark.parametrize('n,c,h,w,relu,with_res', BN_CASES)
