@@ -341,3 +341,27 @@ def test_half_distillation_step_matches_reference_half(pkg):
     sd = {k: v.detach().cpu().numpy() for k, v in student.state_dict().items()}
     pn = np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names])
     assert np.abs(pn - g['param_norms']).max() < 1e-3 * g['param_norms'].max()
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 64, 3, 1, 1), (256, 64, 512, 1, 2, 1), (128, 64, 128, 3, 2, 1), (1024, 16, 256, 1, 1, 1), (512, 16, 512, 3, 1, 2),
+                                   (2048, 16, 272, 3, 1, 1)], ids=lambda s: 'c%d_h%d_k%d_%dx%d_s%d_d%d' % (s[0], s[1], s[2], s[3], s[3], s[4], s[5]))
+def test_hconv_adjoint_identities_at_full_size(shape, pkg):
+    """The fp16 kernels at batch 64: <dy, conv(x, w)> = <dgrad(dy), x> = <wgrad(dy, x), w> up to the fp16 rounding of the stored results."""
+    from_half = pkg.ops_half
+    c, h, k, ks, st, dil = shape
+    pad = dil * (ks - 1) // 2
+    conv = pkg.nn.Conv2d(c, k, ks, stride=st, padding=pad, dilation=dil, bias=False).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(c + k)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, device='cuda', generator=gen) / (c * ks * ks) ** 0.5).half().float())
+    from_half.refresh_weights(conv)
+    x = torch.randn(64, c, h, h, device='cuda', generator=gen).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(x)
+    dy = torch.randn(y.shape, device='cuda', generator=gen).half().contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    form = (dy.double() * y.detach().double()).sum().item()
+    via_w = (conv.weight.grad.double() * conv.weight.detach().double()).sum().item()
+    via_x = (x.grad.double() * x.detach().double()).sum().item()
+    scale = (dy.double().norm() * y.detach().double().norm()).item()
+    assert abs(form - via_w) < 2e-3 * scale and abs(form - via_x) < 2e-3 * scale, (form, via_w, via_x)

@@ -356,3 +356,34 @@ def test_conv_bn_eval_fused(case, pkg):
         got = host(pkg.ops.conv_bn_eval(dev(x), conv, bn, res=None if res is None else dev(res), relu=relu))
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
     assert not pkg.ops.can_fuse_eval(dev(x), conv, bn)                           # with autograd on, the unfused path runs
+
+
+R50_CLASSES = [(3, 256, 64, 7, 2, 1), (64, 64, 64, 1, 1, 1), (64, 64, 64, 3, 1, 1), (64, 64, 256, 1, 1, 1), (256, 64, 64, 1, 1, 1), (256, 64, 128, 1, 1, 1),
+               (128, 64, 128, 3, 2, 1), (128, 32, 512, 1, 1, 1), (256, 64, 512, 1, 2, 1), (512, 32, 128, 1, 1, 1), (128, 32, 128, 3, 1, 1),
+               (512, 32, 256, 1, 1, 1), (256, 32, 256, 3, 2, 1), (256, 16, 1024, 1, 1, 1), (512, 32, 1024, 1, 2, 1), (1024, 16, 256, 1, 1, 1),
+               (256, 16, 256, 3, 1, 1), (1024, 16, 512, 1, 1, 1), (512, 16, 512, 3, 1, 2), (512, 16, 2048, 1, 1, 1), (1024, 16, 2048, 1, 1, 1),
+               (2048, 16, 512, 1, 1, 1), (512, 16, 512, 3, 1, 1), (2048, 16, 272, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('shape', R50_CLASSES, ids=['c%d_h%d_k%d_%dx%d_s%d_d%d' % (s[0], s[1], s[2], s[3], s[3], s[4], s[5]) for s in R50_CLASSES])
+def test_conv_adjoint_identities_at_full_size(shape, pkg):
+    """Size-independent parity property at BASELINE's full sizes (batch 64, every conv class of ResNet-50):
+    forward, dgrad and wgrad are the three faces of one trilinear form, <dy, conv(x, w)> = <dgrad(dy, w), x> = <wgrad(dy, x), w>.
+    This exercises the production plans (split-K forward / dgrad, parity-class dgrad, split wgrad + fold, tap-major weight image)."""
+    ops = pkg.ops
+    c, h, k, ks, st, dil = shape
+    pad = dil * (ks - 1) // 2
+    gen = torch.Generator(device='cuda').manual_seed(c * 7 + k)
+    x = torch.randn(64, c, h, h, device='cuda', generator=gen).requires_grad_(c > 4)
+    w = (torch.randn(k, c, ks, ks, device='cuda', generator=gen) / (c * ks * ks) ** 0.5).requires_grad_(True)
+    y = ops.conv2d(x, w, None, st, pad, dil)
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    form = (dy.double() * y.detach().double()).sum().item()
+    via_w = (w.grad.double() * w.detach().double()).sum().item()
+    scale = (dy.double().norm() * y.detach().double().norm()).item()
+    assert abs(form - via_w) < 2e-5 * scale, (form, via_w)
+    if c > 4:                                            # (the stem never computes an input gradient)
+        via_x = (x.grad.double() * x.detach().double()).sum().item()
+        assert abs(form - via_x) < 2e-5 * scale, (form, via_x)
