@@ -387,3 +387,27 @@ def test_conv_adjoint_identities_at_full_size(shape, pkg):
     if c > 4:                                            # (the stem never computes an input gradient)
         via_x = (x.grad.double() * x.detach().double()).sum().item()
         assert abs(form - via_x) < 2e-5 * scale, (form, via_x)
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 128, 128), (64, 256, 64, 64), (64, 1024, 16, 16), (64, 2048, 16, 16)])
+def test_bn_properties_at_full_size(shape, pkg):
+    """Size-independent BatchNorm properties at the contract's tensor sizes: the training output has zero mean / unit variance per channel,
+    and the input gradient is orthogonal to 1 and to the normalised input (what subtracting k1 + xhat * k2 means)."""
+    ops = pkg.ops
+    n, c, h, w = shape
+    gen = torch.Generator(device='cuda').manual_seed(c)
+    x = (torch.randn(shape, device='cuda', generator=gen) * 3 + 1.5).requires_grad_(True)
+    gamma, beta = torch.ones(c, device='cuda', requires_grad=True), torch.zeros(c, device='cuda', requires_grad=True)
+    rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    y = ops.batch_norm_act(x, gamma, beta, rm, rv, None, False, True, 0.1, 1e-5)
+    yd = y.detach().double()
+    assert yd.mean(dim=(0, 2, 3)).abs().max() < 1e-5
+    assert (yd.var(dim=(0, 2, 3), unbiased=False) - 1).abs().max() < 1e-4
+    dy = torch.randn(shape, device='cuda', generator=gen)
+    y.backward(dy)
+    dx = x.grad.double()
+    scale = dy.double().abs().sum(dim=(0, 2, 3))
+    assert (dx.sum(dim=(0, 2, 3)).abs() / scale).max() < 1e-6
+    assert ((dx * yd).sum(dim=(0, 2, 3)).abs() / scale).max() < 1e-5
+    assert (gamma.grad.double() - (dy.double() * yd).sum(dim=(0, 2, 3))).abs().max() < 1e-3 * (dy.double() * yd).sum(dim=(0, 2, 3)).abs().max()
+    assert (beta.grad.double() - dy.double().sum(dim=(0, 2, 3))).abs().max() < 1e-3 * dy.double().sum(dim=(0, 2, 3)).abs().max()
