@@ -300,6 +300,18 @@ __global__ __launch_bounds__(256) void hconcat_kernel(_Float16* __restrict__ a, 
     }
 }
 
+// standalone F.relu on fp16 (the -skip_relu variants apply it outside the residual blocks, depthnet.py:197-198)
+__global__ __launch_bounds__(256) void hrelu_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ dy, _Float16* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const h8 v = reinterpret_cast<const h8*>(x)[i];
+        h8 g, o;
+        if (dy) g = reinterpret_cast<const h8*>(dy)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = dy ? ((float)v[e] > 0.f ? g[e] : (_Float16)0.f) : ((float)v[e] > 0.f ? v[e] : (_Float16)0.f);
+        reinterpret_cast<h8*>(out)[i] = o;
+    }
+}
+
 static bool hbn_shape_ok(int C) { return C >= 8 && C % 8 == 0 && ((C / 8) <= 256 ? 256 % (C / 8) == 0 : (C / 8) % 256 == 0); }
 
 }  // namespace p3d
@@ -376,6 +388,15 @@ int32_t p3d_hconcat(void* a, void* b, void* cat, int64_t P, int32_t Ca, int32_t 
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(hconcat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (_Float16*)a, (_Float16*)b, (_Float16*)cat, (size_t)P, Ca / 8, Cb / 8, split);
     return check_launch("hconcat");
+}
+
+/* dy == NULL: out = relu(x);  else: out = dy where x > 0 else 0 (x = the forward OUTPUT or input, their signs agree).  n multiple of 8 */
+int32_t p3d_hrelu(const void* x, const void* dy, void* out, int64_t n, void* stream) {
+    P3D_REQUIRE(x && out && n > 0 && n % 8 == 0, "hrelu: bad argument");
+    const int64_t n8 = n / 8;
+    const unsigned blocks = (unsigned)(ceil_div(n8, 256) < 8192 ? ceil_div(n8, 256) : 8192);
+    hipLaunchKernelGGL(hrelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)dy, (_Float16*)out, (size_t)n8);
+    return check_launch("hrelu");
 }
 
 int32_t p3d_hmaxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

@@ -437,6 +437,9 @@ class ReluFn(torch.autograd.Function):
 
 
 def relu(x):
+    if x.dtype == torch.float16:
+        from . import ops_half
+        return ops_half.relu(x)
     return ReluFn.apply(x)
 
 

@@ -355,3 +355,28 @@ class HConcatFn(torch.autograd.Function):
 
 def concat(x, y):
     return HConcatFn.apply(x, y)
+
+
+class HReluFn(torch.autograd.Function):
+    """standalone F.relu on fp16 tensors (depthnet.py:197-198 skip_relu variants)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_half(x)
+        x = _cl(x)
+        y = torch.empty_like(x, memory_format=CL)
+        check(lib().p3d_hrelu(_p(x), None, _p(y), x.numel(), _stream()), 'p3d_hrelu')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = torch.empty_like(y, memory_format=CL)
+        check(lib().p3d_hrelu(_p(y), _p(dy), _p(dx), y.numel(), _stream()), 'p3d_hrelu')
+        return dx
+
+
+def relu(x):
+    return HReluFn.apply(x)

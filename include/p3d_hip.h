@@ -253,6 +253,8 @@ int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const fl
 /* torch.cat((x, y), dim=1) of the Fusion block (fusionnet.py:138) on NHWC fp16: split == 0 writes cat[P][Ca+Cb] from a[P][Ca], b[P][Cb];
  * split != 0 writes a and b from cat (the backward of the concat) */
 int32_t p3d_hconcat(void* a, void* b, void* cat, int64_t P, int32_t Ca, int32_t Cb, int32_t split, void* stream);
+/* standalone F.relu on fp16 (-skip_relu, depthnet.py:197-198): dy == NULL -> out = relu(x); else out = dy masked by x > 0 */
+int32_t p3d_hrelu(const void* x, const void* dy, void* out, int64_t n, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on NHWC fp16; idx [N][Ho][Wo][C] uint8 window codes as in p3d_maxpool3x3s2_fwd */
 int32_t p3d_hmaxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int32_t p3d_hmaxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

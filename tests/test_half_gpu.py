@@ -365,3 +365,26 @@ def test_hconv_adjoint_identities_at_full_size(shape, pkg):
     via_x = (x.grad.double() * x.detach().double()).sum().item()
     scale = (dy.double().norm() * y.detach().double().norm()).item()
     assert abs(form - via_w) < 2e-3 * scale and abs(form - via_x) < 2e-3 * scale, (form, via_w, via_x)
+
+
+def test_hrelu_and_skip_relu_network(pkg):
+    ops = pkg.ops
+    x = torch.randn(2, 16, 5, 7, device='cuda').half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.relu(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert torch.equal(y.detach(), torch.clamp(x.detach(), min=0)) and torch.equal(x.grad, dy * (x.detach() > 0))
+    # -skip_relu network under -half_acc: one training step runs and matches the fp32 loss closely
+    flags = ['-model', 'resnet18', '-suffix', 't', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1', '-num_joints', '17',
+             '-side_in', '128', '-skip_relu']
+    losses = []
+    for extra in ([], ['-half_acc']):
+        args = pkg.opts.parse(flags + extra)
+        torch.manual_seed(3)
+        model = pkg.depth_main.create_model(args)[0].cuda().train()
+        trainer = pkg.depth_train.Trainer(args, model, pkg.utils.get_info())
+        trainer.verbose = False
+        trainer.adapt_learn_rate(1)
+        c, d, tc, tv = pkg.synth.make_batch(4, side=128, rank=2, step=0)
+        losses.append(float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda())))
+    assert losses[1] == pytest.approx(losses[0], rel=2e-3)
