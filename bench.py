@@ -53,7 +53,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='crops per GPU')
     ap.add_argument('--model', default='resnet50')
-    ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet'],
+    ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet', 'partial_fusionnet'],
                     help='informational runs of BASELINE configs 4/5; the contract line is depthnet (config 2)')
     ap.add_argument('--augment', action='store_true', help='BASELINE config 5: colour + eraser augmentation and normalisation of a raw RGB batch on the GPU, inside the timed step')
     ap.add_argument('--half', action='store_true', help='informational: the -half_acc (fp16 NHWC) path; the contract line is fp32')
@@ -75,7 +75,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
-    extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv']}[opt.family]
+    extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv'],
+             'partial_fusionnet': ['-do_fusion', '-partial_conv']}[opt.family]
     args = pkg.opts.parse(['-model', opt.model] + FLAGS + extra + (['-half_acc'] if opt.half else []) + (['-colour', '-eraser'] if opt.augment else []))
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model, _ = pkg.depth_main.create_model(args)

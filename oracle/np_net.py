@@ -194,13 +194,19 @@ class NpNet:
         x, veil, b = self.stage('layer2', x, 128, L[1], s[0], d[0], inplanes=64 * e, veil=veil); chain.append(b)
 
         ychain = []
-        if self.family == 'fusionnet':                                           # fusionnet.py:221-233
-            y, b = self.conv('conv2', y, stride=2, pad=3, need_dx=False); ychain.append(b)
+        if self.family in ('fusionnet', 'partial_fusionnet'):                    # fusionnet.py:221-233
+            yveil = None
+            if self.family == 'partial_fusionnet':       # intended wiring of partial_fusionnet.py:250-275 (dense RGB stem, partial depth stream)
+                yveil = (y != 0).astype(np.float32)
+                y, yveil, b = self.pconv('conv2', y, yveil, stride=2, pad=3, need_dx=False); ychain.append(b)
+                yveil, _ = ops.maxpool3x3s2_fwd(yveil)
+            else:
+                y, b = self.conv('conv2', y, stride=2, pad=3, need_dx=False); ychain.append(b)
             y, b = self.bn('bn2', y); ychain.append(b)
             y, b = self.relu(y); ychain.append(b)
             y, b = self.maxpool(y); ychain.append(b)
-            y, _, b = self.stage('layer5', y, 64, L[0], inplanes=64); ychain.append(b)
-            y, _, b = self.stage('layer6', y, 128, L[1], s[0], d[0], inplanes=64 * e); ychain.append(b)
+            y, yveil, b = self.stage('layer5', y, 64, L[0], inplanes=64, veil=yveil); ychain.append(b)
+            y, yveil, b = self.stage('layer6', y, 128, L[1], s[0], d[0], inplanes=64 * e, veil=yveil); ychain.append(b)
             cx = x.shape[1]
             cat = np.concatenate([x, y], axis=1)
             f, b1 = self.conv('fusion.conv', cat)
@@ -238,7 +244,7 @@ class NpNet:
             if dfeat_n is not None and self.early_dist:
                 dm = dm + dfeat_n
             dx = bl3(dm)
-            if self.family == 'fusionnet':
+            if self.family in ('fusionnet', 'partial_fusionnet'):
                 dx, dy = fuse_bwd(dx)
                 for f in reversed(ychain):
                     dy = f(dy)
@@ -261,7 +267,7 @@ def train_step(sd, color, depth, true_cam, true_val, family='depthnet', model='r
     """One iteration of depth_train.Trainer.vanilla_train / fusion_train (depth_train.py:376-462 / 286-373)
     in fp32 mode.  Returns dict(loss, spec_cam, z, grads, clip_total, clip_coef, new_sd, adam_state)."""
     net = NpNet(sd, family=family, model=model, stride=stride, train=True, acc=acc)
-    if family == 'fusionnet':
+    if family in ('fusionnet', 'partial_fusionnet'):
         z, feat = net.forward(color, depth)
     else:
         z, feat = net.forward(depth if (depth_only or family == 'partial_depthnet') else color)

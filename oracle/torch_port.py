@@ -95,10 +95,17 @@ class TorchPort:
             veil = F.max_pool2d(veil, 3, 2, 1)
         x, veil = self.stage('layer1', x, 64, L[0], inplanes=64, veil=veil)
         x, veil = self.stage('layer2', x, 128, L[1], s[0], d[0], inplanes=64 * e, veil=veil)
-        if self.family == 'fusionnet':
-            y = F.max_pool2d(F.relu(self.bn('bn2', self.conv('conv2', y, 2, 3))), 3, 2, 1)
-            y, _ = self.stage('layer5', y, 64, L[0], inplanes=64)
-            y, _ = self.stage('layer6', y, 128, L[1], s[0], d[0], inplanes=64 * e)
+        if self.family in ('fusionnet', 'partial_fusionnet'):
+            yveil = None
+            if self.family == 'partial_fusionnet':      # intended wiring of partial_fusionnet.py:250-275: dense RGB stem, partial depth stream
+                yveil = (y != 0).float()
+                y, yveil = self.pconv('conv2', y, yveil, 2, 3)
+                yveil = F.max_pool2d(yveil, 3, 2, 1)
+            else:
+                y = self.conv('conv2', y, 2, 3)
+            y = F.max_pool2d(F.relu(self.bn('bn2', y)), 3, 2, 1)
+            y, yveil = self.stage('layer5', y, 64, L[0], inplanes=64, veil=yveil)
+            y, yveil = self.stage('layer6', y, 128, L[1], s[0], d[0], inplanes=64 * e, veil=yveil)
             x = F.relu(self.bn('fusion.bn', self.conv('fusion.conv', torch.cat([x, y], 1))))
         x, _ = self.stage('layer3', x, 256, L[2], s[1], d[1], inplanes=128 * e)
         x, _ = self.stage('layer4', x, 512, L[3], s[2], d[2], inplanes=256 * e)
@@ -120,7 +127,7 @@ class TorchPort:
                    loss_div=10.0, key_index=16, lr=1e-5, weight_decay=4e-5, grad_norm=5.0):
         color, depth = torch.as_tensor(color), torch.as_tensor(depth)
         true_cam, true_val = torch.as_tensor(true_cam), torch.as_tensor(true_val)
-        if self.family == 'fusionnet':
+        if self.family in ('fusionnet', 'partial_fusionnet'):
             z = self.forward(color, depth)
         else:
             z = self.forward(depth if (depth_only or self.family == 'partial_depthnet') else color)

@@ -142,10 +142,14 @@ STEP_CASES = {
     'fusion_r50_b1': ('fusionnet', 'resnet50', 256, 1, 1, 0.0, ['-do_fusion']),
     'partial_r18_b2': ('partial_depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only', '-partial_conv']),
     'partial_r50_b1': ('partial_depthnet', 'resnet50', 256, 1, 1, 0.0, ['-depth_only', '-partial_conv']),
+    # partial_fusionnet with its two stem convolutions swapped to the types its forward() calls them with (see gen_step)
+    'pfusion_r18_b2': ('partial_fusionnet', 'resnet18', 256, 2, 1, 0.0, ['-do_fusion', '-partial_conv']),
+    'pfusion_r50_b1': ('partial_fusionnet', 'resnet50', 256, 1, 1, 0.0, ['-do_fusion', '-partial_conv']),
     # -half_acc: model.half() + fp32 copy_params + static loss scale (depth_train.py:73-83,413-449), on the CPU half kernels of torch
     'half_r18_b2': ('depthnet', 'resnet18', 256, 2, 2, 0.0, ['-half_acc']),
     'half_fusion_r18_b2': ('fusionnet', 'resnet18', 256, 2, 1, 0.0, ['-do_fusion', '-half_acc']),
     'half_partial_r18_b2': ('partial_depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only', '-partial_conv', '-half_acc']),
+    'half_pfusion_r18_b2': ('partial_fusionnet', 'resnet18', 256, 2, 1, 0.0, ['-do_fusion', '-partial_conv', '-half_acc']),
 }
 
 
@@ -163,6 +167,13 @@ def gen_step(case):
     depth_train.root_me = tmp
     mod = importlib.import_module(family)
     model = getattr(mod, model_name)(args, False)
+    if family == 'partial_fusionnet':
+        # The reference builds conv1 as PartialConv and conv2 as nn.Conv2d (partial_fusionnet.py:202-203) but its forward calls
+        # conv1(x) and conv2(y, veil) (:251,257), which raises.  Give the two stems the types forward() expects; every other
+        # module and the whole forward/backward are the reference's own.
+        import partial_conv
+        model.conv1 = torch.nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        model.conv2 = partial_conv.PartialConv(1, 64, kernel_size=7, stride=2, padding=3, bias=False)
     load_det_weights(model, seed=0)
     info = depth_main.get_info()
     tr = depth_train.Trainer(args, model, info)
@@ -436,7 +447,8 @@ def gen_state_keys():
     inv = {}
     import importlib
     for family, extra in [('depthnet', []), ('depthnet', ['-depth_only']), ('fusionnet', ['-do_fusion']),
-                          ('partial_depthnet', ['-depth_only', '-partial_conv'])]:
+                          ('partial_depthnet', ['-depth_only', '-partial_conv']),
+                          ('partial_fusionnet', ['-do_fusion', '-partial_conv'])]:
         for model_name in ['resnet18', 'resnet50']:
             args = ref_args(model_name, 256, extra)
             mod = importlib.import_module(family)

@@ -238,7 +238,7 @@ def test_hmaxpool(shape, pkg):
     assert np.abs(nchw32(dxt) - want).max() < 2e-3 * max(1.0, np.abs(want).max())
 
 
-@pytest.mark.parametrize('case', ['half_r18_b2', 'half_fusion_r18_b2', 'half_partial_r18_b2'])
+@pytest.mark.parametrize('case', ['half_r18_b2', 'half_fusion_r18_b2', 'half_partial_r18_b2', 'half_pfusion_r18_b2'])
 def test_half_train_step_matches_reference_half(case, pkg):
     """-half_acc iterations against what the reference's own fp16 path (model.half() on torch's CPU half kernels, fp32
     copy_params, loss scale 32; depth_train.py:73-83,413-449) produced for the same weights and batches.  The two fp16

@@ -31,7 +31,8 @@ def test_opts_defaults_match_reference(pkg):
 
 @pytest.mark.parametrize('tag,extra,module', [
     ('depthnet', [], 'depthnet'), ('depthnet_depth_only', ['-depth_only'], 'depthnet'),
-    ('fusionnet', ['-do_fusion'], 'fusionnet'), ('partial_depthnet', ['-depth_only', '-partial_conv'], 'partial_depthnet')])
+    ('fusionnet', ['-do_fusion'], 'fusionnet'), ('partial_depthnet', ['-depth_only', '-partial_conv'], 'partial_depthnet'),
+    ('partial_fusionnet', ['-do_fusion', '-partial_conv'], 'partial_fusionnet')])
 @pytest.mark.parametrize('model', ['resnet18', 'resnet50'])
 def test_state_dict_keys_match_reference(pkg, tag, extra, module, model):
     """Checkpoint interchange (log.py:32-40): same keys, order and shapes as the reference factories."""

@@ -45,7 +45,7 @@ def test_head_matches_reference():
 
 
 STEP_CASES = ['depth_r18_b2', 'depth_r18_odd_b1', 'depthonly_r18_b2', 'fusion_r18_b2', 'partial_r18_b2',
-              'depth_r50_b2', 'fusion_r50_b1', 'partial_r50_b1']
+              'depth_r50_b2', 'fusion_r50_b1', 'partial_r50_b1', 'pfusion_r18_b2', 'pfusion_r50_b1']
 
 
 @pytest.mark.parametrize('case', STEP_CASES)
