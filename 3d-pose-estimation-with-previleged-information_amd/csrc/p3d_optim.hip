@@ -234,6 +234,62 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(const T* __restrict__ s
     }
 }
 
+// General crop re-projection (cameralib.reproject_image, cameralib.py:378-443): per sample 20 floats
+//   ray[9]  : crop pixel (x, y, 1) -> direction in the OLD camera's frame  (R_old R_new^-1 K_new^-1; the whole homography when undistorted)
+//   k[6]    : rows 0 and 1 of the old intrinsic matrix (identity rows when ray already is the homography)
+//   dist[5] : OpenCV k1 k2 p1 p2 k3 of the old camera (zeros = none), applied as cameralib.project_points (:636-659)
+// Bilinear taps with constant border 0 as in warp_crops_kernel; round_u8 rounds like cv2's uint8 output.
+template <typename T>
+__global__ __launch_bounds__(256) void reproject_crops_kernel(const T* __restrict__ src, const float* __restrict__ params, float* __restrict__ dst, int Hs,
+                                                              int Ws, int C, int Ho, int Wo, int round_u8) {
+    const int b = blockIdx.y;
+    const float* q = params + b * 20;
+    const T* img = src + (size_t)b * Hs * Ws * C;
+    float* out = dst + (size_t)b * C * Ho * Wo;
+    const bool distorted = q[15] != 0.f || q[16] != 0.f || q[17] != 0.f || q[18] != 0.f || q[19] != 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Ho * Wo; i += gridDim.x * blockDim.x) {
+        const float x = (float)(i % Wo), y = (float)(i / Wo);
+        const float w = q[6] * x + q[7] * y + q[8];
+        float px = (q[0] * x + q[1] * y + q[2]) / w, py = (q[3] * x + q[4] * y + q[5]) / w;
+        if (distorted) {
+            const float r2 = px * px + py * py, r4 = r2 * r2, r6 = r4 * r2;
+            const float f = q[15] * r2 + q[16] * r4 + q[19] * r6 + 1.f + px * (2.f * q[18]) + py * (2.f * q[17]);
+            px = px * f + r2 * q[18];
+            py = py * f + r2 * q[17];
+        }
+        const float sx = q[9] * px + q[10] * py + q[11], sy = q[12] * px + q[13] * py + q[14];
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        const bool finite = sx == sx && sy == sy && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            if (finite) {
+                const bool xl = (unsigned)x0 < (unsigned)Ws, xr = (unsigned)(x0 + 1) < (unsigned)Ws;
+                const bool yt = (unsigned)y0 < (unsigned)Hs, yb = (unsigned)(y0 + 1) < (unsigned)Hs;
+                const float p00 = (xl && yt) ? (float)img[((size_t)y0 * Ws + x0) * C + c] : 0.f;
+                const float p01 = (xr && yt) ? (float)img[((size_t)y0 * Ws + x0 + 1) * C + c] : 0.f;
+                const float p10 = (xl && yb) ? (float)img[((size_t)(y0 + 1) * Ws + x0) * C + c] : 0.f;
+                const float p11 = (xr && yb) ? (float)img[((size_t)(y0 + 1) * Ws + x0 + 1) * C + c] : 0.f;
+                v = (p00 * (1.f - ax) + p01 * ax) * (1.f - ay) + (p10 * (1.f - ax) + p11 * ax) * ay;
+                if (round_u8) v = rintf(v);
+            }
+            out[(size_t)c * Ho * Wo + i] = v;
+        }
+    }
+}
+
+// depth_datasets.enhance_ntu / enhance_pku (depth_datasets.py:39-56), preceded by the optional utils.to_depth division (utils.py:68-75)
+__global__ __launch_bounds__(256) void enhance_depth_kernel(float* __restrict__ x, const float* __restrict__ factor, size_t n, float unit, float threshold,
+                                                            int nexponent) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = x[i];
+        if (factor) v = v / factor[i];
+        v = v / unit;
+        x[i] = nexponent ? (v >= threshold ? expf(-v) : 0.f) : v / 3.0f;
+    }
+}
+
 }  // namespace p3d
 
 using namespace p3d;
@@ -247,6 +303,25 @@ int32_t p3d_warp_crops(const void* src, int32_t src_is_u8, const float* homograp
     if (src_is_u8) hipLaunchKernelGGL(warp_crops_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, homography, dst, Hs, Ws, C, Ho, Wo);
     else hipLaunchKernelGGL(warp_crops_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, homography, dst, Hs, Ws, C, Ho, Wo);
     return check_launch("warp_crops");
+}
+
+int32_t p3d_reproject_crops(const void* src, int32_t src_is_u8, const float* params20, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                            int32_t Ho, int32_t Wo, int32_t round_u8, void* stream) {
+    P3D_REQUIRE(src && params20 && dst && B > 0 && Hs > 0 && Ws > 0 && C > 0 && Ho > 0 && Wo > 0, "reproject_crops: bad argument");
+    dim3 grid((unsigned)(ceil_div((int64_t)Ho * Wo, 256) < 256 ? ceil_div((int64_t)Ho * Wo, 256) : 256), (unsigned)B);
+    if (src_is_u8)
+        hipLaunchKernelGGL(reproject_crops_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, params20, dst, Hs, Ws, C, Ho, Wo,
+                           round_u8);
+    else
+        hipLaunchKernelGGL(reproject_crops_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, params20, dst, Hs, Ws, C, Ho, Wo, 0);
+    return check_launch("reproject_crops");
+}
+
+int32_t p3d_enhance_depth(float* x, const float* factor, int64_t n, float threshold, int32_t nexponent, void* stream) {
+    P3D_REQUIRE(x && n > 0, "enhance_depth: bad argument");
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    hipLaunchKernelGGL(enhance_depth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, factor, (size_t)n, (float)(10.0 / 255.0), threshold, nexponent);
+    return check_launch("enhance_depth");
 }
 
 int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream) {

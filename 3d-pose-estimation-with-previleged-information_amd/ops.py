@@ -648,6 +648,33 @@ def warp_crops(frames, homography, out_hw):
     return out
 
 
+def reproject_crops(frames, params20, out_hw, round_u8=True):
+    """Batch of cameralib.reproject_image calls (cameralib.py:378-443): frames [B,Hs,Ws,C] uint8 / fp32 as decoded, params20 [B,20] fp32
+    (cameralib.reproject_params) -> [B,C,Ho,Wo] fp32."""
+    if not frames.is_cuda or frames.dtype not in (torch.uint8, torch.float32) or frames.dim() != 4:
+        raise P3DError('reproject_crops: frames must be a [B,Hs,Ws,C] uint8 / fp32 tensor on the HIP device')
+    _need_gpu(params20)
+    frames, params20 = frames.contiguous(), params20.contiguous()
+    b, hs, ws, c = frames.shape
+    if tuple(params20.shape) != (b, 20) or params20.dtype != torch.float32:
+        raise P3DError('reproject_crops: params20 must be fp32 [B,20]')
+    ho, wo = out_hw
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=frames.device)
+    check(lib().p3d_reproject_crops(_p(frames), int(frames.dtype == torch.uint8), _p(params20), _p(out), b, hs, ws, c, ho, wo, int(bool(round_u8)),
+                                    _stream()), 'p3d_reproject_crops')
+    return out
+
+
+def enhance_depth_(crops, threshold, nexponent, factor=None):
+    """In place: depth_datasets.enhance_ntu / enhance_pku (depth_datasets.py:39-56) on PNG-unit depth crops, after the optional utils.to_depth
+    division by `factor` (same shape)."""
+    _need_gpu(crops, factor)
+    if crops.dtype != torch.float32 or not crops.is_contiguous() or (factor is not None and (factor.shape != crops.shape or not factor.is_contiguous())):
+        raise P3DError('enhance_depth_: contiguous fp32 crops (and factor of the same shape) expected')
+    check(lib().p3d_enhance_depth(_p(crops), _p(factor), crops.numel(), float(threshold), int(bool(nexponent)), _stream()), 'p3d_enhance_depth')
+    return crops
+
+
 def conv_bn_eval(x, conv, bn, res=None, relu=False):
     """Inference only (no autograd): conv (no bias) + BatchNorm with frozen statistics (+ residual, + ReLU) as one kernel launch
     (model.eval() forward of a residual block, depthnet.py:42-56,98-116)."""

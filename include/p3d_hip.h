@@ -201,6 +201,14 @@ int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour,
  * constant border 0; uint8 sources are rounded like cv2's uint8 output.  homography: [B][3][3] fp32 (device), new image -> old image. */
 int32_t p3d_warp_crops(const void* src, int32_t src_is_u8, const float* homography, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
                        int32_t Ho, int32_t Wo, void* stream);
+/* cameralib.reproject_image general case (cameralib.py:378-443): like p3d_warp_crops but through the OLD camera's lens model.  params20 = B x
+ * { ray[9] (crop pixel -> old-camera direction; the full homography when undistorted), k[6] (rows 0,1 of the old intrinsics; identity rows
+ * with a homography), dist[5] (k1 k2 p1 p2 k3, cameralib.project_points :636-659; zeros = none) } on the device.  round_u8: round uint8 sources like cv2. */
+int32_t p3d_reproject_crops(const void* src, int32_t src_is_u8, const float* params20, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                            int32_t Ho, int32_t Wo, int32_t round_u8, void* stream);
+/* depth_datasets.enhance_ntu / enhance_pku (depth_datasets.py:39-56) in place on PNG-unit depth crops (0..1): v = x / (10/255);
+ * nexponent ? exp(-v) * (v >= threshold) : v / 3.  factor (nullable, same shape): utils.to_depth's divisor map (utils.py:68-75), applied first. */
+int32_t p3d_enhance_depth(float* x, const float* factor, int64_t n, float threshold, int32_t nexponent, void* stream);
 /* transforms.ToTensor() + Normalize(mean, std) of the loader (depth_datasets.py:78-79,91-93), in place on [B,3,H,W] holding 0..255:
  * x = (x / 255 - mean[c]) / std[c]; mean3 / std3 are HOST pointers to 3 floats */
 int32_t p3d_normalize_rgb(float* img, int32_t B, int32_t HW, const float* mean3, const float* std3, void* stream);

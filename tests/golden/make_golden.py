@@ -466,13 +466,70 @@ def gen_state_keys():
     print('state_keys.json', list(inv))
 
 
+def gen_camera():
+    """The reference's cameralib.Camera driven through the camera edits of get_input_image (depth_datasets.py:176-191) and the point transforms
+    parse_sample uses.  cv2 is absent, so the two cv2-backed methods cannot run: image_to_camera (-> turn_towards(image point)) is replaced by
+    turn_towards(target_world_point=...) with the world point given as INPUT, and the remap itself is not driven.  Everything recorded below
+    is computed by the reference's own numpy code."""
+    import cameralib
+    rng = np.random.Generator(np.random.PCG64(77))
+    out, meta = {}, []
+    for i in range(4):
+        axis = rng.standard_normal(3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0.2, 1.2)
+        kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        rot = np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+        centre = rng.standard_normal(3) * 500
+        intr = np.array([[1050 + 20 * i, 0, 960 + 5 * i], [0, 1065 - 10 * i, 540 - 3 * i], [0, 0, 1]], np.float64)
+        dist = None if i == 0 else np.array([0.08, -0.12, 0.002 * i, -0.001 * i, 0.03]) * (1 if i < 3 else -1)
+        cam = cameralib.Camera(centre, rot, intr, dist, world_up=(0, 0, 1) if i % 2 == 0 else (0, -1, 0))
+        world = centre + (rot.T @ (rng.standard_normal((17, 3)) * [300, 500, 200] + [0, 0, 3000]).T).T
+        target = world.mean(axis=0)
+        side = 256
+        name = 'cam%d' % i
+        out[name + '.in'] = np.concatenate([centre, rot.reshape(-1), intr.reshape(-1), np.zeros(5) if dist is None else dist, cam.world_up])
+        out[name + '.world'] = world
+        out[name + '.target'] = target
+        out[name + '.w2c'] = cam.world_to_camera(world)
+        out[name + '.w2i'] = cam.world_to_image(world)
+        out[name + '.c2w'] = cam.camera_to_world(cam.world_to_camera(world))
+        new = cam.copy()
+        new.turn_towards(target_world_point=target)
+        out[name + '.R_turn'] = new.R.copy()
+        new.undistort()
+        new.square_pixels()
+        out[name + '.K_square'] = np.asarray(new.intrinsic_matrix).copy()
+        far = new.world_to_image(world[:2])
+        new.zoom(side / np.linalg.norm(far[0] - far[1]))
+        new.center_principal_point((side, side))
+        new.zoom(1.07)
+        if i % 2:
+            new.horizontal_flip()
+        out[name + '.K_new'] = np.asarray(new.intrinsic_matrix).copy()
+        out[name + '.R_new'] = new.R.copy()
+        out[name + '.new_w2c'] = new.world_to_camera(world)
+        out[name + '.new_c2i'] = new.camera_to_image(new.world_to_camera(world))
+        out[name + '.back_rotate'] = cam.R @ new.R.T
+        und = cam.copy(); und.undistort()
+        out[name + '.homography'] = cameralib.get_homography(und, new)
+        pts = rng.uniform(0, 1000, size=(6, 2)).astype(np.float32)
+        out[name + '.pts'] = pts
+        out[name + '.pts_fast'] = cameralib.reproject_points_fast(pts, und, new)
+        meta.append(dict(name=name, distorted=dist is not None, flipped=bool(i % 2), side=side))
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'camera.npz'), **out)
+    print('camera.npz', len(meta), 'cameras')
+
+
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'camera', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
+        elif t == 'camera':
+            gen_camera()
         elif t == 'head':
             gen_head()
         elif t == 'legacy':

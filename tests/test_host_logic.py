@@ -130,7 +130,7 @@ def test_synthetic_loader_contract(pkg):
     assert float((depth == 0).float().mean()) > 0.2                         # ~30 % holes feed the partial-conv mask
     rgb = pkg.datasets.data_loader(args, 'valid', pkg.utils.get_info())
     assert len(next(iter(rgb))) == 4                                        # (color, cam, valid, back_rotate)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                                  # neither -synthetic nor a metadata.json with the dataset root
         pkg.depth_datasets.data_loader(parse(pkg, 'resnet18'), 'train', pkg.utils.get_info())
 
 
