@@ -13,7 +13,7 @@ def __getattr__(name):
     # torch-dependent submodules are imported on first use so that numpy-only helpers stay light
     import importlib
     if name in ('ops', 'nn', 'optim', 'dist', 'utils', 'opts', 'depthnet', 'resnet', 'fusionnet', 'partial_conv',
-                'partial_depthnet', 'partial_fusionnet', 'cameralib', 'crops', 'depth_train', 'depth_main', 'depth_datasets', 'datasets', 'joint_settings', '_lib', 'log', 'train', 'main',
+                'partial_depthnet', 'partial_fusionnet', 'cameralib', 'crops', 'mat_utils', 'depth_train', 'depth_main', 'depth_datasets', 'datasets', 'joint_settings', '_lib', 'log', 'train', 'main',
                 'augment', 'graphed', 'ops_half'):
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

@@ -53,6 +53,9 @@ SIGNATURES = {
     'p3d_softargmax3d_fwd': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_softargmax3d_bwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_pose_loss_fwd_bwd': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _f32, _i32, _f32, _ptr, _ptr]),
+    'p3d_masked_loss_fwd_bwd': (_i32, [_ptr] * 5 + [_i32, _i32, _i32, _ptr, _ptr]),
+    'p3d_recon_cam_fwd': (_i32, [_ptr] * 4 + [_i32, _i32, _ptr]),
+    'p3d_recon_cam_bwd': (_i32, [_ptr] * 6 + [_i32, _i32, _ptr]),
     'p3d_l2norm_sq_accum': (_i32, [_ptr, _i64, _ptr, _ptr]),
     'p3d_adam_step': (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _ptr, _f32, _ptr]),
     'p3d_adam_step_dev': (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _f32, _ptr, _f32, _i32, _ptr, _ptr]),

@@ -273,6 +273,121 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// criterion(pred[valid], target[valid]) with mean reduction over the selected rows x C (train.py:94,112: the image-space and the
+// reconstruction losses of joint_train); dpred = d loss / d pred.  One 256-thread block.
+__global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ valid,
+                                                          float* __restrict__ loss, float* __restrict__ dpred, int rows, int C, int criterion,
+                                                          const float* __restrict__ count_override) {
+    __shared__ double red[8];
+    const int t = threadIdx.x;
+    double cnt = 0.0, acc = 0.0;
+    for (int i = t; i < rows; i += 256) cnt += valid[i] ? (double)C : 0.0;
+    cnt = wave_sum(cnt);
+    if ((t & 63) == 0) red[t >> 6] = cnt;
+    __syncthreads();
+    cnt = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float denom = (count_override != nullptr && count_override[0] > 0.f) ? count_override[0] : (float)(cnt > 0.0 ? cnt : 1.0);
+    for (int i = t; i < rows * C; i += 256) {
+        float per = 0.f, dper = 0.f;
+        if (valid[i / C]) {
+            const float diff = pred[i] - target[i];
+            const float ad = fabsf(diff);
+            if (criterion == 0) {
+                if (ad < 1.f) { per = 0.5f * diff * diff; dper = diff; }
+                else { per = ad - 0.5f; dper = diff > 0.f ? 1.f : -1.f; }
+            } else if (criterion == 1) {
+                per = ad; dper = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            } else {
+                per = diff * diff; dper = 2.f * diff;
+            }
+        }
+        acc += per;
+        dpred[i] = dper / denom;
+    }
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / denom);
+}
+
+// ---------------------------------------------------------------------------------------------
+// utils.get_recon_cam (utils.py:335-366): least-squares position t of the unknown reference point such that the root-relative pose, moved by t,
+// projects onto the estimated image coordinates:  rows (1, 0, -nx_j | nx_j z_j - x_j), (0, 1, -ny_j | ny_j z_j - y_j) with n_j the first two
+// components of K^-1 (u_j, v_j, 1);  t = (A^T A)^-1 A^T b in closed form (A^T A depends on sum n, sum |n|^2 only);  recon_j = relat_j + t.
+// One thread per sample, double precision inside (B <= a few hundred, J <= a few dozen: launch-latency sized work).
+struct ReconSys { double kinv[6]; double m[9]; double t[3]; };
+
+__device__ inline void inv3_sym(const double* m, double* o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[8];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = o[1]; o[4] = (a * f - c * c) * id; o[5] = (b * c - a * e) * id;
+    o[6] = o[2]; o[7] = o[5]; o[8] = (a * d - b * b) * id;
+}
+
+__device__ inline void recon_solve(const float* __restrict__ sm, const float* __restrict__ rc, const float* __restrict__ K, int J, ReconSys& s) {
+    // rows 0 and 1 of K^-1 (bottom row of K is (0, 0, 1))
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5];
+    const double det = a * e - b * d;
+    s.kinv[0] = e / det; s.kinv[1] = -b / det; s.kinv[2] = (b * f - c * e) / det;
+    s.kinv[3] = -d / det; s.kinv[4] = a / det; s.kinv[5] = (c * d - a * f) / det;
+    double sx = 0, sy = 0, sq = 0, r0 = 0, r1 = 0, r2 = 0;
+    for (int j = 0; j < J; ++j) {
+        const double u = sm[2 * j], v = sm[2 * j + 1];
+        const double nx = s.kinv[0] * u + s.kinv[1] * v + s.kinv[2], ny = s.kinv[3] * u + s.kinv[4] * v + s.kinv[5];
+        const double x = rc[3 * j], y = rc[3 * j + 1], z = rc[3 * j + 2];
+        const double bx = nx * z - x, by = ny * z - y;
+        sx += nx; sy += ny; sq += nx * nx + ny * ny;
+        r0 += bx; r1 += by; r2 -= nx * bx + ny * by;
+    }
+    const double M[9] = {(double)J, 0, -sx, 0, (double)J, -sy, -sx, -sy, sq};
+    inv3_sym(M, s.m);
+    for (int i = 0; i < 3; ++i) s.t[i] = s.m[3 * i] * r0 + s.m[3 * i + 1] * r1 + s.m[3 * i + 2] * r2;
+}
+
+__global__ __launch_bounds__(64) void recon_cam_fwd_kernel(const float* __restrict__ spec_mat, const float* __restrict__ relat, const float* __restrict__ K,
+                                                           float* __restrict__ recon, int B, int J) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    ReconSys s;
+    recon_solve(spec_mat + (size_t)b * J * 2, relat + (size_t)b * J * 3, K + b * 9, J, s);
+    for (int i = 0; i < J * 3; ++i) recon[(size_t)b * J * 3 + i] = (float)((double)relat[(size_t)b * J * 3 + i] + s.t[i % 3]);
+}
+
+__global__ __launch_bounds__(64) void recon_cam_bwd_kernel(const float* __restrict__ drecon, const float* __restrict__ spec_mat, const float* __restrict__ relat,
+                                                           const float* __restrict__ K, float* __restrict__ dspec_mat, float* __restrict__ drelat, int B, int J) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* sm = spec_mat + (size_t)b * J * 2;
+    const float* rc = relat + (size_t)b * J * 3;
+    const float* g = drecon + (size_t)b * J * 3;
+    ReconSys s;
+    recon_solve(sm, rc, K + b * 9, J, s);
+    double gs[3] = {0, 0, 0};
+    for (int i = 0; i < J * 3; ++i) gs[i % 3] += g[i];
+    double w[3];
+    for (int i = 0; i < 3; ++i) w[i] = s.m[3 * i] * gs[0] + s.m[3 * i + 1] * gs[1] + s.m[3 * i + 2] * gs[2];
+    // d L / d M = -w t^T;  only M02 = M20 = -sum nx, M12 = M21 = -sum ny, M22 = sum |n|^2 vary
+    const double g02 = -(w[0] * s.t[2] + w[2] * s.t[0]), g12 = -(w[1] * s.t[2] + w[2] * s.t[1]), g22 = -w[2] * s.t[2];
+    for (int j = 0; j < J; ++j) {
+        const double u = sm[2 * j], v = sm[2 * j + 1];
+        const double nx = s.kinv[0] * u + s.kinv[1] * v + s.kinv[2], ny = s.kinv[3] * u + s.kinv[4] * v + s.kinv[5];
+        const double x = rc[3 * j], y = rc[3 * j + 1], z = rc[3 * j + 2];
+        const double dnx = w[0] * z - w[2] * (2 * nx * z - x) - g02 + 2 * g22 * nx;
+        const double dny = w[1] * z - w[2] * (2 * ny * z - y) - g12 + 2 * g22 * ny;
+        dspec_mat[((size_t)b * J + j) * 2] = (float)(s.kinv[0] * dnx + s.kinv[3] * dny);
+        dspec_mat[((size_t)b * J + j) * 2 + 1] = (float)(s.kinv[1] * dnx + s.kinv[4] * dny);
+        float* o = drelat + ((size_t)b * J + j) * 3;
+        o[0] = (float)(g[3 * j] - w[0] + w[2] * nx);
+        o[1] = (float)(g[3 * j + 1] - w[1] + w[2] * ny);
+        o[2] = (float)(g[3 * j + 2] + w[0] * nx + w[1] * ny - w[2] * (nx * nx + ny * ny));
+    }
+}
+
 }  // namespace p3d
 
 using namespace p3d;
@@ -332,6 +447,28 @@ int32_t p3d_pose_loss_fwd_bwd(const float* relat, const float* true_cam, const u
     hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, relat, true_cam, true_val, loss, spec_cam, drelat, B, J,
                        key_index, loss_div, criterion, loss_scale, count_override);
     return check_launch("pose_loss");
+}
+
+int32_t p3d_masked_loss_fwd_bwd(const float* pred, const float* target, const uint8_t* valid, float* loss, float* dpred, int32_t rows, int32_t C,
+                                int32_t criterion, const float* count_override, void* stream) {
+    P3D_REQUIRE(pred && target && valid && loss && dpred && rows > 0 && C > 0, "masked_loss: bad argument");
+    P3D_REQUIRE(criterion >= 0 && criterion <= 2, "masked_loss: bad criterion %d", criterion);
+    hipLaunchKernelGGL(masked_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, valid, loss, dpred, rows, C, criterion, count_override);
+    return check_launch("masked_loss");
+}
+
+int32_t p3d_recon_cam_fwd(const float* spec_mat, const float* relat_cam, const float* intrinsics, float* recon, int32_t B, int32_t J, void* stream) {
+    P3D_REQUIRE(spec_mat && relat_cam && intrinsics && recon && B > 0 && J >= 2, "recon_cam_fwd: bad argument (at least two joints are needed)");
+    hipLaunchKernelGGL(recon_cam_fwd_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, spec_mat, relat_cam, intrinsics, recon, B, J);
+    return check_launch("recon_cam_fwd");
+}
+
+int32_t p3d_recon_cam_bwd(const float* drecon, const float* spec_mat, const float* relat_cam, const float* intrinsics, float* dspec_mat, float* drelat_cam,
+                          int32_t B, int32_t J, void* stream) {
+    P3D_REQUIRE(drecon && spec_mat && relat_cam && intrinsics && dspec_mat && drelat_cam && B > 0 && J >= 2, "recon_cam_bwd: bad argument");
+    hipLaunchKernelGGL(recon_cam_bwd_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, drecon, spec_mat, relat_cam, intrinsics,
+                       dspec_mat, drelat_cam, B, J);
+    return check_launch("recon_cam_bwd");
 }
 
 }  // extern "C"

@@ -540,6 +540,64 @@ def pose_loss(relat, true_cam, true_val, key_index, loss_div, criterion='SmoothL
     return PoseLossFn.apply(relat, true_cam, true_val, int(key_index), float(loss_div), criterion, count_override)
 
 
+class MaskedLossFn(torch.autograd.Function):
+    """criterion(pred.view(-1, C)[valid.view(-1)], target.view(-1, C)[valid.view(-1)]) with mean reduction (train.py:94,112)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, valid, criterion, count_override):
+        _need_gpu(pred, target)
+        if not valid.is_cuda:
+            raise P3DError('masked_loss: valid must be on the HIP device')
+        pred, target = pred.contiguous(), target.contiguous()
+        val = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.contiguous()
+        if val.dtype != torch.uint8 or pred.shape != target.shape or val.numel() * pred.shape[-1] != pred.numel():
+            raise P3DError('masked_loss: pred %s / target %s / valid %s do not match' % (tuple(pred.shape), tuple(target.shape), tuple(valid.shape)))
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        check(lib().p3d_masked_loss_fwd_bwd(_p(pred), _p(target), _p(val), _p(loss), _p(dpred), val.numel(), pred.shape[-1], CRITERIA[criterion],
+                                            _p(count_override), _stream()), 'p3d_masked_loss_fwd_bwd')
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dpred,) = ctx.saved_tensors
+        return dpred * dloss, None, None, None, None
+
+
+def masked_loss(pred, target, valid, criterion='SmoothL1', count_override=None):
+    return MaskedLossFn.apply(pred, target, valid, criterion, count_override)
+
+
+class ReconCamFn(torch.autograd.Function):
+    """utils.get_recon_cam (utils.py:335-366) with its analytic backward."""
+
+    @staticmethod
+    def forward(ctx, spec_mat, relat_cam, intrinsics):
+        _need_gpu(spec_mat, relat_cam, intrinsics)
+        spec_mat, relat_cam, intrinsics = spec_mat.contiguous(), relat_cam.contiguous(), intrinsics.contiguous().float()
+        b, j, _ = relat_cam.shape
+        if tuple(spec_mat.shape) != (b, j, 2) or tuple(intrinsics.shape) != (b, 3, 3) or relat_cam.shape[2] != 3:
+            raise P3DError('get_recon_cam: spec_mat %s / relat_cam %s / intrinsics %s' % (tuple(spec_mat.shape), tuple(relat_cam.shape), tuple(intrinsics.shape)))
+        recon = torch.empty_like(relat_cam)
+        check(lib().p3d_recon_cam_fwd(_p(spec_mat), _p(relat_cam), _p(intrinsics), _p(recon), b, j, _stream()), 'p3d_recon_cam_fwd')
+        ctx.save_for_backward(spec_mat, relat_cam, intrinsics)
+        return recon
+
+    @staticmethod
+    def backward(ctx, drecon):
+        spec_mat, relat_cam, intrinsics = ctx.saved_tensors
+        b, j, _ = relat_cam.shape
+        dspec, drelat = torch.empty_like(spec_mat), torch.empty_like(relat_cam)
+        check(lib().p3d_recon_cam_bwd(_p(drecon.contiguous()), _p(spec_mat), _p(relat_cam), _p(intrinsics), _p(dspec), _p(drelat), b, j, _stream()),
+              'p3d_recon_cam_bwd')
+        return dspec, drelat, None
+
+
+def recon_cam(spec_mat, relat_cam, intrinsics):
+    return ReconCamFn.apply(spec_mat, relat_cam, intrinsics)
+
+
 DISTILL_MODES = {'l2': 0, 'sigmoid': 1, 'bce': 2}
 
 

@@ -49,6 +49,34 @@ def decode(heatmap, depth_range):
     return ops.softargmax3d(heatmap.logits, heatmap.depth, heatmap.num_joints, heatmap.height, heatmap.width, depth_range)
 
 
+def get_deter_cam(spec_mat, relat_cam, intrinsics, valid=None):
+    """Test-time numpy twin of get_recon_cam (utils.py:298-332): the same least-squares placement, on the host after evaluation."""
+    spec_mat, relat_cam, intrinsics = (np.asarray(a) for a in (spec_mat, relat_cam, intrinsics))
+    batch, joints = spec_mat.shape[:2]
+    if valid is not None:
+        count = np.sum(valid, axis=1)
+        assert (count != 0).all() and (count != 1).all()
+    unproject = np.linalg.inv(intrinsics).transpose(0, 2, 1)
+    normalized = np.einsum('bij,bjk->bik', np.concatenate([spec_mat, np.ones((batch, joints, 1))], axis=-1), unproject)[:, :, :2]
+    A = np.concatenate([np.tile(np.eye(2), (batch, joints, 1)), -normalized.reshape(batch, -1, 1)], axis=-1)
+    b = (normalized * relat_cam[:, :, 2:] - relat_cam[:, :, :2]).reshape(batch, -1, 1)
+    At = A.transpose(0, 2, 1)
+    refer = np.linalg.inv(At @ A) @ (At @ b)
+    return relat_cam + refer.transpose(0, 2, 1)
+
+
+def get_recon_cam(spec_mat, relat_cam, intrinsics, valid=None):
+    """Differentiable reconstruction of the reference-point location at train time (utils.py:335-366): least squares over ALL joints of
+    relat_cam + t projecting onto spec_mat under `intrinsics`; returns relat_cam + t, [B, J, 3].
+
+    The reference body asserts on a name `valid` that it never receives (utils.py:349-350, a NameError as shipped); here it is an optional
+    argument with the same two checks (every sample needs at least two valid joints).  Like the reference, the fit itself does not use it."""
+    if valid is not None:
+        count = valid.sum(dim=1)
+        assert bool((count != 0).all()) and bool((count != 1).all())
+    return ops.recon_cam(spec_mat, relat_cam, intrinsics)
+
+
 def get_attention(side_in, stride, image_coords, attention):
     """Distillation attention map (utils.py:14-42): sum over joints of exp(-r^2/5) around each joint's position on the
     side_out x side_out feature grid, normalised to max 1; all ones without -attention.  Host numpy, made in the loader."""

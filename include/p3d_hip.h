@@ -156,6 +156,17 @@ int32_t p3d_pose_loss_fwd_bwd(const float* relat, const float* true_cam, const u
                               float* spec_cam, float* drelat, int32_t B, int32_t J, int32_t key_index,
                               float loss_div, int32_t criterion, float loss_scale, const float* count_override, void* stream);
 
+/* criterion(pred[valid], target[valid]), mean over the selected rows x C (the image-space and reconstruction losses of train.py:94,112):
+ * pred/target [rows][C], valid [rows] bytes -> loss[1], dpred = d loss / d pred.  count_override as in p3d_pose_loss_fwd_bwd. */
+int32_t p3d_masked_loss_fwd_bwd(const float* pred, const float* target, const uint8_t* valid, float* loss, float* dpred, int32_t rows, int32_t C,
+                                int32_t criterion, const float* count_override, void* stream);
+
+/* utils.get_recon_cam (utils.py:335-366): differentiable least-squares placement of the root-relative pose relat_cam [B,J,3] such that it projects
+ * onto spec_mat [B,J,2] under intrinsics [B,3,3]: recon = relat_cam + (A^T A)^-1 A^T b.  bwd: gradients w.r.t. spec_mat and relat_cam. */
+int32_t p3d_recon_cam_fwd(const float* spec_mat, const float* relat_cam, const float* intrinsics, float* recon, int32_t B, int32_t J, void* stream);
+int32_t p3d_recon_cam_bwd(const float* drecon, const float* spec_mat, const float* relat_cam, const float* intrinsics, float* dspec_mat, float* drelat_cam,
+                          int32_t B, int32_t J, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.utils.clip_grad_norm_ + optim.Adam(weight_decay) on flat buffers (depth_train.py:455-456, :83)
  * ------------------------------------------------------------------------------------------ */

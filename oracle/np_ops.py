@@ -443,3 +443,75 @@ def warp_crop(image_hwc, homography, out_hw):
     if np.asarray(image_hwc).dtype == np.uint8:
         out = np.rint(out)
     return out.reshape(ho, wo, -1).transpose(2, 0, 1).astype(np.float32)
+
+
+# ---- legacy joint-space head (train.py:78-114) -------------------------------------------------------------------------------------
+def recon_cam(spec_mat, relat_cam, intrinsics):
+    """utils.get_recon_cam / get_deter_cam (utils.py:298-366), written with the explicit [2J x 3] system as the reference builds it.
+    Returns (recon, cache)."""
+    spec_mat, relat_cam, intrinsics = (np.asarray(a, np.float64) for a in (spec_mat, relat_cam, intrinsics))
+    batch, joints = spec_mat.shape[:2]
+    kinv = np.linalg.inv(intrinsics)
+    homog = np.concatenate([spec_mat, np.ones((batch, joints, 1))], -1)
+    normalized = np.einsum('bij,bkj->bik', homog, kinv)[:, :, :2]
+    A = np.concatenate([np.tile(np.eye(2), (batch, joints, 1)), -normalized.reshape(batch, -1, 1)], -1)
+    rhs = (normalized * relat_cam[:, :, 2:] - relat_cam[:, :, :2]).reshape(batch, -1, 1)
+    At = A.transpose(0, 2, 1)
+    minv = np.linalg.inv(At @ A)
+    refer = minv @ (At @ rhs)
+    return relat_cam + refer.transpose(0, 2, 1), (A, rhs, minv, refer, normalized, kinv, relat_cam)
+
+
+def recon_cam_bwd(drecon, cache):
+    """Gradients of recon_cam w.r.t. (spec_mat, relat_cam) by matrix calculus on the explicit system: t = M^-1 A^T b, M = A^T A."""
+    A, rhs, minv, refer, normalized, kinv, relat_cam = cache
+    drecon = np.asarray(drecon, np.float64)
+    batch, joints = drecon.shape[:2]
+    gsum = drecon.sum(axis=1)[:, :, None]                     # d L / d t
+    w = minv @ gsum                                           # M symmetric
+    dM = -w @ refer.transpose(0, 2, 1)
+    dA = A @ (dM + dM.transpose(0, 2, 1)) + rhs @ w.transpose(0, 2, 1)
+    drhs = (A @ w).reshape(batch, joints, 2)
+    dnorm = -dA[:, :, 2].reshape(batch, joints, 2) + drhs * relat_cam[:, :, 2:]
+    drelat = drecon.copy()
+    drelat[:, :, :2] -= drhs
+    drelat[:, :, 2] += (drhs * normalized).sum(-1)
+    dspec = np.einsum('bjk,bki->bji', dnorm, kinv[:, :2, :2])
+    return dspec, drelat
+
+
+def masked_loss(pred, target, valid, criterion='SmoothL1'):
+    """criterion(pred[valid], target[valid]) with mean reduction (train.py:94,100,112) -> (loss, dpred)."""
+    pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    mask = np.asarray(valid, bool)[..., None]
+    diff = (pred - target) * mask
+    count = max(mask.sum() * pred.shape[-1], 1)
+    if criterion == 'SmoothL1':
+        per = np.where(np.abs(diff) < 1, 0.5 * diff * diff, np.abs(diff) - 0.5)
+        dper = np.where(np.abs(diff) < 1, diff, np.sign(diff))
+    elif criterion == 'L1':
+        per, dper = np.abs(diff), np.sign(diff)
+    else:
+        per, dper = diff * diff, 2 * diff
+    return float((per * mask).sum() / count), dper * mask / count
+
+
+def softargmax2d(z, map_range):
+    """mat_utils.to_heatmap + decode (mat_utils.py:32-56): softmax over H*W, expectation against linspace(0, 1, n) * map_range."""
+    z = np.asarray(z, np.float64)
+    b, j, h, w = z.shape
+    flat = z.reshape(b, j, -1)
+    heat = np.exp(flat - flat.max(-1, keepdims=True))
+    heat = (heat / heat.sum(-1, keepdims=True)).reshape(b, j, h, w)
+    gx, gy = np.linspace(0, 1, w), np.linspace(0, 1, h)
+    coords = np.stack([(heat.sum(2) * gx).sum(-1), (heat.sum(3) * gy).sum(-1)], -1) * map_range
+    return coords, heat
+
+
+def softargmax2d_bwd(dcoords, heat, coords, map_range):
+    b, j, h, w = heat.shape
+    gx, gy = np.linspace(0, 1, w) * map_range, np.linspace(0, 1, h) * map_range
+    dc = np.asarray(dcoords, np.float64)
+    field = dc[:, :, 0, None, None] * (gx[None, None, None, :] - coords[:, :, 0, None, None]) + \
+        dc[:, :, 1, None, None] * (gy[None, None, :, None] - coords[:, :, 1, None, None])
+    return heat * field

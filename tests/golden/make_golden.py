@@ -466,6 +466,98 @@ def gen_state_keys():
     print('state_keys.json', list(inv))
 
 
+def joint_batch(batch, side, seed):
+    spec_ = importlib.util.spec_from_file_location('joint_inputs', os.path.join(HERE, 'joint_inputs.py'))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    return mod.joint_batch(synth, batch, side, seed)
+
+
+def gen_joint():
+    """Legacy joint-space path (train.py:54-145): utils.get_recon_cam / get_deter_cam (their body reads a global `valid` that is never defined,
+    utils.py:311-312,349-350 -- the harness sets utils.valid to the batch's mask, nothing else is touched), mat_utils.to_heatmap / decode, and one
+    unmodified Trainer.joint_train iteration with -do_track at epoch 2 (args.thresh_* added to the namespace: opts.py lacks them, train.py:45-49)."""
+    args = ref_args('resnet18', 128, ['-joint_space', '-do_track'])
+    args.thresh_solid, args.thresh_close, args.thresh_rough = 40.0, 80.0, 150.0
+    import utils
+    import mat_utils
+    import train
+    import resnet
+    import depth_main
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(31))
+    b, j = 3, 17
+    intr = np.tile(np.array([[300.0, 0.5, 128], [0, 310.0, 120], [0, 0, 1]], np.float32), (b, 1, 1))
+    intr[1, 0, 0] = 280
+    relat = (rng.standard_normal((b, j, 3)) * 250).astype(np.float32)
+    root = np.array([[100, -50, 3200], [-300, 120, 2500], [20, 10, 4100]], np.float32)
+    cam = relat + root[:, None]
+    spec_mat = (cam[:, :, :2] / cam[:, :, 2:] * intr[:, None, [0, 1], [0, 1]] + intr[:, None, :2, 2] + rng.standard_normal((b, j, 2)) * 1.5).astype(np.float32)
+    valid = rng.random((b, j)) > 0.2
+    valid[:, :2] = True
+    utils.valid = torch.from_numpy(valid)
+    sm, rc = torch.from_numpy(spec_mat).requires_grad_(True), torch.from_numpy(relat).requires_grad_(True)
+    recon = utils.get_recon_cam(sm, rc, torch.from_numpy(intr))
+    drecon = rng.standard_normal((b, j, 3)).astype(np.float32)
+    recon.backward(torch.from_numpy(drecon))
+    utils.valid = valid
+    deter = utils.get_deter_cam(spec_mat, relat, intr)
+    out.update({'recon.spec_mat': spec_mat, 'recon.relat': relat, 'recon.intr': intr, 'recon.valid': valid, 'recon.out': tnp(recon),
+                'recon.drecon': drecon, 'recon.dspec_mat': tnp(sm.grad), 'recon.drelat': tnp(rc.grad), 'recon.deter': deter})
+    z = (rng.standard_normal((2, j, 8, 8)) * 3).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    coords = mat_utils.decode(mat_utils.to_heatmap(zt, j, 8, 8), 128)
+    dc = rng.standard_normal((2, j, 2)).astype(np.float32)
+    coords.backward(torch.from_numpy(dc))
+    out.update({'mat.z': z, 'mat.coords': tnp(coords), 'mat.dc': dc, 'mat.dz': tnp(zt.grad)})
+    true_mat = spec_mat[:2] * (120.0 / 256)
+    st = mat_utils.analyze(tnp(coords), true_mat, valid[:2], 128)
+    out['mat.stats'] = np.array(json.dumps({k: float(v) for k, v in st.items()}))
+    out['mat.true'] = true_mat
+
+    model = resnet.resnet18(args)
+    load_det_weights(model, seed=0)
+    info = depth_main.get_info()
+    tr = train.Trainer(args, model, info)
+
+    class Py2Int(int):
+        """train.py is Python 2 code: `side_out = (self.side_in - 1) / self.stride + 1` (train.py:62) relies on int / int flooring.  Giving the
+        stride operand Python 2's division keeps the file unmodified and its arithmetic as written."""
+
+        def __rtruediv__(self, other):
+            return other // int(self)
+    tr.stride = Py2Int(tr.stride)
+    c, cam_b, mat_b, tv, intr_b = joint_batch(2, 128, 0)
+    utils.valid = torch.from_numpy(tv)
+    loader = [tuple(torch.from_numpy(a) for a in (c, cam_b, mat_b, tv, intr_b))]
+    rec = {}
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm, *a, **k):
+        params = list(params)
+        rec['grads'] = [tnp(p.grad) for p in params]
+        total = orig_clip(params, max_norm, *a, **k)
+        rec['clip_total'] = float(total)
+        return total
+    train.nn.utils.clip_grad_norm_ = clip
+    tr.model.train()
+    tr.adapt_learn_rate(2)
+    record = tr.joint_train(2, loader, torch.device('cpu'))
+    train.nn.utils.clip_grad_norm_ = orig_clip
+    names = [n for n, _ in model.named_parameters()]
+    sd = {k: tnp(v) for k, v in model.state_dict().items()}
+    rs = np.random.Generator(np.random.PCG64(5))
+    idx = {n: rs.integers(0, sd[n].size, size=4) for n in names}
+    out.update({'step.meta': np.array(json.dumps(dict(names=names, lr=tr.optimizer.param_groups[0]['lr'], record={k: float(v) for k, v in record.items()},
+                                                      clip_total=rec['clip_total']))),
+                'step.grad_norms': np.array([np.linalg.norm(g.astype(np.float64)) for g in rec['grads']]),
+                'step.param_norms': np.array([np.linalg.norm(sd[n].astype(np.float64)) for n in names]),
+                'step.param_samples': np.array([sd[n].reshape(-1)[idx[n]] for n in names]),
+                'step.sample_idx': np.array([idx[n] for n in names])})
+    np.savez_compressed(os.path.join(HERE, 'joint.npz'), **out)
+    print('joint.npz', record, rec['clip_total'])
+
+
 def gen_camera():
     """The reference's cameralib.Camera driven through the camera edits of get_input_image (depth_datasets.py:176-191) and the point transforms
     parse_sample uses.  cv2 is absent, so the two cv2-backed methods cannot run: image_to_camera (-> turn_towards(image point)) is replaced by
@@ -524,10 +616,12 @@ def gen_camera():
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'camera', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'camera', 'joint', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
+        elif t == 'joint':
+            gen_joint()
         elif t == 'camera':
             gen_camera()
         elif t == 'head':
