@@ -170,14 +170,15 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
 
 // dgamma / dbeta and the constants of pass 2: coef2[c] = {k1 = sum g / P, k2 = sum g xhat / P, 0, 0}.  grid C/16
 __global__ __launch_bounds__(256) void hbn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* dgamma, float* dbeta,
-                                                               float4* __restrict__ coef2, int P, int C, int accumulate) {
+                                                               float4* __restrict__ coef2, int P, int C, int accumulate, int frozen) {
     double s1, s2;
     int c;
     hbn_sum_partials(partial, nblk, C >> 3, C, s1, s2, c);
     if ((threadIdx.x >> 4) != 0 || c >= C) return;
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-    coef2[c] = make_float4((float)(s1 / P), (float)(s2 / P), 0.f, 0.f);
+    // frozen statistics (model.eval() BatchNorm inside a training step, depthnet.py:158-161): mean / var do not depend on x -> dx = sc * g
+    coef2[c] = frozen ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4((float)(s1 / P), (float)(s2 / P), 0.f, 0.f);
 }
 
 // backward pass 2: dx = gamma*invstd*(g - k1 - xhat*k2) (gamma*invstd is the forward's sc), dres = g
@@ -362,8 +363,8 @@ int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, con
     return check_launch("hbn_eval_fwd");
 }
 
-int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
-                          int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+static int32_t hbn_bwd_impl(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                            int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream, int frozen) {
     P3D_REQUIRE(dy && x && coef && dx && dgamma && dbeta, "hbn_train_bwd: null tensor");
     P3D_REQUIRE(!relu || y || !dres, "hbn_train_bwd: relu backward of a layer with a residual needs the forward output");
     P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_bwd: bad shape P=%d C=%d", P, C);
@@ -375,10 +376,28 @@ int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const fl
     hipLaunchKernelGGL(hbn_bwd_reduce_kernel, dim3(g.nblk, g.G / g.Gb), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
                        (const float4*)coef, partial, P, C, relu);
     hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, g.nblk, dgamma, dbeta, coef2,
-                       P, C, accumulate);
+                       P, C, accumulate, frozen);
     hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
                        (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)dres, P, C, relu);
     return check_launch("hbn_train_bwd");
+}
+
+int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                          int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return hbn_bwd_impl(dy, x, y, coef, dx, dres, dgamma, dbeta, P, C, relu, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+int32_t p3d_hbn_frozen_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return hbn_bwd_impl(dy, x, y, coef, dx, dres, dgamma, dbeta, P, C, relu, accumulate, workspace, workspace_bytes, stream, 1);
+}
+
+int32_t p3d_hbn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* coef, int32_t C, float eps,
+                          void* stream) {
+    P3D_REQUIRE(gamma && beta && running_mean && running_var && coef && C > 0, "hbn_eval_coef: bad argument");
+    hipLaunchKernelGGL(hbn_eval_coef_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var,
+                       (float4*)coef, C, eps);
+    return check_launch("hbn_eval_coef");
 }
 
 /* split == 0: cat[P][Ca+Cb] = concat(a[P][Ca], b[P][Cb]);  split != 0: a, b = the two channel windows of cat (backward of the concat) */

@@ -70,8 +70,6 @@ def to_test_worker(test_loader, no_depth, depth_only, do_fusion=False):
 class Trainer:
 
     def __init__(self, args, model, data_info, reducer_bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
-        if args.half_acc and args.do_teach and args.do_freeze:
-            raise NotImplementedError('-half_acc: frozen-BatchNorm distillation (-do_freeze) is not implemented in fp16')
         if args.semi_teach and not args.do_teach:
             raise ValueError('-semi_teach adds unlabelled pairs to the distillation loss: it needs -do_teach')
         self.model = model

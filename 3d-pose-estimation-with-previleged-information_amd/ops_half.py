@@ -259,7 +259,11 @@ class HBatchNormActFn(torch.autograd.Function):
         else:
             check(L.p3d_hbn_eval_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), n * h * w, c, eps, int(relu),
                                      _p(ws), ws.numel(), st), 'p3d_hbn_eval_fwd')
-            ctx.save_for_backward(x, None, None)
+            coef = None
+            if any(ctx.needs_input_grad[:3]):                       # frozen statistics inside a training step (-do_freeze)
+                coef = torch.empty((c, 4), dtype=torch.float32, device=x.device)
+                check(L.p3d_hbn_eval_coef(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(coef), c, eps, st), 'p3d_hbn_eval_coef')
+            ctx.save_for_backward(x, y if (relu and res is not None) else None, coef)
         ctx.cfg = (bool(relu), bool(training), res is not None)
         ctx.params = (gamma, beta)
         ctx.res_join = res_join
@@ -269,8 +273,6 @@ class HBatchNormActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, coef = ctx.saved_tensors
         relu, training, has_res = ctx.cfg
-        if not training:
-            raise P3DError('fp16 BatchNorm backward with frozen statistics is not implemented (-half_acc with -do_freeze)')
         dy = _cl(dy)
         n, c, h, w = x.shape
         L, st = lib(), _stream()
@@ -284,8 +286,9 @@ class HBatchNormActFn(torch.autograd.Function):
         dgamma = g_sink if direct else torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = b_sink if direct else torch.empty_like(dgamma)
         ws = workspace(x.device, L.p3d_hbn_workspace_bytes(c))
-        check(L.p3d_hbn_train_bwd(_p(dy), _p(x), _p(y), _p(coef), _p(dx), _p(dres) if (dres is not None and relu) else None,
-                                  _p(dgamma), _p(dbeta), n * h * w, c, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_hbn_train_bwd')
+        bwd = L.p3d_hbn_train_bwd if training else L.p3d_hbn_frozen_bwd
+        check(bwd(_p(dy), _p(x), _p(y), _p(coef), _p(dx), _p(dres) if (dres is not None and relu) else None,
+                  _p(dgamma), _p(dbeta), n * h * w, c, int(relu), int(direct), _p(ws), ws.numel(), st), 'p3d_hbn_train_bwd')
         if direct:
             dgamma = dbeta = None
             _grad_done(g_param)

@@ -269,6 +269,13 @@ int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, con
                          void* workspace, size_t workspace_bytes, void* stream);
 int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm with FROZEN statistics inside a training step (freeze_batchnorm, depthnet.py:158-161, under -do_freeze): the forward is
+ * p3d_hbn_eval_fwd; p3d_hbn_eval_coef writes the {scale, shift, mean, invstd} table of the running statistics for the backward, which is
+ * dx = scale * g (no batch-statistics terms), dgamma = sum g * xhat, dbeta = sum g with g the ReLU-masked incoming gradient. */
+int32_t p3d_hbn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float* coef, int32_t C, float eps,
+                          void* stream);
+int32_t p3d_hbn_frozen_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* torch.cat((x, y), dim=1) of the Fusion block (fusionnet.py:138) on NHWC fp16: split == 0 writes cat[P][Ca+Cb] from a[P][Ca], b[P][Cb];
  * split != 0 writes a and b from cat (the backward of the concat) */
 int32_t p3d_hconcat(void* a, void* b, void* cat, int64_t P, int32_t Ca, int32_t Cb, int32_t split, void* stream);

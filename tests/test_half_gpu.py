@@ -388,3 +388,66 @@ def test_hrelu_and_skip_relu_network(pkg):
         c, d, tc, tv = pkg.synth.make_batch(4, side=128, rank=2, step=0)
         losses.append(float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda())))
     assert losses[1] == pytest.approx(losses[0], rel=2e-3)
+
+
+def test_hbn_frozen_statistics_backward(pkg):
+    """BatchNorm in eval mode inside a training step (-do_freeze, depthnet.py:158-161) on fp16: forward with the running statistics, backward
+    dx = g * gamma / sqrt(var + eps), dgamma = sum g * xhat, dbeta = sum g; against torch autograd in fp32 on the same fp16-rounded inputs."""
+    torch.manual_seed(5)
+    for c, relu, with_res in ((64, True, True), (128, True, False), (256, False, False)):
+        bn = pkg.nn.BatchNorm2d(c).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 0.5)
+            bn.running_var.uniform_(0.5, 2.0)
+        bn.eval()
+        x = torch.randn(4, c, 9, 7, device='cuda').half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        res = torch.randn_like(x).requires_grad_(True) if with_res else None
+        before = (bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+        y = bn(x, res=res, relu=relu)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        assert torch.equal(bn.running_mean, before[0]) and torch.equal(bn.running_var, before[1]) and int(bn.num_batches_tracked) == before[2]
+        xf = x.detach().float().requires_grad_(True)
+        rf = res.detach().float().requires_grad_(True) if with_res else None
+        w, b = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.batch_norm(xf, bn.running_mean, bn.running_var, w, b, False, 0.1, bn.eps)
+        if with_res:
+            ref = ref + rf
+        if relu:
+            ref = torch.relu(ref)
+        ref.backward(dy.float())
+        assert (y.float() - ref).abs().max() < 2e-2
+        keep = (ref.detach().abs() > 2e-2) | (not relu)                       # away from the ReLU switch (fp16 rounding of y can flip the mask)
+        assert ((x.grad.float() - xf.grad).abs() * keep).max() < 2e-2
+        assert (bn.weight.grad - w.grad).abs().max() < 2e-2 * w.grad.abs().max() + 0.05
+        assert (bn.bias.grad - b.grad).abs().max() < 2e-2 * b.grad.abs().max() + 0.05
+        if with_res:
+            assert ((res.grad.float() - rf.grad).abs() * keep).max() < 1e-3
+
+
+def test_half_frozen_distillation_step(pkg):
+    """-do_teach -do_freeze under -half_acc: the distillation step runs with every BatchNorm of both networks frozen (running statistics stay
+    put) and its losses agree with the fp32 path on the same weights and batch."""
+    flags = ['-model', 'resnet18', '-suffix', 't', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1', '-num_joints', '17',
+             '-side_in', '128', '-do_teach', '-do_fusion', '-do_freeze']
+    records, stats = [], []
+    for extra in ([], ['-half_acc']):
+        args = pkg.opts.parse(flags + extra)
+        student, teacher = pkg.depthnet.resnet18(args, False), pkg.fusionnet.resnet18(args, False)
+        for net, seed in ((student, 0), (teacher, 1)):
+            det = pkg.synth.det_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in det.items()})
+        trainer = pkg.depth_train.Trainer(args, student.cuda(), pkg.utils.get_info())
+        trainer.set_teacher(teacher.cuda())
+        trainer.verbose = False
+        mean0 = student.bn1.running_mean.clone()
+        c, d, tc, tv = pkg.synth.make_batch(2, side=128, rank=11, step=0)
+        att = np.ones((2, 1, 8, 8), np.float32)
+        records.append(trainer.train(1, [tuple(torch.from_numpy(x) for x in (c, d, tc, tv, att))]))
+        assert torch.equal(student.bn1.running_mean, mean0)
+        stats.append(trainer.optimizer.steps_taken() if extra else 1)
+    assert stats[1] == 1
+    assert records[1]['cam_train_loss'] == pytest.approx(records[0]['cam_train_loss'], rel=5e-3)
+    assert records[1]['dist_train_loss'] == pytest.approx(records[0]['dist_train_loss'], rel=2e-2)

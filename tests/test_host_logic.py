@@ -111,8 +111,6 @@ def test_trainer_lr_schedule_and_guards(pkg):
         assert tr.optimizer.param_groups[0]['lr'] == pytest.approx(lr)
         assert tr.optimizer.param_groups[1]['lr'] == pytest.approx(lr)
     assert tr.data_info.key_index == 16 and tr.data_info.short_names[16] == 'pelv'
-    with pytest.raises(NotImplementedError):                                # fp16 does not cover frozen-BatchNorm distillation
-        pkg.depth_train.Trainer(parse(pkg, 'resnet18', ['-half_acc', '-do_teach', '-do_freeze']), net, pkg.utils.get_info())
     with pytest.raises(pkg._lib.P3DError):                                  # and, like fp32, only on the GPU
         pkg.depth_train.Trainer(parse(pkg, 'resnet18', ['-half_acc']), pkg.depth_main.create_model(args)[0], pkg.utils.get_info())
     # no CPU fallback: a forward on CPU tensors must fail loudly, not run on ATen
