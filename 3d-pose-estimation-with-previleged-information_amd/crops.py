@@ -77,12 +77,17 @@ def to_depth_divisor(depth_cam, side_in):
 
 
 class GpuCropLoader:
-    """Wraps the DataLoader over raw samples (dicts, see depth_datasets.Dataset.parse_sample) and yields the reference's tuples."""
+    """Wraps the DataLoader over raw samples (dicts, see depth_datasets.Dataset.parse_sample) and yields the reference's tuples.
 
-    def __init__(self, loader, side_in, raw_color, device=None):
+    The GPU stage of batch i+1 (pinned upload of the raw frames, ~8 ms for 64 1080p frames, + the crop kernels) is issued on a second HIP stream while
+    the trainer works on batch i on the launch stream, so the copy engine runs beside the convolutions; the consumer side only waits on an event."""
+
+    def __init__(self, loader, side_in, raw_color, device=None, prefetch=True):
         self.loader, self.side_in, self.raw_color = loader, side_in, raw_color
         self.device = device
         self.dataset = loader.dataset
+        self.prefetch = prefetch
+        self._stream = None
 
     def __len__(self):
         return len(self.loader)
@@ -96,22 +101,55 @@ class GpuCropLoader:
             raise ValueError('a batch mixes uint8 and fp32 source frames')
         return ops.reproject_crops(frames, params, (self.side_in, self.side_in), round_u8=flags.pop())
 
-    def __iter__(self):
+    def _stage(self, raw):
+        """Everything the GPU does for one batch, on the CURRENT stream -> the reference's tuple."""
         from . import ops
+        color = self._crops(raw['color_frame'], raw['color_params'], raw['color_round'])
+        if not self.raw_color:
+            ops.normalize_rgb_(color)                                          # ToTensor (/255) + Normalize (depth_datasets.py:90-92)
+        items = [color]
+        if 'depth_frame' in raw:
+            depth = self._crops(raw['depth_frame'], raw['depth_params'], raw['depth_round'])
+            divisor = raw['depth_divisor'].to(self.device).reshape(depth.shape).contiguous() if 'depth_divisor' in raw else None
+            ops.enhance_depth_(depth, float(raw['depth_threshold'][0]), bool(raw['nexponent'][0]), divisor)
+            items.append(depth)
+        items += [raw['true_cam'], raw['true_val']]
+        for key in ('back_rotate', 'atten_map'):
+            if key in raw:
+                items.append(raw[key])
+        return tuple(items)
+
+    def _stage_ahead(self, raw):
+        with torch.cuda.stream(self._stream):
+            items = self._stage(raw)
+            ready = torch.cuda.Event()
+            ready.record(self._stream)
+        return items, ready
+
+    def __iter__(self):
         if self.device is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
-        for raw in self.loader:
-            color = self._crops(raw['color_frame'], raw['color_params'], raw['color_round'])
-            if not self.raw_color:
-                ops.normalize_rgb_(color)                                          # ToTensor (/255) + Normalize (depth_datasets.py:90-92)
-            items = [color]
-            if 'depth_frame' in raw:
-                depth = self._crops(raw['depth_frame'], raw['depth_params'], raw['depth_round'])
-                divisor = raw['depth_divisor'].to(self.device).reshape(depth.shape).contiguous() if 'depth_divisor' in raw else None
-                ops.enhance_depth_(depth, float(raw['depth_threshold'][0]), bool(raw['nexponent'][0]), divisor)
-                items.append(depth)
-            items += [raw['true_cam'], raw['true_val']]
-            for key in ('back_rotate', 'atten_map'):
-                if key in raw:
-                    items.append(raw[key])
-            yield tuple(items)
+        if not self.prefetch:
+            for raw in self.loader:
+                yield self._stage(raw)
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        source = iter(self.loader)
+        ahead = None
+        for raw in source:
+            staged = self._stage_ahead(raw)
+            if ahead is not None:
+                yield self._hand_over(ahead)
+            ahead = staged
+        if ahead is not None:
+            yield self._hand_over(ahead)
+
+    def _hand_over(self, staged):
+        items, ready = staged
+        consumer = torch.cuda.current_stream(self.device)
+        consumer.wait_event(ready)
+        for item in items:
+            if torch.is_tensor(item) and item.is_cuda:
+                item.record_stream(consumer)                                       # allocated on the side stream, used on the launch stream
+        return items

@@ -290,6 +290,28 @@ def test_loader_matches_oracle_pipeline(pkg, tmp_path, kind, extra):
 
 
 @pytest.mark.gpu
+def test_prefetching_loader_equals_plain_loader(pkg, tmp_path):
+    """The side-stream prefetch hands out the same batches, in order, as the stage run inline on the launch stream -- also when the consumer keeps the
+    GPU busy between batches (the next batch is staged while the previous one is still being used)."""
+    meta, _, _ = make_site(str(tmp_path / 'pku'), 'pku')
+    info = pkg.utils.get_info()
+    args = site_args(pkg, 'pku', meta, ['-nexponent'])
+    got = []
+    for prefetch in (False, True):
+        loader = pkg.depth_datasets.data_loader(args, 'valid', info)
+        loader.prefetch = prefetch
+        batches = []
+        busy = torch.randn(2048, 2048, device='cuda')
+        for items in loader:
+            batches.append([t.clone() if torch.is_tensor(t) else t for t in items])
+            busy = busy @ busy * 1e-3                                         # keep the launch stream occupied
+        got.append(batches)
+    assert len(got[0]) == len(got[1]) == 2
+    for a, b in zip(*got):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
 def test_training_from_site_files(pkg, tmp_path):
     """One epoch of the fusion trainer and one evaluation pass fed by the file-backed loader (depth_main.main's inner loop, depth_main.py:147-160)."""
     meta, _, _ = make_site(str(tmp_path / 'ntu'), 'ntu')

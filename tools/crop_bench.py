@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--side', type=int, default=256)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--train', action='store_true', help='also time ResNet-50 training steps fed by GpuCropLoader (with / without the side-stream prefetch)')
     opt = ap.parse_args()
     rng = np.random.Generator(np.random.PCG64(0))
     cl, crops, ops = pkg.cameralib, pkg.crops, pkg.ops
@@ -64,7 +65,49 @@ def main():
     out['crops_per_s_gpu_stage'] = round(opt.batch / gpu_ms * 1e3)
     out['crops_per_s_with_upload'] = round(opt.batch / (gpu_ms + out['upload_ms']) * 1e3)
     out['upload_GBps'] = round((frames_c.numel() + frames_d.numel() * 4) / out['upload_ms'] / 1e6, 1)
+    if opt.train:
+        out.update(train_fed(opt, frames_c, frames_d, np.stack(params_c), np.stack(params_d)))
     print(json.dumps(out))
+
+
+def train_fed(opt, frames_c, frames_d, params_c, params_d):
+    """depthnet ResNet-50 training steps (the contract workload) whose batches come through GpuCropLoader from pinned raw frames, as the DataLoader
+    hands them over; decoding is not part of this (it happens in the worker processes)."""
+    cam, _, tc, tv = pkg.synth.make_batch(opt.batch, side=opt.side, rank=0, step=0)[0:4]
+    raw = dict(color_frame=frames_c, color_params=torch.from_numpy(params_c).pin_memory(), color_round=[True] * opt.batch,
+               depth_frame=frames_d, depth_params=torch.from_numpy(params_d).pin_memory(), depth_round=[False] * opt.batch,
+               depth_threshold=torch.full((opt.batch,), 0.1), nexponent=torch.ones(opt.batch, dtype=torch.bool),
+               true_cam=torch.from_numpy(tc), true_val=torch.from_numpy(tv))
+
+    class Source:
+        dataset = None
+
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for _ in range(self.n):
+                yield raw
+    args = pkg.opts.parse(['-model', 'resnet50', '-suffix', 'b', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1', '-num_joints', '17',
+                           '-side_in', str(opt.side), '-batch_size', str(opt.batch)])
+    model = pkg.depth_main.create_model(args)[0].cuda()
+    trainer = pkg.depth_train.Trainer(args, model, pkg.utils.get_info())
+    trainer.verbose = False
+    res = {}
+    for name, prefetch in (('inline', False), ('prefetch', True)):
+        loader = pkg.crops.GpuCropLoader(Source(opt.iters + 3), opt.side, False, prefetch=prefetch)
+        trainer.train(1, pkg.crops.GpuCropLoader(Source(3), opt.side, False, prefetch=prefetch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.train(1, loader)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / (opt.iters + 3)
+        res['train_ms_per_step_' + name] = round(ms, 2)
+        res['train_crops_per_s_' + name] = round(opt.batch / ms * 1e3)
+    return res
 
 
 if __name__ == '__main__':
