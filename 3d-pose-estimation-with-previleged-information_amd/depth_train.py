@@ -7,9 +7,10 @@
 
 One step = forward (conv/BN/pool kernels) -> fused soft-argmax head -> fused loss (value + gradient) ->
 backward -> [RCCL all-reduce of the flat gradient, overlapped] -> global-norm clip + Adam (2 launches).
-Differences from the reference, all documented in DESIGN.md: one process per GPU instead of
-nn.DataParallel; `-half_acc` and distillation (`-do_teach`) are "next" rows of the scope table and raise
-NotImplementedError; evaluation (`.test`) is implemented; metadata.json is optional (only `no_depth` / `thresholds` are read).
+Also here: evaluation (`.test`, depth_train.py:477-618), distillation (`-do_teach`: `set_teacher`, `distill_train`, `semi_train`; depth_train.py:115-283),
+`-half_acc` (fp16 NHWC kernels, fp32 masters, static loss scale and overflow skip on the device; depth_train.py:73-83,413-449).
+Differences from the reference, all documented in DESIGN.md: one process per GPU instead of nn.DataParallel; metadata.json is optional
+(`no_depth` / `thresholds` / `loader` / `root` are read when present).
 """
 import json
 import os

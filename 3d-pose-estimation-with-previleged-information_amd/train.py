@@ -28,7 +28,9 @@ class Trainer:
         self.data_info = data_info
         self.list_params = list(model.parameters())
         if args.half_acc:
-            raise NotImplementedError('-half_acc (fp16 copies + static loss scaling, train.py:20-28) is not implemented')
+            # train.py:20-28 halves the model, but its cam_train / joint_train (train.py:54-192) never cast the input nor scale the loss:
+            # the legacy trainer cannot train in fp16 as shipped.  depth_main's -half_acc is the working fp16 path.
+            raise NotImplementedError('-half_acc is not available in the legacy trainer (use depth_main -half_acc)')
         assert args.do_track <= args.joint_space                                  # main.py:72
         self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
         self.reducer = p3d_dist.GradReducer(self.optimizer)
