@@ -95,6 +95,7 @@ class Trainer:
 
         metadata = _load_metadata(args)
         self.no_depth = metadata['no_depth'][args.data_name] if metadata else False
+        self.data_name = args.data_name
         self.thresh = metadata['thresholds'][args.data_name] if metadata else None
 
         if self.semi_teach:
@@ -234,7 +235,12 @@ class Trainer:
         loss_avg = 0.0
         total = 0
         pending = []
-        for i_batch, (color_image, depth_image, true_cam, true_val) in enumerate(data_loader):
+        for i_batch, items in enumerate(data_loader):
+            if self.no_depth and len(items) == 3:     # RGB-only loader (`datasets`): the reference's loop (depth_train.py:385) only takes 4-tuples,
+                items = (items[0], None, items[1], items[2])     # i.e. cannot train on the datasets it marks no_depth; accepted here
+                if self.do_fusion or self.depth_only:
+                    raise ValueError('dataset %r has no depth stream (metadata.json no_depth): -do_fusion / -depth_only cannot train on it' % self.data_name)
+            color_image, depth_image, true_cam, true_val = items
             color_image = self.to(color_image, device) if (self.do_fusion or not self.depth_only) else None
             depth_image = self.to(depth_image, device) if (self.do_fusion or self.depth_only) else None
             if self.gpu_augment is not None and color_image is not None:

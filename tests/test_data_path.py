@@ -327,3 +327,21 @@ def test_training_from_site_files(pkg, tmp_path):
     assert np.isfinite(rec['cam_train_loss']) and rec['cam_train_loss'] > 0
     test_rec = trainer.test(1, loader.data_loader(args, 'valid', info))
     assert np.isfinite(test_rec['test_loss']) and 0 <= test_rec['score_pck'] <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,extra', [('ntu', ['-do_fusion', '-half_acc', '-geometry', '-shuffle']), ('pku', ['-depth_only', '-partial_conv', '-nexponent']),
+                                        ('h36m', [])])
+def test_depth_main_on_site_files(pkg, tmp_path, kind, extra):
+    """`python depth_main.py -data_name <site> ...` from the files on disk: train -> test -> checkpoint, then -val_only from that checkpoint
+    (depth_main.py:111-160).  h36m goes through the RGB-only `datasets` loader metadata.json names (no_depth)."""
+    meta, _, _ = make_site(str(tmp_path / kind), kind)
+    flags = ['-model', 'resnet18', '-suffix', 'site', '-data_name', kind, '-save_path', str(tmp_path / 'runs'), '-criterion', 'SmoothL1', '-num_joints', '17',
+             '-side_in', '128', '-batch_size', '2', '-workers', '2', '-metadata', meta] + list(extra)
+    state = pkg.depth_main.main(flags + ['-n_epochs', '1', '-save_record'])
+    assert state['epoch'] == 1
+    root = tmp_path / 'runs' / 'resnet18-site'
+    record = torch.load(root / 'train_record.pth')
+    assert np.isfinite(record['cam_train_loss'][0]) and 0 <= record['score_pck'][0] <= 1
+    again = pkg.depth_main.main(flags + ['-n_epochs', '1', '-val_only'])
+    assert again['test_loss'] == pytest.approx(record['test_loss'][0], rel=1e-4)          # the validation phase has no random flip / zoom
