@@ -113,8 +113,11 @@ class GpuCropLoader:
             divisor = raw['depth_divisor'].to(self.device).reshape(depth.shape).contiguous() if 'depth_divisor' in raw else None
             ops.enhance_depth_(depth, float(raw['depth_threshold'][0]), bool(raw['nexponent'][0]), divisor)
             items.append(depth)
-        items += [raw['true_cam'], raw['true_val']]
-        for key in ('back_rotate', 'atten_map'):
+        items.append(raw['true_cam'])
+        if 'true_mat' in raw:                                                      # joint-space tuples of the legacy trainer (train.py:66)
+            items.append(raw['true_mat'])
+        items.append(raw['true_val'])
+        for key in ('intrinsics', 'back_rotate', 'atten_map'):
             if key in raw:
                 items.append(raw[key])
         return tuple(items)

@@ -1,6 +1,8 @@
 """RGB-only loader API of the legacy entry point (datasets.py:22-27,141-148):
     data_loader(args, phase, data_info) -> loader with len() and an iterator
-yielding (color[B,3,S,S] f32, cam[B,J,3] f32, valid[B,J] bool[, back_rotate[B,3,3]]).
+yielding (color[B,3,S,S] f32, cam[B,J,3] f32, valid[B,J] bool[, back_rotate[B,3,3]]).  Under -joint_space the tuples carry what train.py's joint_train /
+joint_test unpack (train.py:66,212) and the reference's own datasets.py no longer produces: true_mat[B,J,2] = the joints projected into the crop and
+intrinsics[B,3,3] of the crop camera -> (color, cam, mat, valid, intrinsics[, back_rotate]).
 
 File-backed mode (`-data_name h36m`: <root>/samples.pkl + split.json, datasets.py:30-72): as in depth_datasets, the workers decode frames and plan
 the crop cameras and the crops are resampled on the GPU per batch (crops.GpuCropLoader).  `-synthetic N` serves N deterministic synthetic batches.
@@ -40,6 +42,7 @@ class Dataset(data.Dataset):
         self.num_joints = args.num_joints
         self.at_test = phase != 'train'
         self.raw_color = bool(args.colour or args.eraser)
+        self.joint_space = bool(getattr(args, 'joint_space', False))
         self.synthetic = int(getattr(args, 'synthetic', 0) or 0)
         if self.synthetic:
             self.count = self.synthetic * args.batch_size
@@ -75,6 +78,9 @@ class Dataset(data.Dataset):
         out = dict(color_frame=torch.from_numpy(frame), color_params=torch.from_numpy(params), color_round=rounded,
                    true_cam=torch.from_numpy(np.ascontiguousarray(camera_coords, dtype=np.float32)),
                    true_val=torch.from_numpy(np.ascontiguousarray(valid, dtype=bool)))
+        if self.joint_space:
+            out['true_mat'] = torch.from_numpy(np.ascontiguousarray(new_cam.camera_to_image(camera_coords), dtype=np.float32))
+            out['intrinsics'] = torch.from_numpy(np.asarray(new_cam.intrinsic_matrix, dtype=np.float32))
         if self.at_test:
             out['back_rotate'] = torch.from_numpy(np.asarray(sample['camera'].R @ new_cam.R.T, dtype=np.float32))
         return out
@@ -87,6 +93,12 @@ class Dataset(data.Dataset):
             return self.parse_sample(self.samples[index])
         color, depth, cam, val = synth.make_batch(1, side=self.side_in, num_joints=self.num_joints, rank=0, step=index)
         items = [torch.from_numpy(color[0]), torch.from_numpy(cam[0]), torch.from_numpy(val[0])]
+        if self.joint_space:                  # synthetic crop camera: focal 1.2 * side, principal point at the centre, joints 3 m in front of it
+            side = float(self.side_in)
+            intr = np.array([[1.2 * side, 0, side / 2], [0, 1.2 * side, side / 2], [0, 0, 1]], np.float32)
+            placed = cam[0] + np.array([0, 0, 3000.0], np.float32)
+            mat = placed[:, :2] / placed[:, 2:] * intr[[0, 1], [0, 1]] + intr[:2, 2]
+            items = [items[0], torch.from_numpy(placed.astype(np.float32)), torch.from_numpy(mat.astype(np.float32)), items[2], torch.from_numpy(intr)]
         if self.at_test:
             items.append(torch.eye(3))
         return tuple(items)

@@ -46,15 +46,21 @@ def create_model(args):
     return model.cuda(), state
 
 
-def _test_tuples(loader):
-    """datasets.py yields (color, cam, valid, back_rotate); train.py's cam_test unpacks (image, cam, back_rotate, valid)."""
+def _test_tuples(loader, joint_space=False):
+    """datasets.py yields (color, cam, valid, back_rotate); train.py's cam_test unpacks (image, cam, back_rotate, valid) (train.py:327).
+    Joint space: (color, cam, mat, valid, intrinsics, back_rotate) -> (image, cam, mat, back_rotate, valid, intrinsics) (train.py:212)."""
     class _Reordered:
         def __len__(self):
             return len(loader)
 
         def __iter__(self):
-            for color, cam, valid, back_rotate in loader:
-                yield color, cam, back_rotate, valid
+            for items in loader:
+                if joint_space:
+                    color, cam, mat, valid, intrinsics, back_rotate = items
+                    yield color, cam, mat, back_rotate, valid, intrinsics
+                else:
+                    color, cam, valid, back_rotate = items
+                    yield color, cam, back_rotate, valid
     return _Reordered()
 
 
@@ -83,10 +89,10 @@ def main(argv=None):
         trainer.reducer = p3d_dist.GradReducer(trainer.optimizer)
         trainer.world = trainer.reducer.world
     if args.test_only or args.val_only:
-        return trainer.test(0, _test_tuples(test_loader))
+        return trainer.test(0, _test_tuples(test_loader, args.joint_space))
     for epoch in range(logger.state['epoch'] + 1, args.n_epochs + 1):
         train_rec = trainer.train(epoch, data_loader)
-        test_rec = trainer.test(epoch, _test_tuples(test_loader)) if trainer.thresh is not None else {}
+        test_rec = trainer.test(epoch, _test_tuples(test_loader, args.joint_space)) if trainer.thresh is not None else {}
         logger.record(epoch, train_rec, test_rec, model)
     if rank == 0:
         logger.final_print()

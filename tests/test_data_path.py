@@ -345,3 +345,28 @@ def test_depth_main_on_site_files(pkg, tmp_path, kind, extra):
     assert np.isfinite(record['cam_train_loss'][0]) and 0 <= record['score_pck'][0] <= 1
     again = pkg.depth_main.main(flags + ['-n_epochs', '1', '-val_only'])
     assert again['test_loss'] == pytest.approx(record['test_loss'][0], rel=1e-4)          # the validation phase has no random flip / zoom
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra', [[], ['-joint_space', '-do_track']], ids=['cam', 'joint_track'])
+def test_legacy_main_on_site_files(pkg, tmp_path, extra):
+    """`python main.py -data_name h36m ...` from files: the RGB-only trainer, and the joint-space trainer with the least-squares track, whose loader
+    tuples (true_mat, intrinsics of the crop camera) come from the same crop plan."""
+    meta, _, _ = make_site(str(tmp_path / 'h36m'), 'h36m')
+    flags = ['-model', 'resnet18', '-suffix', 'legacy', '-data_name', 'h36m', '-save_path', str(tmp_path / 'runs'), '-criterion', 'SmoothL1', '-num_joints', '17',
+             '-side_in', '128', '-batch_size', '2', '-workers', '0', '-metadata', meta, '-n_epochs', '2', '-save_record'] + list(extra)
+    if extra:
+        ds = pkg.datasets.Dataset(pkg.opts.parse(flags), 'valid', pkg.utils.get_info())
+        item, s = ds[0], ds.samples[0]
+        new = pkg.crops.plan_crop(s['camera'], s['bbox'], 128)
+        assert np.allclose(item['intrinsics'].numpy(), new.intrinsic_matrix, rtol=1e-6)
+        assert np.allclose(item['true_mat'].numpy(), new.world_to_image(s['skeleton']), atol=1e-2)
+        # the projected joints of a person-centred crop land around the crop
+        assert np.abs(item['true_mat'].numpy() - 64).max() < 200
+    state = pkg.main.main(flags)
+    assert state['epoch'] == 2
+    record = torch.load(tmp_path / 'runs' / 'resnet18-legacy' / 'train_record.pth')
+    assert len(record['cam_train_loss']) == 2 and all(np.isfinite(record['cam_train_loss']))
+    if extra:
+        assert record['recon_train_loss'][0] == 0 and record['recon_train_loss'][1] > 0       # the track starts at epoch 2 (train.py:64)
+        assert 0 <= record['recon_score_pck'][1] <= 1 and np.isfinite(record['mat_train_loss'][1])
