@@ -12,46 +12,50 @@ from . import depth_train, dist as p3d_dist
 from .utils import get_info   # noqa: F401  (depth_main.get_info, depth_main.py:14-33)
 
 
+def _network(args, family, pretrain):
+    """resnet18 / resnet50 factory of one network family module ({partial_}{depth|fusion}net)."""
+    module = importlib.import_module('.' + family, package=__package__)
+    if not hasattr(module, args.model):
+        raise AssertionError('%s has no factory %r' % (family, args.model))
+    return getattr(module, args.model)(args, pretrain)
+
+
+def _family(args):
+    return ('partial_' if args.partial_conv else '') + ('fusion' if args.do_fusion else 'depth') + 'net'
+
+
+def _resume(args, model):
+    """-resume: weights and the logger state of args.model_path (depth_main.py:63-70); returns the state or None."""
+    if not args.resume:
+        return None
+    print('=> Loads checkpoint from ' + args.model_path)
+    saved = torch.load(args.model_path, map_location='cpu')
+    model.load_state_dict(saved['model'])
+    return saved['state']
+
+
 def create_model(args):
-    """depth_main.py:36-74: pick {partial_}{depth|fusion}net by flags, build args.model, optionally resume."""
-    name = ('partial_' if args.partial_conv else '') + ('fusion' if args.do_fusion else 'depth') + 'net'
-    module = importlib.import_module('.' + name, package=__package__)
-    assert hasattr(module, args.model)
-    model = getattr(module, args.model)(args, args.pretrain)
-    state = None
+    """depth_main.py:36-74: the network the flags select; -test_only / -val_only load model_<n_epochs>.pth of the run directory, -resume a given file."""
+    model = _network(args, _family(args), args.pretrain)
     if args.test_only or args.val_only:
-        save_path = os.path.join(args.save_path, args.model + '-' + args.suffix)
-        assert os.path.exists(save_path)
-        checkpoint = os.path.join(save_path, 'model_{}.pth'.format(args.n_epochs))
-        print('=> Loads checkpoint from ' + checkpoint)
-        checkpoint = torch.load(checkpoint, map_location='cpu')['model']
-        assert len(set(model.state_dict().keys()).difference(set(checkpoint.keys()))) == 0     # depth_main.py:57-60
-        model.load_state_dict(checkpoint)
-    if args.resume:
-        print('=> Loads checkpoint from ' + args.model_path)
-        checkpoint = torch.load(args.model_path, map_location='cpu')
-        model.load_state_dict(checkpoint['model'])
-        state = checkpoint['state']
-    return model, state
+        run_dir = os.path.join(args.save_path, args.model + '-' + args.suffix)
+        assert os.path.exists(run_dir)
+        path = os.path.join(run_dir, 'model_{}.pth'.format(args.n_epochs))
+        print('=> Loads checkpoint from ' + path)
+        weights = torch.load(path, map_location='cpu')['model']
+        missing = set(model.state_dict()) - set(weights)                           # depth_main.py:57-60: extra keys are fine, missing ones are not
+        assert not missing, sorted(missing)
+        model.load_state_dict(weights)
+    return model, _resume(args, model)
 
 
 def create_pair(args):
-    """depth_main.py:77-108: teacher = {partial_}{fusion|depth}net loaded from args.teacher_path, student = depthnet.
+    """depth_main.py:77-108: teacher = the flags' family with the weights of args.teacher_path, student = depthnet.
     (The reference wraps `model` instead of `teacher` in DataParallel when n_cudas > 1, depth_main.py:106; not reproduced.)"""
-    name = ('partial_' if args.partial_conv else '') + ('fusion' if args.do_fusion else 'depth') + 'net'
-    teacher_module = importlib.import_module('.' + name, package=__package__)
-    assert hasattr(teacher_module, args.model)
-    teacher = getattr(teacher_module, args.model)(args, False)
+    teacher = _network(args, _family(args), False)
     teacher.load_state_dict(torch.load(args.teacher_path, map_location='cpu')['model'])
-    student_module = importlib.import_module('.depthnet', package=__package__)
-    model = getattr(student_module, args.model)(args, args.pretrain)
-    state = None
-    if args.resume:
-        print('=> Loads checkpoint from ' + args.model_path)
-        checkpoint = torch.load(args.model_path, map_location='cpu')
-        model.load_state_dict(checkpoint['model'])
-        state = checkpoint['state']
-    return model, teacher, state
+    model = _network(args, 'depthnet', args.pretrain)
+    return model, teacher, _resume(args, model)
 
 
 def main(argv=None):
