@@ -64,6 +64,7 @@ SIGNATURES = {
     'p3d_augment_colour': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr]),
     'p3d_augment_erase': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_x3_enable': (_i32, [_i32]),
     'p3d_reproject_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_enhance_depth': (_i32, [_ptr, _ptr, _i64, _f32, _i32, _ptr]),
     'p3d_normalize_rgb': (_i32, [_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _ptr]),

@@ -34,6 +34,12 @@
 
 namespace p3d {
 
+// p3d_x3.hip (opt-in, P3D_X3=1)
+bool x3_wgrad_applies(const p3d_conv_desc* d);
+int x3_wgrad_splits(const p3d_conv_desc* d);
+void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
+
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
@@ -1268,7 +1274,8 @@ size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     // the larger of the masked / unmasked plans, so one query serves both
     const WgradPlan a = plan_wgrad(d, false), b = plan_wgrad(d, true);
-    const int splits = a.splits > b.splits ? a.splits : b.splits;
+    int splits = a.splits > b.splits ? a.splits : b.splits;
+    if (x3_wgrad_applies(d) && x3_wgrad_splits(d) > splits) splits = x3_wgrad_splits(d);
     return (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
@@ -1277,7 +1284,9 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && x && dw, "conv2d_wgrad: null tensor");
     const bool masked = mask_in || mult;
-    const WgradPlan pl = plan_wgrad(d, masked);
+    WgradPlan pl = plan_wgrad(d, masked);
+    const bool x3 = !masked && x3_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (x3) { pl.splits = x3_wgrad_splits(d); pl.tapm = false; }
     const size_t need = (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
     if (!workspace || workspace_bytes < need) {
         set_error("conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
@@ -1300,7 +1309,8 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
         if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && al16(x) && al16(mask_in)) wv = 2;
     }
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
-    launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
+    if (x3) x3_wgrad_launch(d, dy, x, (float*)workspace, pl.splits, (hipStream_t)stream);      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
+    else launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
     int nslab = pl.splits;
     if (nslab > 16) {            // deep split: fold to <= 16 slabs with a grid that fills the chip, then the final (layout) pass

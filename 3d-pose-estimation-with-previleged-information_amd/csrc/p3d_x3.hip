@@ -1,0 +1,152 @@
+// OPT-IN (P3D_X3=1), off by default and not part of the contract measurement: weight gradient of the 1x1 / stride-1 convolutions as an exact-fp32
+// GEMM on the bf16 MFMA pipe.
+//
+//   dw[k][c] = sum over images n and pixels p of dy[n][k][p] * x[n][c][p]                  (conv backward w.r.t. the weight, depthnet.py:40-56 layers)
+//
+// Both operands are pixel-contiguous, i.e. contiguous along the reduction index.  Every fp32 value is split on its way into LDS into three bf16
+// pieces by mantissa truncation (x = hi + mid + lo exactly, 8 + 8 + 8 bits); per K = 16 step the six piece products that can exceed 2^-24 |a b|
+// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first.  Measured error
+// equals the fp32 MFMA path's (tools/probe).  128x128 tile per block, 4 waves of 64x64, double-buffered LDS, split over images into workspace
+// slabs [split][K_out][C] that the ordinary slab_fold / wgrad_reduce passes of p3d_conv.hip finish (deterministic, no atomics).
+#include "p3d_common.h"
+
+namespace p3d {
+
+using bf8 = __bf16 __attribute__((ext_vector_type(8)));
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
+
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 16;
+constexpr int X3_PIECE = X3_BM * X3_BK * 2;          // bytes of one bf16 piece of one operand tile (128 rows x 16 k)
+
+__device__ __forceinline__ void x3_split_store(unsigned char* base, const f32x4 v) {
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];                         // (a bit_cast straight from an ext-vector element reads element 0 with this clang)
+        const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+        const float r1 = x - __builtin_bit_cast(float, hb);
+        const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, mb);
+        hi[e] = hb; mid[e] = mb; lo[e] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+    }
+    *reinterpret_cast<u32x2*>(base) = u32x2{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
+    *reinterpret_cast<u32x2*>(base + X3_PIECE) = u32x2{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
+    *reinterpret_cast<u32x2*>(base + 2 * X3_PIECE) = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+}
+
+// grid (ceil(C / 128), ceil(K / 128), splits); block z reduces K steps [z * spb, min(total, (z + 1) * spb)) of the N * P / 16 steps (image-major)
+__global__ __launch_bounds__(256) void x3_wgrad1x1_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ slabs, int N, int K,
+                                                          int C, int P, int spb) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * X3_PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * X3_PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * X3_BM, n0 = blockIdx.x * X3_BN;
+    const int steps_per_img = P / X3_BK;
+    const int s0 = blockIdx.z * spb, s1 = (s0 + spb < N * steps_per_img) ? s0 + spb : N * steps_per_img;
+    const int row = t >> 2, kq = t & 3;                      // staging: rows row, row + 64; floats 4 kq .. 4 kq + 3 of the K step
+    const bool a_ok[2] = {m0 + row < K, m0 + row + 64 < K}, b_ok[2] = {n0 + row < C, n0 + row + 64 < C};
+    const int nk = s1 - s0;
+    f32x4 ra[2], rb[2];
+    int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * X3_BK;
+    auto fetch = [&]() {
+        const float* ga = dy + ((size_t)f_img * K + m0 + row) * P + f_p + 4 * kq;
+        const float* gb = x + ((size_t)f_img * C + n0 + row) * P + f_p + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(ga + (size_t)i * 64 * P) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(gb + (size_t)i * 64 * P) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f_p += X3_BK;
+        if (f_p == P) { f_p = 0; ++f_img; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            x3_split_store(As + buf * 3 * X3_PIECE + (row + 64 * i) * (X3_BK * 2) + kq * 8, ra[i]);
+            x3_split_store(Bs + buf * 3 * X3_PIECE + (row + 64 * i) * (X3_BK * 2) + kq * 8, rb[i]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    if (nk > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch();
+        const unsigned char* a_rd = As + buf * 3 * X3_PIECE + (wm * 64 + fr) * (X3_BK * 2) + fh * 16;
+        const unsigned char* b_rd = Bs + buf * 3 * X3_PIECE + (wn * 64 + fr) * (X3_BK * 2) + fh * 16;
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * X3_PIECE + a * 32 * (X3_BK * 2));
+                bf[p][a] = *reinterpret_cast<const bf8*>(b_rd + p * X3_PIECE + a * 32 * (X3_BK * 2));
+            }
+#define P3D_X3_PROD(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)             \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][a], bf[PB][b], acc[a][b], 0, 0, 0);
+        P3D_X3_PROD(2, 0) P3D_X3_PROD(0, 2) P3D_X3_PROD(1, 1) P3D_X3_PROD(1, 0) P3D_X3_PROD(0, 1) P3D_X3_PROD(0, 0)
+#undef P3D_X3_PROD
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 31 (input channel c), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output channel k)
+    float* out = slabs + (size_t)blockIdx.z * K * C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = n0 + wn * 64 + b * 32 + fr;
+            if (c >= C) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (k < K) out[(size_t)k * C + c] = acc[a][b][r];
+            }
+        }
+}
+
+static int g_x3 = -1;       // -1: not decided yet (environment), 0 / 1: set
+bool x3_enabled() {
+    if (g_x3 < 0) { const char* e = getenv("P3D_X3"); g_x3 = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_x3 == 1;
+}
+
+// 1x1, stride 1, no padding, dense, whole weight tensor, >= 128 channels on both sides, pixel count a multiple of the K step
+bool x3_wgrad_applies(const p3d_conv_desc* d) {
+    return x3_enabled() && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->c_offset == 0 && d->c_total == d->C && d->K >= 128 && d->C >= 128 &&
+           (d->Ho * d->Wo) % X3_BK == 0 && d->H == d->Ho && d->W == d->Wo;
+}
+
+int x3_wgrad_splits(const p3d_conv_desc* d) {
+    const int64_t tiles = ceil_div(d->K, X3_BM) * ceil_div(d->C, X3_BN);
+    const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / X3_BK);
+    int64_t splits = ceil_div(1024, tiles);
+    if (splits > total / 32) splits = total / 32;           // at least 32 K steps per block
+    if (splits < 1) splits = 1;
+    const int64_t spb = ceil_div(total, splits);
+    return (int)ceil_div(total, spb);
+}
+
+void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st) {
+    const int spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / X3_BK), splits);
+    hipLaunchKernelGGL(x3_wgrad1x1_kernel, dim3((unsigned)ceil_div(d->C, X3_BN), (unsigned)ceil_div(d->K, X3_BM), (unsigned)splits), dim3(256), 0, st, dy, x, slabs,
+                       d->N, d->K, d->C, d->Ho * d->Wo, spb);
+}
+
+}  // namespace p3d
+
+extern "C" int32_t p3d_x3_enable(int32_t on) {
+    const int32_t before = p3d::x3_enabled() ? 1 : 0;
+    p3d::g_x3 = on ? 1 : 0;
+    return before;
+}

@@ -706,6 +706,11 @@ def warp_crops(frames, homography, out_hw):
     return out
 
 
+def set_x3(on):
+    """Opt-in exact-fp32 weight gradients on the bf16 MFMA pipe for the big 1x1 layers (csrc/p3d_x3.hip); returns the previous setting."""
+    return bool(lib().p3d_x3_enable(int(bool(on))))
+
+
 def reproject_crops(frames, params20, out_hw, round_u8=True):
     """Batch of cameralib.reproject_image calls (cameralib.py:378-443): frames [B,Hs,Ws,C] uint8 / fp32 as decoded, params20 [B,20] fp32
     (cameralib.reproject_params) -> [B,C,Ho,Wo] fp32."""

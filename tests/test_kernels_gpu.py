@@ -411,3 +411,28 @@ def test_bn_properties_at_full_size(shape, pkg):
     assert ((dx * yd).sum(dim=(0, 2, 3)).abs() / scale).max() < 1e-5
     assert (gamma.grad.double() - (dy.double() * yd).sum(dim=(0, 2, 3))).abs().max() < 1e-3 * (dy.double() * yd).sum(dim=(0, 2, 3)).abs().max()
     assert (beta.grad.double() - dy.double().sum(dim=(0, 2, 3))).abs().max() < 1e-3 * dy.double().sum(dim=(0, 2, 3)).abs().max()
+
+
+def test_x3_wgrad_matches_fp32_path(pkg):
+    """Opt-in p3d_x3 path (exact fp32 through the bf16 MFMA pipe): weight gradients of 1x1 convolutions agree with float64 as closely as the fp32 MFMA
+    kernel does, for full, ragged (channel counts that are not multiples of the 128 tile) and accumulate-into-gradient cases."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    try:
+        for (n, c, k, h) in [(8, 256, 128, 16), (5, 192, 320, 8), (64, 512, 128, 32), (3, 1024, 256, 16)]:
+            x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 6 - 3).exp2()
+            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
+            ref = torch.einsum('nkp,ncp->kc', dy.double().flatten(2), x.double().flatten(2))
+            outs = {}
+            for on in (False, True):
+                ops.set_x3(on)
+                w = torch.zeros(k, c, 1, 1, device='cuda', requires_grad=True)
+                y = ops.conv2d(x, w, None, 1, 0, 1)
+                y.backward(dy)
+                outs[on] = w.grad.view(k, c).double()
+            scale = ref.abs().max()
+            err_fp32, err_x3 = ((outs[False] - ref).abs().max() / scale).item(), ((outs[True] - ref).abs().max() / scale).item()
+            assert err_x3 < 3e-6 and err_x3 < 4 * err_fp32 + 2e-7, (n, c, k, h, err_fp32, err_x3)        # both at fp32 rounding level (split counts differ)
+            assert not torch.equal(outs[False], outs[True])                      # the other kernel really ran
+    finally:
+        ops.set_x3(False)
