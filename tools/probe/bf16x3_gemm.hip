@@ -121,6 +121,103 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_kernel(const float* __restric
         }
 }
 
+// ---- variant with PRE-SPLIT operands: A3 / B3 = three bf16 planes [3][rows][K] written once by presplit_kernel; the GEMM loop has no VALU work ----
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = in[i];
+        const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+        const float r1 = x - __builtin_bit_cast(float, hb);
+        const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, mb);
+        out[i] = (unsigned short)(hb >> 16);
+        out[n + i] = (unsigned short)(mb >> 16);
+        out[2 * n + i] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void bf16x3_gemm_presplit_kernel(const unsigned short* __restrict__ A3, const unsigned short* __restrict__ B3, float* __restrict__ C,
+                                                                   int M, int N, int K) {
+    constexpr int BK = 16, ROWB = 32, PIECE = BM * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int row = t >> 1, half = t & 1;                     // staging: one 16-B chunk (8 bf16) per piece per operand per thread
+    const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+    const unsigned short* ga = A3 + (size_t)(m0 + row) * K + half * 8;
+    const unsigned short* gb = B3 + (size_t)(n0 + row) * K + half * 8;
+    f32x4 ra[3], rb[3];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            ra[p] = *reinterpret_cast<const f32x4*>(ga + p * planeA + k0);
+            rb[p] = *reinterpret_cast<const f32x4*>(gb + p * planeB + k0);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<f32x4*>(As + (buf * 3 + p) * PIECE + row * ROWB + half * 16) = ra[p];
+            *reinterpret_cast<f32x4*>(Bs + (buf * 3 + p) * PIECE + row * ROWB + half * 16) = rb[p];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nk = K / BK;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        const unsigned char* a_rd = As + buf * 3 * PIECE + (wm * 64 + fr) * ROWB + fh * 16;
+        const unsigned char* b_rd = Bs + buf * 3 * PIECE + (wn * 64 + fr) * ROWB + fh * 16;
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * PIECE + a * 32 * ROWB);
+                bf[p][a] = *reinterpret_cast<const bf8*>(b_rd + p * PIECE + a * 32 * ROWB);
+            }
+#define P3D_PROD2(PA, PB)                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)              \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][a], bf[PB][b], acc[a][b], 0, 0, 0);
+        P3D_PROD2(2, 0) P3D_PROD2(0, 2) P3D_PROD2(1, 1) P3D_PROD2(1, 0) P3D_PROD2(0, 1) P3D_PROD2(0, 0)
+#undef P3D_PROD2
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                C[(size_t)m * N + n] = acc[a][b][r];
+            }
+        }
+}
+
+extern "C" int bf16x3_presplit(const float* in, void* out3, long long n, void* stream) {
+    hipLaunchKernelGGL(presplit_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, in, (unsigned short*)out3, (size_t)n);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int bf16x3_gemm_presplit(const void* A3, const void* B3, float* C, int M, int N, int K, void* stream) {
+    if (M % BM || N % BN || K % 16) return 1;
+    hipLaunchKernelGGL(bf16x3_gemm_presplit_kernel, dim3(N / BN, M / BM), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)A3, (const unsigned short*)B3, C, M, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" int bf16x3_gemm_masked(const float* A, const float* B, float* C, int M, int N, int K, int mask, void* stream) {
     hipLaunchKernelGGL((bf16x3_gemm_kernel<6, 16>), dim3(N / BN, M / BM), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, mask);
     return hipGetLastError() == hipSuccess ? 0 : 2;
