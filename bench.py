@@ -149,6 +149,27 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     ops.WGRAD_STREAM = overlap
 
+    # Informational, never `value`: the same steps with the opt-in exact-fp32-on-the-bf16-pipe weight gradients of the big 1x1 layers
+    # (csrc/p3d_x3.hip) switched on; same barrier / synchronize / max-over-ranks protocol.
+    x3_line = None
+    if not opt.half:
+        was = ops.set_x3(True)
+        xsteps = min(opt.steps, 10)
+        trainer.train_step(*batches[0])
+        sync()
+        t2 = time.perf_counter()
+        for i in range(xsteps):
+            trainer.train_step(*batches[i % nbuf])
+        sync()
+        x3_elapsed = time.perf_counter() - t2
+        ops.set_x3(was)
+        if dist.is_initialized():
+            t = torch.tensor([x3_elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            x3_elapsed = float(t.item())
+        x3_line = {'value': round(opt.batch * world * xsteps / x3_elapsed, 2), 'unit': 'crops/s', 'ms_per_step': round(x3_elapsed / xsteps * 1e3, 3), 'steps': xsteps,
+                   'note': 'opt-in P3D_X3=1: 1x1 weight gradients as exact fp32 on the bf16 MFMA pipe; NOT the contract configuration'}
+
     if rank == 0:
         crops = opt.batch * world * opt.steps
         value = crops / elapsed
@@ -201,6 +222,8 @@ def main():
             out['roofline']['traffic'] = None
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
+        if x3_line is not None:
+            out['optin_x3_wgrad'] = x3_line
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
