@@ -207,6 +207,83 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_presplit_kernel(const unsigne
         }
 }
 
+// ---- variant with a 64 x 128 register tile per wave (block tile 128 x 256): 18 KB of LDS fragments per 48 MFMAs instead of 12 KB per 24 ----
+__global__ __launch_bounds__(256, 2) void bf16x3_gemm_wide_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    constexpr int BK = 16, ROWB = 32, WBN = 256;
+    constexpr int PA = BM * ROWB, PB = WBN * ROWB;          // bytes of one piece of the A / B tile
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * PA];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * PB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * WBN;
+    const int row = t >> 2, kq = t & 3;
+    const float* ga = A + (size_t)(m0 + row) * K + 4 * kq;
+    const float* gb = B + (size_t)(n0 + row) * K + 4 * kq;
+    const size_t step64 = (size_t)64 * K;
+    f32x4 ra[2], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ga + i * step64 + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gb + i * step64 + k0);
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split_store<PA>(As + buf * 3 * PA + (row + 64 * i) * ROWB + kq * 8, ra[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_store<PB>(Bs + buf * 3 * PB + (row + 64 * i) * ROWB + kq * 8, rb[i]);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nk = K / BK;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        const unsigned char* a_rd = As + buf * 3 * PA + (wm * 64 + fr) * ROWB + fh * 16;
+        const unsigned char* b_rd = Bs + buf * 3 * PB + (wn * 128 + fr) * ROWB + fh * 16;
+        bf8 af[3][2], bf[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * PA + a * 32 * ROWB);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[p][b] = *reinterpret_cast<const bf8*>(b_rd + p * PB + b * 32 * ROWB);
+        }
+#define P3D_PRODW(QA, QB)                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)              \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][a], bf[QB][b], acc[a][b], 0, 0, 0);
+        P3D_PRODW(2, 0) P3D_PRODW(0, 2) P3D_PRODW(1, 1) P3D_PRODW(1, 0) P3D_PRODW(0, 1) P3D_PRODW(0, 0)
+#undef P3D_PRODW
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + wn * 128 + b * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                C[(size_t)m * N + n] = acc[a][b][r];
+            }
+        }
+}
+
+extern "C" int bf16x3_gemm_wide(const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
+    if (M % BM || N % 256 || K % 16) return 1;
+    hipLaunchKernelGGL(bf16x3_gemm_wide_kernel, dim3(N / 256, M / BM), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" int bf16x3_presplit(const float* in, void* out3, long long n, void* stream) {
     hipLaunchKernelGGL(presplit_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, in, (unsigned short*)out3, (size_t)n);
     return hipGetLastError() == hipSuccess ? 0 : 2;
