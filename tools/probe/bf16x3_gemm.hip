@@ -207,36 +207,38 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_presplit_kernel(const unsigne
         }
 }
 
-// ---- variant with a 64 x 128 register tile per wave (block tile 128 x 256): 18 KB of LDS fragments per 48 MFMAs instead of 12 KB per 24 ----
-__global__ __launch_bounds__(256, 2) void bf16x3_gemm_wide_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
-    constexpr int BK = 16, ROWB = 32, WBN = 256;
-    constexpr int PA = BM * ROWB, PB = WBN * ROWB;          // bytes of one piece of the A / B tile
+// ---- variants with larger register tiles per wave: TM x TN MFMA tiles of 32 x 32 (block tile 64 TM x 64 TN, 4 waves as 2 x 2).
+//      TM = 2, TN = 4: 18 KB of LDS fragments per 48 MFMAs;  TM = TN = 4: 24 KB per 96 MFMAs (accumulators fill the AGPRs, one wave per SIMD) ----
+template <int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void bf16x3_gemm_wide_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    constexpr int BK = 16, ROWB = 32, WBM = 64 * TM, WBN = 64 * TN;
+    constexpr int PA = WBM * ROWB, PB = WBN * ROWB;          // bytes of one piece of the A / B tile
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * PA];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * PB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * WBN;
+    const int m0 = blockIdx.y * WBM, n0 = blockIdx.x * WBN;
     const int row = t >> 2, kq = t & 3;
     const float* ga = A + (size_t)(m0 + row) * K + 4 * kq;
     const float* gb = B + (size_t)(n0 + row) * K + 4 * kq;
     const size_t step64 = (size_t)64 * K;
-    f32x4 ra[2], rb[4];
+    f32x4 ra[TM], rb[TN];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ga + i * step64 + k0);
+        for (int i = 0; i < TM; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ga + i * step64 + k0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gb + i * step64 + k0);
+        for (int i = 0; i < TN; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gb + i * step64 + k0);
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) split_store<PA>(As + buf * 3 * PA + (row + 64 * i) * ROWB + kq * 8, ra[i]);
+        for (int i = 0; i < TM; ++i) split_store<PA>(As + buf * 3 * PA + (row + 64 * i) * ROWB + kq * 8, ra[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split_store<PB>(Bs + buf * 3 * PB + (row + 64 * i) * ROWB + kq * 8, rb[i]);
+        for (int i = 0; i < TN; ++i) split_store<PB>(Bs + buf * 3 * PB + (row + 64 * i) * ROWB + kq * 8, rb[i]);
     };
-    f32x16 acc[2][4];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
@@ -247,18 +249,18 @@ __global__ __launch_bounds__(256, 2) void bf16x3_gemm_wide_kernel(const float* _
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) fetch((kt + 1) * BK);
-        const unsigned char* a_rd = As + buf * 3 * PA + (wm * 64 + fr) * ROWB + fh * 16;
-        const unsigned char* b_rd = Bs + buf * 3 * PB + (wn * 128 + fr) * ROWB + fh * 16;
-        bf8 af[3][2], bf[3][4];
+        const unsigned char* a_rd = As + buf * 3 * PA + (wm * 32 * TM + fr) * ROWB + fh * 16;
+        const unsigned char* b_rd = Bs + buf * 3 * PB + (wn * 32 * TN + fr) * ROWB + fh * 16;
+        bf8 af[3][TM], bf[3][TN];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * PA + a * 32 * ROWB);
+            for (int a = 0; a < TM; ++a) af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * PA + a * 32 * ROWB);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bf[p][b] = *reinterpret_cast<const bf8*>(b_rd + p * PB + b * 32 * ROWB);
+            for (int b = 0; b < TN; ++b) bf[p][b] = *reinterpret_cast<const bf8*>(b_rd + p * PB + b * 32 * ROWB);
         }
 #define P3D_PRODW(QA, QB)                                                                                     \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)              \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a) _Pragma("unroll") for (int b = 0; b < TN; ++b)            \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][a], bf[QB][b], acc[a][b], 0, 0, 0);
         P3D_PRODW(2, 0) P3D_PRODW(0, 2) P3D_PRODW(1, 1) P3D_PRODW(1, 0) P3D_PRODW(0, 1) P3D_PRODW(0, 0)
 #undef P3D_PRODW
@@ -266,21 +268,27 @@ __global__ __launch_bounds__(256, 2) void bf16x3_gemm_wide_kernel(const float* _
         __syncthreads();
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int n = n0 + wn * 128 + b * 32 + fr;
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + wn * 32 * TN + b * 32 + fr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int m = m0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 C[(size_t)m * N + n] = acc[a][b][r];
             }
         }
 }
 
-extern "C" int bf16x3_gemm_wide(const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
-    if (M % BM || N % 256 || K % 16) return 1;
-    hipLaunchKernelGGL(bf16x3_gemm_wide_kernel, dim3(N / 256, M / BM), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K);
+extern "C" int bf16x3_gemm_wide(const float* A, const float* B, float* C, int M, int N, int K, int big, void* stream) {
+    if (K % 16) return 1;
+    if (big) {
+        if (M % 256 || N % 256) return 1;
+        hipLaunchKernelGGL((bf16x3_gemm_wide_kernel<4, 4, 1>), dim3(N / 256, M / 256), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K);
+    } else {
+        if (M % 128 || N % 256) return 1;
+        hipLaunchKernelGGL((bf16x3_gemm_wide_kernel<2, 4, 2>), dim3(N / 256, M / 128), dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -17,7 +17,7 @@ lib = ctypes.CDLL(os.path.join(HERE, 'bf16x3_gemm.so'))
 lib.bf16x3_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 lib.bf16x3_gemm.restype = ctypes.c_int
 lib.bf16x3_presplit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
-lib.bf16x3_gemm_wide.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+lib.bf16x3_gemm_wide.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 lib.bf16x3_gemm_presplit.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
 
 
@@ -55,9 +55,14 @@ def main():
             out[tag + '_ms'] = round(ms, 4)
             out[tag + '_tflops'] = round(2.0 * m * n * k / ms / 1e9, 1)
             out[tag + '_max_err'] = float((C.double() - ref).abs().max().item() / scale)
-        ms = timed(lambda: lib.bf16x3_gemm_wide(A.data_ptr(), B.data_ptr(), C.data_ptr(), m, n, k, stream))
-        out['bf16x6_wide_ms'], out['bf16x6_wide_tflops'] = round(ms, 4), round(2.0 * m * n * k / ms / 1e9, 1)
-        out['bf16x6_wide_max_err'] = float((C.double() - ref).abs().max().item() / scale)
+        for tag, big in (('wide', 0), ('wide128', 1)):
+            if big and m % 256:
+                continue
+            def runw():
+                assert lib.bf16x3_gemm_wide(A.data_ptr(), B.data_ptr(), C.data_ptr(), m, n, k, big, stream) == 0
+            ms = timed(runw)
+            out['bf16x6_%s_ms' % tag], out['bf16x6_%s_tflops' % tag] = round(ms, 4), round(2.0 * m * n * k / ms / 1e9, 1)
+            out['bf16x6_%s_max_err' % tag] = float((C.double() - ref).abs().max().item() / scale)
         A3 = torch.empty(3, m, k, dtype=torch.int16, device='cuda')
         B3 = torch.empty(3, n, k, dtype=torch.int16, device='cuda')
         out['presplit_pass_ms'] = round(timed(lambda: (lib.bf16x3_presplit(A.data_ptr(), A3.data_ptr(), m * k, stream), lib.bf16x3_presplit(B.data_ptr(), B3.data_ptr(), n * k, stream))), 4)
