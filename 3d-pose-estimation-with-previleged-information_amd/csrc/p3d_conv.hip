@@ -38,6 +38,10 @@ namespace p3d {
 bool x3_wgrad_applies(const p3d_conv_desc* d);
 int x3_wgrad_splits(const p3d_conv_desc* d);
 void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
+bool x3_fwd_applies(const p3d_conv_desc* d);
+bool x3_dgrad_applies(const p3d_conv_desc* d);
+void x3_fwd_launch(const p3d_conv_desc* d, const float* x, const float* w, float* y, hipStream_t st);
+void x3_dgrad_launch(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st);
 
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -1098,6 +1102,11 @@ static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const flo
                                const float* ep_res, int ep_relu) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
+    if (!bias && !mask_in && !mult && !ep_scale && !ep_res && !ep_relu && x3_fwd_applies(d) &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
+        x3_fwd_launch(d, x, w, y, (hipStream_t)stream);
+        return check_launch("conv2d_fwd x3");
+    }
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
     p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
@@ -1203,6 +1212,10 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
                          const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && w && dx, "conv2d_dgrad: null tensor");
+    if (!mask_in && !mult && x3_dgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in (p3d_x3.hip)
+        x3_dgrad_launch(d, dy, w, dx, (hipStream_t)stream);
+        return check_launch("conv2d_dgrad x3");
+    }
     IgemmParams p = base_params(d);
     p.A = w; p.B = dy; p.Cout = dx; p.mask_in = mask_in; p.mult = mult;
     p.M = d->C; p.Kd = d->K * d->R * d->S;

@@ -1,5 +1,5 @@
-// OPT-IN (P3D_X3=1), off by default and not part of the contract measurement: weight gradient of the 1x1 / stride-1 convolutions as an exact-fp32
-// GEMM on the bf16 MFMA pipe.
+// OPT-IN (P3D_X3=1), off by default and not part of the contract measurement: the dense 1x1 / stride-1 convolutions (weight gradient here, forward and
+// data gradient further down) as exact-fp32 GEMMs on the bf16 MFMA pipe.
 //
 //   dw[k][c] = sum over images n and pixels p of dy[n][k][p] * x[n][c][p]                  (conv backward w.r.t. the weight, depthnet.py:40-56 layers)
 //
@@ -141,6 +141,128 @@ void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, fl
     const int spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / X3_BK), splits);
     hipLaunchKernelGGL(x3_wgrad1x1_kernel, dim3((unsigned)ceil_div(d->C, X3_BN), (unsigned)ceil_div(d->K, X3_BM), (unsigned)splits), dim3(256), 0, st, dy, x, slabs,
                        d->N, d->K, d->C, d->Ho * d->Wo, spb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward and data gradient of the dense 1x1 / stride-1 convolutions on the same six-product loop:
+//   forward (AT = false):  y[n][m][p]  = sum_c W[m][c] * x[n][c][p]          A = W is reduction-contiguous, B = x[n] is [c][p]
+//   dgrad   (AT = true):   dx[n][m][p] = sum_k W[k][m] * dy[n][k][p]         A = W is [k][m], B = dy[n] is [k][p]
+// Operands whose ROWS are the reduction index ([k][columns], NCHW activations and the transposed weight) are staged as they lie -- 16 reduction rows of
+// 128 bf16 columns, 256-B rows, 16-B chunks XOR-swizzled -- and the MFMA fragments (8 consecutive k of one column per lane) come out of
+// ds_read_b64_tr_b16, the same transposing read and swizzle as the fp16 weight-gradient kernel (p3d_hconv.hip).  One block = 128 output channels x 128
+// consecutive pixels of one image; no split.  Requires M % 128 == 0, reduction length % 16 == 0, pixels per image % 128 == 0.
+using s4t = short __attribute__((ext_vector_type(4)));
+using s8v = short __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int x3_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <bool AT>
+__global__ __launch_bounds__(256) void x3_conv1x1_kernel(const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ Y, int M, int Kred, int P,
+                                                          int tiles_per_img, int accumulate) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * X3_PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * X3_PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * X3_BM;
+    const int img = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - img * tiles_per_img) * X3_BN;
+    const float* xb = X + (size_t)img * Kred * P + p0;
+    // staging maps: reduction-contiguous operand: rows (t >> 2) + 64 i, floats 4 (t & 3) ..;  row-is-reduction operand: rows (t >> 5) + 8 i, columns 4 (t & 31) ..
+    const int nrow = t >> 2, nkq = t & 3, trow = t >> 5, tp4 = t & 31;
+    f32x4 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (AT) ra[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(k0 + trow + 8 * i) * M + m0 + 4 * tp4);
+            else ra[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(m0 + nrow + 64 * i) * Kred + k0 + 4 * nkq);
+            rb[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(k0 + trow + 8 * i) * P + 4 * tp4);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (AT) x3_split_store(As + buf * 3 * X3_PIECE + x3_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), ra[i]);
+            else x3_split_store(As + buf * 3 * X3_PIECE + (nrow + 64 * i) * (X3_BK * 2) + nkq * 8, ra[i]);
+            x3_split_store(Bs + buf * 3 * X3_PIECE + x3_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), rb[i]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    // transposed fragment read (see p3d_hconv.hip): 16-lane group g reads the 4-row x 16-column block of rows 8 (g >> 1) + 4 half .. +3, columns cb + 16 (g & 1) .. +15
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+    auto tr_frag = [&](const unsigned char* base, int cb) {
+        const int c0 = (cb + 16 * (g & 1)) >> 3;
+        s8v v;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = 8 * (g >> 1) + 4 * half + q;
+            const unsigned char* addr = base + x3_tr_off(row, c0 + (pq >> 1)) + 8 * (pq & 1);
+            const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
+        }
+        return __builtin_bit_cast(bf8, v);
+    };
+    const int nk = Kred / X3_BK;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * X3_BK);
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (AT) af[p][a] = tr_frag(As + (buf * 3 + p) * X3_PIECE, wm * 64 + a * 32);
+                else af[p][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + p) * X3_PIECE + (wm * 64 + a * 32 + fr) * (X3_BK * 2) + fh * 16);
+                bf[p][a] = tr_frag(Bs + (buf * 3 + p) * X3_PIECE, wn * 64 + a * 32);
+            }
+#define P3D_X3_PROD(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)             \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][a], bf[PB][b], acc[a][b], 0, 0, 0);
+        P3D_X3_PROD(2, 0) P3D_X3_PROD(0, 2) P3D_X3_PROD(1, 1) P3D_X3_PROD(1, 0) P3D_X3_PROD(0, 1) P3D_X3_PROD(0, 0)
+#undef P3D_X3_PROD
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 31 (pixel, contiguous in memory), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output channel)
+    float* yb = Y + (size_t)img * M * P + p0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = wn * 64 + b * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float* dst = yb + (size_t)m * P + n;
+                *dst = accumulate ? *dst + acc[a][b][r] : acc[a][b][r];
+            }
+        }
+}
+
+// dense 1x1 / stride 1 / no padding over the whole weight tensor; m = output rows of the GEMM (K for forward, C for dgrad), kred = its reduction length
+static bool x3_1x1_shape(const p3d_conv_desc* d, int m, int kred) {
+    return x3_enabled() && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->c_offset == 0 && d->c_total == d->C && d->H == d->Ho && d->W == d->Wo &&
+           m % X3_BM == 0 && kred % X3_BK == 0 && kred >= 64 && (d->Ho * d->Wo) % X3_BN == 0;
+}
+bool x3_fwd_applies(const p3d_conv_desc* d) { return !d->accumulate && x3_1x1_shape(d, d->K, d->C); }
+bool x3_dgrad_applies(const p3d_conv_desc* d) { return x3_1x1_shape(d, d->C, d->K); }
+
+void x3_fwd_launch(const p3d_conv_desc* d, const float* x, const float* w, float* y, hipStream_t st) {
+    const int P = d->Ho * d->Wo, tiles = P / X3_BN;
+    hipLaunchKernelGGL(x3_conv1x1_kernel<false>, dim3((unsigned)(d->N * tiles), (unsigned)(d->K / X3_BM)), dim3(256), 0, st, w, x, y, d->K, d->C, P, tiles, 0);
+}
+
+void x3_dgrad_launch(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
+    const int P = d->Ho * d->Wo, tiles = P / X3_BN;
+    hipLaunchKernelGGL(x3_conv1x1_kernel<true>, dim3((unsigned)(d->N * tiles), (unsigned)(d->C / X3_BM)), dim3(256), 0, st, w, dy, dx, d->C, d->K, P, tiles, d->accumulate);
 }
 
 }  // namespace p3d

@@ -707,7 +707,7 @@ def warp_crops(frames, homography, out_hw):
 
 
 def set_x3(on):
-    """Opt-in exact-fp32 weight gradients on the bf16 MFMA pipe for the big 1x1 layers (csrc/p3d_x3.hip); returns the previous setting."""
+    """Opt-in exact-fp32 kernels on the bf16 MFMA pipe for the dense 1x1 stride-1 layers (forward, dgrad, wgrad; csrc/p3d_x3.hip); returns the previous setting."""
     return bool(lib().p3d_x3_enable(int(bool(on))))
 
 

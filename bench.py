@@ -149,7 +149,7 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     ops.WGRAD_STREAM = overlap
 
-    # Informational, never `value`: the same steps with the opt-in exact-fp32-on-the-bf16-pipe weight gradients of the big 1x1 layers
+    # Informational, never `value`: the same steps with the opt-in exact-fp32-on-the-bf16-pipe kernels of the dense 1x1 layers
     # (csrc/p3d_x3.hip) switched on; same barrier / synchronize / max-over-ranks protocol.
     x3_line = None
     if not opt.half:
@@ -168,7 +168,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             x3_elapsed = float(t.item())
         x3_line = {'value': round(opt.batch * world * xsteps / x3_elapsed, 2), 'unit': 'crops/s', 'ms_per_step': round(x3_elapsed / xsteps * 1e3, 3), 'steps': xsteps,
-                   'note': 'opt-in P3D_X3=1: 1x1 weight gradients as exact fp32 on the bf16 MFMA pipe; NOT the contract configuration'}
+                   'note': 'opt-in P3D_X3=1: forward, data and weight gradients of the dense 1x1 stride-1 layers as exact fp32 on the bf16 MFMA pipe (csrc/p3d_x3.hip); NOT the contract configuration'}
 
     if rank == 0:
         crops = opt.batch * world * opt.steps
@@ -223,7 +223,7 @@ def main():
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
         if x3_line is not None:
-            out['optin_x3_wgrad'] = x3_line
+            out['optin_x3'] = x3_line
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -30,7 +30,7 @@ def test_bench_line_schema():
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], abs=1e-3) and 0.2 < r['frac'] < 1.0
     assert r['traffic'] is None or r['traffic'] > 0
-    x3 = line['optin_x3_wgrad']                                          # informational side measurement, never `value`
+    x3 = line['optin_x3']                                          # informational side measurement, never `value`
     assert x3['unit'] == 'crops/s' and x3['value'] > 0 and 'NOT the contract' in x3['note']
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['unit'] == 'crops/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']

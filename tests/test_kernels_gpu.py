@@ -436,3 +436,33 @@ def test_x3_wgrad_matches_fp32_path(pkg):
             assert not torch.equal(outs[False], outs[True])                      # the other kernel really ran
     finally:
         ops.set_x3(False)
+
+
+def test_x3_forward_and_dgrad_match_fp32_path(pkg):
+    """Opt-in p3d_x3 path for the forward and data-gradient passes of dense 1x1 / stride-1 convolutions (transposing LDS reads for the NCHW operand and
+    the transposed weight): error against float64 at the fp32 kernel's level; shapes the path does not cover fall back to the fp32 kernel."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(10)
+    try:
+        for (n, c, k, h, covered) in [(4, 256, 128, 16, (True, True)), (3, 128, 512, 32, (True, True)), (64, 2048, 512, 16, (True, True)), (2, 64, 256, 64, (True, False)),
+                                      (2, 256, 64, 16, (False, True)), (2, 192, 128, 8, (False, False))]:
+            x = (torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 6 - 3).exp2())
+            w0 = torch.randn(k, c, 1, 1, device='cuda', generator=gen) / c ** 0.5
+            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
+            y_ref = torch.einsum('kc,ncp->nkp', w0.view(k, c).double(), x.double().flatten(2)).view(n, k, h, h)
+            dx_ref = torch.einsum('kc,nkp->ncp', w0.view(k, c).double(), dy.double().flatten(2)).view(n, c, h, h)
+            res = {}
+            for on in (False, True):
+                ops.set_x3(on)
+                xr = x.clone().requires_grad_(True)
+                w = w0.clone().requires_grad_(True)
+                y = ops.conv2d(xr, w, None, 1, 0, 1)
+                y.backward(dy)
+                res[on] = (y.detach().double(), xr.grad.double(), w.grad.double())
+            for i, ref in ((0, y_ref), (1, dx_ref)):
+                scale = ref.abs().max()
+                e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
+                assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, i, e32, e3)
+                assert torch.equal(res[False][i], res[True][i]) != covered[i]       # covered passes really ran the other kernel
+    finally:
+        ops.set_x3(False)
