@@ -71,5 +71,18 @@ of the large 3x3 layers FETCH was 232 MB per launch).  At ~0.24 ms per launch th
 ''' % (RND, RND, RND, RND, RND, RND, json.dumps(fb), r['achieved'], sum(r['conv_ms_per_step'].values()), tables,
        tr['FETCH_SIZE']['kb_per_launch'] * 1024 / 1e6, tr['WRITE_SIZE']['kb_per_launch'] * 1024 / 1e6, tr['FETCH_SIZE']['launches'],
        lines(go('final_convbench.log')), pm.strip(), lines(go('final_hconvbench.log')))
+x3_path = os.path.join(ROOT, 'profiles', '%s_bench_x3_optin.json' % RND)
+if os.path.exists(x3_path):
+    x3 = json.loads(open(x3_path).read().strip().split('\n')[-1])
+    o = x3.get('optin_x3') or x3.get('optin_x3_wgrad')
+    out += '''
+
+## Opt-in exact-fp32-on-the-bf16-pipe kernels for the dense 1x1 layers (`P3D_X3=1`, DESIGN.md section 9; NOT the contract configuration)
+
+`%s_bench_x3_optin.json`: an un-profiled `python bench.py` line; its `optin_x3` object is the same steps re-timed with the switch on (%.1f ms/step, %.0f crops/s against that
+line's %.1f ms / %.0f).  `%s_x3_optin_kernel_stats.csv`: rocprofv3 --kernel-trace --stats of `P3D_X3=1 P3D_WGRAD_STREAM=0 python3 bench.py --steps 5 --warmup 2`
+(`p3d::x3_conv1x1_kernel<false>` forward, `<true>` dgrad, `p3d::x3_wgrad1x1_kernel`).  `%s_conv_bench_x3_optin.txt`: per-layer timings with the switch on.
+`%s_bf16x3_probe.json` / `%s_bf16x3_probe_pmc.txt`: the stand-alone GEMM probe (tile shapes, pre-split operands, counters).
+''' % (RND, o['ms_per_step'], o['value'], x3['ms_per_step'], x3['value'], RND, RND, RND, RND)
 open(os.path.join(ROOT, 'profiles', '%s_summary.md' % RND), 'w').write(out)
 print('wrote profiles/%s_summary.md' % RND)
