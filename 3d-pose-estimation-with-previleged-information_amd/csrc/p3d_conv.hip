@@ -42,6 +42,11 @@ bool x3_fwd_applies(const p3d_conv_desc* d);
 bool x3_dgrad_applies(const p3d_conv_desc* d);
 void x3_fwd_launch(const p3d_conv_desc* d, const float* x, const float* w, float* y, hipStream_t st);
 void x3_dgrad_launch(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st);
+bool x3_fwd_rs_applies(const p3d_conv_desc* d);
+bool x3_dgrad_rs_applies(const p3d_conv_desc* d);
+size_t x3_rs_image_bytes(const p3d_conv_desc* d);
+void x3_fwd_rs_launch(const p3d_conv_desc* d, const float* x, const float* wt_image, const float* bias, float* y, hipStream_t st);
+void x3_dgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* wt_image, float* dx, hipStream_t st);
 
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -1094,7 +1099,9 @@ static FwdPlan plan_fwd(const p3d_conv_desc* d, bool masked, bool allow_split) {
 size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     const FwdPlan pl = plan_fwd(d, false, true);
-    return weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
+    const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
+    const size_t x3 = x3_fwd_rs_applies(d) ? x3_rs_image_bytes(d) : 0;
+    return base > x3 ? base : x3;
 }
 
 static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask_in, const float* mult,
@@ -1106,6 +1113,14 @@ static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const flo
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
         x3_fwd_launch(d, x, w, y, (hipStream_t)stream);
         return check_launch("conv2d_fwd x3");
+    }
+    if (!mask_in && !mult && !ep_scale && !ep_res && !ep_relu && x3_fwd_rs_applies(d) && workspace && workspace_bytes >= x3_rs_image_bytes(d) &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {      // opt-in, R x S taps: tap-major weight image first
+        const int64_t kc = (int64_t)d->K * d->C;
+        hipLaunchKernelGGL(weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)workspace, d->K, d->C, d->R * d->S);
+        x3_fwd_rs_launch(d, x, (const float*)workspace, bias, y, (hipStream_t)stream);
+        return check_launch("conv2d_fwd x3 rs");
     }
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
@@ -1202,7 +1217,9 @@ size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     if (d->stride == 1) {
         const FwdPlan pl = plan_dgrad1(d, false);
-        return weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
+        const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
+        const size_t x3 = x3_dgrad_rs_applies(d) ? x3_rs_image_bytes(d) : 0;
+        return base > x3 ? base : x3;
     }
     const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
     return (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
@@ -1215,6 +1232,14 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
     if (!mask_in && !mult && x3_dgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in (p3d_x3.hip)
         x3_dgrad_launch(d, dy, w, dx, (hipStream_t)stream);
         return check_launch("conv2d_dgrad x3");
+    }
+    if (!mask_in && !mult && x3_dgrad_rs_applies(d) && workspace && workspace_bytes >= x3_rs_image_bytes(d) &&
+        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {      // opt-in, R x S taps
+        const int64_t kc = (int64_t)d->K * d->C;
+        hipLaunchKernelGGL(weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)workspace, d->K, d->C, d->R * d->S);
+        x3_dgrad_rs_launch(d, dy, (const float*)workspace, dx, (hipStream_t)stream);
+        return check_launch("conv2d_dgrad x3 rs");
     }
     IgemmParams p = base_params(d);
     p.A = w; p.B = dy; p.Cout = dx; p.mask_in = mask_in; p.mult = mult;

@@ -265,6 +265,148 @@ void x3_dgrad_launch(const p3d_conv_desc* d, const float* dy, const float* w, fl
     hipLaunchKernelGGL(x3_conv1x1_kernel<true>, dim3((unsigned)(d->N * tiles), (unsigned)(d->C / X3_BM)), dim3(256), 0, st, w, dy, dx, d->C, d->K, P, tiles, d->accumulate);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// R x S taps ("same" convolutions: stride 1, pad = dil (R - 1) / 2), forward and data gradient, on the loop of x3_conv1x1_kernel:
+//   forward:  y[n][m][p]  = bias[m] + sum_tap sum_c Wt[tap][m][c] * x[n][c][p + off(tap)]
+//   dgrad:    dx[n][m][p] = sum_tap sum_k Wt[tap][k][m] * dy[n][k][p - off(tap)]            off(tap) = ((r - R/2) dil, (s - S/2) dil), zero outside the image
+// Wt = the tap-major weight image [tap][K][C] (weight_tapmajor_kernel of p3d_conv.hip writes it into the call's workspace).  The K loop runs tap-major: nk = R S x (reduction / 16).
+// The shifted activation rows are fetched with per-element bounds (four scalar loads when the column shift is not zero, one 16-B load otherwise).
+// Rows m >= M of a ragged last tile (the 272-channel regressor) are staged as zeros and not stored.
+template <bool AT>
+__global__ __launch_bounds__(256) void x3_convrs_kernel(const float* __restrict__ Wt, const float* __restrict__ X, const float* __restrict__ bias, float* __restrict__ Y,
+                                                         int M, int Kred, int H, int Wd, int R, int S, int dil, int tiles_per_img, int accumulate) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * X3_PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * X3_PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int P = H * Wd;
+    const int m0 = blockIdx.y * X3_BM;
+    const int img = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - img * tiles_per_img) * X3_BN;
+    const float* xb = X + (size_t)img * Kred * P;
+    const int nrow = t >> 2, nkq = t & 3, trow = t >> 5, tp4 = t & 31;
+    const int pg = p0 + 4 * tp4, ph = pg / Wd, pw = pg - ph * Wd;          // this thread's 4 consecutive pixels (one image row: Wd % 4 == 0)
+    const size_t wplane = AT ? (size_t)Kred * M : (size_t)M * Kred;         // one tap of the image (K x C floats either way)
+    const int ksteps = Kred / X3_BK;
+    const int nk = R * S * ksteps;
+    f32x4 ra[2], rb[2];
+    int f_tap = 0, f_k = 0;
+    auto fetch = [&]() {
+        const int r = f_tap / S, sx = f_tap - r * S;
+        const int sign = AT ? -1 : 1;
+        const int dh = sign * (r - R / 2) * dil, dw = sign * (sx - S / 2) * dil;
+        const float* wt = Wt + (size_t)f_tap * wplane;
+        const int hh = ph + dh, w0 = pw + dw;
+        const bool row_ok = (unsigned)hh < (unsigned)H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (AT) ra[i] = *reinterpret_cast<const f32x4*>(wt + (size_t)(f_k + trow + 8 * i) * M + m0 + 4 * tp4);
+            else ra[i] = (m0 + nrow + 64 * i < M) ? *reinterpret_cast<const f32x4*>(wt + (size_t)(m0 + nrow + 64 * i) * Kred + f_k + 4 * nkq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = xb + (size_t)(f_k + trow + 8 * i) * P + hh * Wd + w0;
+            if (dw == 0) {
+                rb[i] = row_ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = (row_ok && (unsigned)(w0 + e) < (unsigned)Wd) ? src[e] : 0.f;
+            }
+        }
+        f_k += X3_BK;
+        if (f_k == Kred) { f_k = 0; ++f_tap; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (AT) x3_split_store(As + buf * 3 * X3_PIECE + x3_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), ra[i]);
+            else x3_split_store(As + buf * 3 * X3_PIECE + (nrow + 64 * i) * (X3_BK * 2) + nkq * 8, ra[i]);
+            x3_split_store(Bs + buf * 3 * X3_PIECE + x3_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), rb[i]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+    auto tr_frag = [&](const unsigned char* base, int cb) {
+        const int c0 = (cb + 16 * (g & 1)) >> 3;
+        s8v v;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = 8 * (g >> 1) + 4 * half + q;
+            const unsigned char* addr = base + x3_tr_off(row, c0 + (pq >> 1)) + 8 * (pq & 1);
+            const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
+        }
+        return __builtin_bit_cast(bf8, v);
+    };
+    fetch();
+    stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch();
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (AT) af[p][a] = tr_frag(As + (buf * 3 + p) * X3_PIECE, wm * 64 + a * 32);
+                else af[p][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + p) * X3_PIECE + (wm * 64 + a * 32 + fr) * (X3_BK * 2) + fh * 16);
+                bf[p][a] = tr_frag(Bs + (buf * 3 + p) * X3_PIECE, wn * 64 + a * 32);
+            }
+#define P3D_X3_PROD(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)             \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][a], bf[PB][b], acc[a][b], 0, 0, 0);
+        P3D_X3_PROD(2, 0) P3D_X3_PROD(0, 2) P3D_X3_PROD(1, 1) P3D_X3_PROD(1, 0) P3D_X3_PROD(0, 1) P3D_X3_PROD(0, 0)
+#undef P3D_X3_PROD
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* yb = Y + (size_t)img * M * P + p0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = wn * 64 + b * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= M) continue;
+                float v = acc[a][b][r];
+                if (bias) v += bias[m];
+                float* dst = yb + (size_t)m * P + n;
+                *dst = accumulate ? *dst + v : v;
+            }
+        }
+}
+
+// "same" R x R convolution (R odd, > 1), stride 1, dense, whole weight tensor
+static bool x3_rs_shape(const p3d_conv_desc* d, int kred) {
+    return x3_enabled() && d->R == d->S && d->R > 1 && (d->R & 1) && d->stride == 1 && d->pad == d->dil * (d->R - 1) / 2 && d->c_offset == 0 && d->c_total == d->C &&
+           d->H == d->Ho && d->W == d->Wo && kred % X3_BK == 0 && kred >= 64 && (d->Ho * d->Wo) % X3_BN == 0 && d->W % 4 == 0;
+}
+// one block per (128 output rows, 128 pixels) and no split: worth it only when that fills the chip twice over (smaller grids stay on the split-K fp32 kernel) and the row tile is full enough
+static bool x3_rs_grid_ok(const p3d_conv_desc* d, int m) {
+    return m >= X3_BM && ceil_div(m, X3_BM) * ((int64_t)d->N * d->Ho * d->Wo / X3_BN) >= 512 && (m % X3_BM == 0 || m % X3_BM >= 64);
+}
+bool x3_fwd_rs_applies(const p3d_conv_desc* d) { return !d->accumulate && x3_rs_shape(d, d->C) && x3_rs_grid_ok(d, d->K); }
+bool x3_dgrad_rs_applies(const p3d_conv_desc* d) { return d->C % X3_BM == 0 && x3_rs_shape(d, d->K) && x3_rs_grid_ok(d, d->C); }
+size_t x3_rs_image_bytes(const p3d_conv_desc* d) { return (((size_t)d->K * d->C * d->R * d->S * sizeof(float)) + 255) & ~(size_t)255; }
+
+void x3_fwd_rs_launch(const p3d_conv_desc* d, const float* x, const float* wt_image, const float* bias, float* y, hipStream_t st) {
+    const int P = d->Ho * d->Wo, tiles = P / X3_BN;
+    hipLaunchKernelGGL(x3_convrs_kernel<false>, dim3((unsigned)(d->N * tiles), (unsigned)ceil_div(d->K, X3_BM)), dim3(256), 0, st, wt_image, x, bias, y, d->K, d->C,
+                       d->H, d->W, d->R, d->S, d->dil, tiles, 0);
+}
+
+void x3_dgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* wt_image, float* dx, hipStream_t st) {
+    const int P = d->Ho * d->Wo, tiles = P / X3_BN;
+    hipLaunchKernelGGL(x3_convrs_kernel<true>, dim3((unsigned)(d->N * tiles), (unsigned)(d->C / X3_BM)), dim3(256), 0, st, wt_image, dy, (const float*)nullptr, dx, d->C, d->K,
+                       d->H, d->W, d->R, d->S, d->dil, tiles, d->accumulate);
+}
+
 }  // namespace p3d
 
 extern "C" int32_t p3d_x3_enable(int32_t on) {

@@ -168,7 +168,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             x3_elapsed = float(t.item())
         x3_line = {'value': round(opt.batch * world * xsteps / x3_elapsed, 2), 'unit': 'crops/s', 'ms_per_step': round(x3_elapsed / xsteps * 1e3, 3), 'steps': xsteps,
-                   'note': 'opt-in P3D_X3=1: forward, data and weight gradients of the dense 1x1 stride-1 layers as exact fp32 on the bf16 MFMA pipe (csrc/p3d_x3.hip); NOT the contract configuration'}
+                   'note': 'opt-in P3D_X3=1: the dense stride-1 layers (1x1: all passes; R x R: forward and dgrad on large grids) as exact fp32 on the bf16 MFMA pipe (csrc/p3d_x3.hip); NOT the contract configuration'}
 
     if rank == 0:
         crops = opt.batch * world * opt.steps

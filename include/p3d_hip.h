@@ -85,8 +85,8 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
                          const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* db[k] (=|+=) sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
-/* OPT-IN, default off (also P3D_X3=1 in the environment): forward, data gradient and weight gradient of the dense 1x1 / stride-1 convolutions (output rows a
- * multiple of 128, pixels per image a multiple of 128; weight gradient: >= 128 channels on both sides) as an exact-fp32 GEMM on the bf16 MFMA pipe (three-piece operand split, six piece products, fp32 accumulation; csrc/p3d_x3.hip).
+/* OPT-IN, default off (also P3D_X3=1 in the environment): the dense stride-1 convolutions -- 1x1: forward, data and weight gradient; R x R "same": forward and data
+ * gradient when the grid fills the chip -- (pixels per image a multiple of 128) as exact-fp32 GEMMs on the bf16 MFMA pipe (three-piece operand split, six piece products, fp32 accumulation; csrc/p3d_x3.hip).
  * Same results to fp32 rounding as the fp32 MFMA path; not used for the contract measurement.  Returns the previous setting. */
 int32_t p3d_x3_enable(int32_t on);
 int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream);

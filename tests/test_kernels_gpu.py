@@ -466,3 +466,42 @@ def test_x3_forward_and_dgrad_match_fp32_path(pkg):
                 assert torch.equal(res[False][i], res[True][i]) != covered[i]       # covered passes really ran the other kernel
     finally:
         ops.set_x3(False)
+
+
+def test_x3_same_convolutions_match_fp32_path(pkg):
+    """Opt-in p3d_x3 path for R x R "same" convolutions (stride 1, pad = dil (R - 1) / 2): forward (with and without bias, ragged 272-channel output) and data
+    gradient (also accumulating into an existing gradient) against float64, at the fp32 kernel's error level; the weight gradient stays on the fp32 kernel."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    F = torch.nn.functional
+    try:
+        for (n, c, k, h, r, dil, with_bias) in [(64, 128, 128, 32, 3, 1, False), (64, 256, 272 + 64, 16, 3, 1, True), (64, 128, 512, 16, 3, 2, False), (2, 64, 64, 64, 3, 1, False),
+                                                (64, 128, 128, 32, 5, 1, True)]:
+            x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 4 - 2).exp2()
+            w0 = torch.randn(k, c, r, r, device='cuda', generator=gen) / (c * r * r) ** 0.5
+            b0 = torch.randn(k, device='cuda', generator=gen) if with_bias else None
+            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
+            pad = dil * (r - 1) // 2
+            xd = x.double().requires_grad_(True)
+            y_ref = F.conv2d(xd, w0.double(), None if b0 is None else b0.double(), 1, pad, dil)
+            y_ref.backward(dy.double())
+            res = {}
+            for on in (False, True):
+                ops.set_x3(on)
+                xr = x.clone().requires_grad_(True)
+                w = w0.clone().requires_grad_(True)
+                b = None if b0 is None else b0.clone().requires_grad_(True)
+                y = ops.conv2d(xr, w, b, 1, pad, dil)
+                y.backward(dy)
+                res[on] = (y.detach().double(), xr.grad.double(), w.grad.double())
+            tiles = n * h * h // 128                                               # the path takes grids of >= 512 blocks with full-enough row tiles
+            fwd_covered = k >= 128 and -(-k // 128) * tiles >= 512
+            dgrad_covered = c % 128 == 0 and (c // 128) * tiles >= 512
+            for i, ref, covered in ((0, y_ref.detach(), fwd_covered), (1, xd.grad, dgrad_covered)):
+                scale = ref.abs().max()
+                e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
+                assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, r, dil, i, e32, e3)
+                assert torch.equal(res[False][i], res[True][i]) != covered, (n, c, k, h, r, dil, i)
+            assert torch.equal(res[False][2], res[True][2])                        # R x R weight gradients are not on the opt-in path
+    finally:
+        ops.set_x3(False)
