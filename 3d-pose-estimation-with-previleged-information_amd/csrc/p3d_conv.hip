@@ -38,6 +38,9 @@ namespace p3d {
 bool x3_wgrad_applies(const p3d_conv_desc* d);
 int x3_wgrad_splits(const p3d_conv_desc* d);
 void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
+bool x3_wgrad_rs_applies(const p3d_conv_desc* d);
+int x3_wgrad_rs_splits(const p3d_conv_desc* d);
+void x3_wgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
 bool x3_fwd_applies(const p3d_conv_desc* d);
 bool x3_dgrad_applies(const p3d_conv_desc* d);
 void x3_fwd_launch(const p3d_conv_desc* d, const float* x, const float* w, float* y, hipStream_t st);
@@ -1314,6 +1317,7 @@ size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d) {
     const WgradPlan a = plan_wgrad(d, false), b = plan_wgrad(d, true);
     int splits = a.splits > b.splits ? a.splits : b.splits;
     if (x3_wgrad_applies(d) && x3_wgrad_splits(d) > splits) splits = x3_wgrad_splits(d);
+    if (x3_wgrad_rs_applies(d) && x3_wgrad_rs_splits(d) > splits) splits = x3_wgrad_rs_splits(d);
     return (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
@@ -1325,6 +1329,8 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     WgradPlan pl = plan_wgrad(d, masked);
     const bool x3 = !masked && x3_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     if (x3) { pl.splits = x3_wgrad_splits(d); pl.tapm = false; }
+    const bool x3rs = !masked && !x3 && x3_wgrad_rs_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (x3rs) { pl.splits = x3_wgrad_rs_splits(d); pl.tapm = false; }
     const size_t need = (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
     if (!workspace || workspace_bytes < need) {
         set_error("conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
@@ -1348,6 +1354,7 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     }
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
     if (x3) x3_wgrad_launch(d, dy, x, (float*)workspace, pl.splits, (hipStream_t)stream);      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
+    else if (x3rs) x3_wgrad_rs_launch(d, dy, x, (float*)workspace, pl.splits, (hipStream_t)stream);
     else launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
     int nslab = pl.splits;

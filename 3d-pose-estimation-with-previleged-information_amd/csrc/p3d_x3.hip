@@ -407,6 +407,119 @@ void x3_dgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* wt
                        d->H, d->W, d->R, d->S, d->dil, tiles, d->accumulate);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the R x R "same" convolutions:  dw[k][c][tap] = sum_n sum_p dy[n][k][p] * x[n][c][p + off(tap)]   (zero outside the image).
+// x3_wgrad1x1_kernel with the tap as one more grid dimension (blockIdx.z = tap * nsplit + split): the activation rows are fetched shifted, with per-element bounds; a K step is 16
+// consecutive pixels of one image row (W % 16 == 0).  Slab layout [split][k][c * RS + tap], i.e. the weight's own [k][c][r][s] order, which wgrad_reduce_kernel sums.
+__global__ __launch_bounds__(256) void x3_wgradrs_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ slabs, int N, int K, int C, int H, int Wd,
+                                                          int R, int S, int dil, int spb, int nsplit) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * X3_PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * X3_PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * X3_BM, n0 = blockIdx.x * X3_BN;
+    const int tap = blockIdx.z / nsplit, split = blockIdx.z - tap * nsplit;
+    const int P = H * Wd, RS = R * S;
+    const int dh = (tap / S - R / 2) * dil, dw = (tap % S - S / 2) * dil;
+    const int steps_per_img = P / X3_BK;
+    const int s0 = split * spb, s1 = (s0 + spb < N * steps_per_img) ? s0 + spb : N * steps_per_img;
+    const int row = t >> 2, kq = t & 3;
+    const bool a_ok[2] = {m0 + row < K, m0 + row + 64 < K}, b_ok[2] = {n0 + row < C, n0 + row + 64 < C};
+    const int nk = s1 - s0;
+    f32x4 ra[2], rb[2];
+    int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * X3_BK;
+    auto fetch = [&]() {
+        const float* ga = dy + ((size_t)f_img * K + m0 + row) * P + f_p + 4 * kq;
+        const int pp = f_p + 4 * kq, h = pp / Wd, w0 = pp - h * Wd + dw, hh = h + dh;
+        const bool row_ok = (unsigned)hh < (unsigned)H;
+        const float* gb = x + ((size_t)f_img * C + n0 + row) * P + hh * Wd + w0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(ga + (size_t)i * 64 * P) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = gb + (size_t)i * 64 * P;
+            if (dw == 0) {
+                rb[i] = (b_ok[i] && row_ok) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = (b_ok[i] && row_ok && (unsigned)(w0 + e) < (unsigned)Wd) ? src[e] : 0.f;
+            }
+        }
+        f_p += X3_BK;
+        if (f_p == P) { f_p = 0; ++f_img; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            x3_split_store(As + buf * 3 * X3_PIECE + (row + 64 * i) * (X3_BK * 2) + kq * 8, ra[i]);
+            x3_split_store(Bs + buf * 3 * X3_PIECE + (row + 64 * i) * (X3_BK * 2) + kq * 8, rb[i]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    if (nk > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch();
+        const unsigned char* a_rd = As + buf * 3 * X3_PIECE + (wm * 64 + fr) * (X3_BK * 2) + fh * 16;
+        const unsigned char* b_rd = Bs + buf * 3 * X3_PIECE + (wn * 64 + fr) * (X3_BK * 2) + fh * 16;
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                af[p][a] = *reinterpret_cast<const bf8*>(a_rd + p * X3_PIECE + a * 32 * (X3_BK * 2));
+                bf[p][a] = *reinterpret_cast<const bf8*>(b_rd + p * X3_PIECE + a * 32 * (X3_BK * 2));
+            }
+#define P3D_X3_PROD(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)             \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][a], bf[PB][b], acc[a][b], 0, 0, 0);
+        P3D_X3_PROD(2, 0) P3D_X3_PROD(0, 2) P3D_X3_PROD(1, 1) P3D_X3_PROD(1, 0) P3D_X3_PROD(0, 1) P3D_X3_PROD(0, 0)
+#undef P3D_X3_PROD
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = slabs + (size_t)split * K * C * RS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = n0 + wn * 64 + b * 32 + fr;
+            if (c >= C) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (k < K) out[((size_t)k * C + c) * RS + tap] = acc[a][b][r];
+            }
+        }
+}
+
+bool x3_wgrad_rs_applies(const p3d_conv_desc* d) {
+    return x3_enabled() && d->R == d->S && d->R > 1 && (d->R & 1) && d->stride == 1 && d->pad == d->dil * (d->R - 1) / 2 && d->c_offset == 0 && d->c_total == d->C &&
+           d->H == d->Ho && d->W == d->Wo && d->K >= 128 && d->C >= 128 && (int64_t)d->K * d->C >= 512 * 512 && d->W % X3_BK == 0;      // smaller weights measured slower than the fp32 kernel
+}
+
+int x3_wgrad_rs_splits(const p3d_conv_desc* d) {
+    const int64_t tiles = ceil_div(d->K, X3_BM) * ceil_div(d->C, X3_BN) * d->R * d->S;
+    const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / X3_BK);
+    int64_t splits = ceil_div(1024, tiles);
+    if (splits > total / 32) splits = total / 32;
+    if (splits < 1) splits = 1;
+    const int64_t spb = ceil_div(total, splits);
+    return (int)ceil_div(total, spb);
+}
+
+void x3_wgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st) {
+    const int spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / X3_BK), splits);
+    hipLaunchKernelGGL(x3_wgradrs_kernel, dim3((unsigned)ceil_div(d->C, X3_BN), (unsigned)ceil_div(d->K, X3_BM), (unsigned)(splits * d->R * d->S)), dim3(256), 0, st, dy, x, slabs,
+                       d->N, d->K, d->C, d->H, d->W, d->R, d->S, d->dil, spb, splits);
+}
+
 }  // namespace p3d
 
 extern "C" int32_t p3d_x3_enable(int32_t on) {

@@ -470,12 +470,12 @@ def test_x3_forward_and_dgrad_match_fp32_path(pkg):
 
 def test_x3_same_convolutions_match_fp32_path(pkg):
     """Opt-in p3d_x3 path for R x R "same" convolutions (stride 1, pad = dil (R - 1) / 2): forward (with and without bias, ragged 272-channel output) and data
-    gradient (also accumulating into an existing gradient) against float64, at the fp32 kernel's error level; the weight gradient stays on the fp32 kernel."""
+    gradient and (for the large weights) weight gradient against float64, at the fp32 kernel's error level."""
     ops = pkg.ops
     gen = torch.Generator(device='cuda').manual_seed(11)
     F = torch.nn.functional
     try:
-        for (n, c, k, h, r, dil, with_bias) in [(64, 128, 128, 32, 3, 1, False), (64, 256, 272 + 64, 16, 3, 1, True), (64, 128, 512, 16, 3, 2, False), (2, 64, 64, 64, 3, 1, False),
+        for (n, c, k, h, r, dil, with_bias) in [(64, 128, 128, 32, 3, 1, False), (64, 256, 272 + 64, 16, 3, 1, True), (64, 128, 512, 16, 3, 2, False), (2, 64, 64, 64, 3, 1, False), (4, 512, 512, 16, 3, 2, False), (3, 2048, 272, 16, 3, 1, True),
                                                 (64, 128, 128, 32, 5, 1, True)]:
             x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 4 - 2).exp2()
             w0 = torch.randn(k, c, r, r, device='cuda', generator=gen) / (c * r * r) ** 0.5
@@ -502,6 +502,10 @@ def test_x3_same_convolutions_match_fp32_path(pkg):
                 e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
                 assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, r, dil, i, e32, e3)
                 assert torch.equal(res[False][i], res[True][i]) != covered, (n, c, k, h, r, dil, i)
-            assert torch.equal(res[False][2], res[True][2])                        # R x R weight gradients are not on the opt-in path
+            dw_ref = torch.nn.grad.conv2d_weight(x.double(), w0.shape, dy.double(), 1, pad, dil)
+            scale = dw_ref.abs().max()
+            e32, e3 = ((res[False][2] - dw_ref).abs().max() / scale).item(), ((res[True][2] - dw_ref).abs().max() / scale).item()
+            assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, r, dil, 'wgrad', e32, e3)
+            assert torch.equal(res[False][2], res[True][2]) != (k >= 128 and c >= 128 and k * c >= 512 * 512 and h % 16 == 0)
     finally:
         ops.set_x3(False)
