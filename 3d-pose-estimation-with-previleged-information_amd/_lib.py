@@ -39,6 +39,7 @@ SIGNATURES = {
     'p3d_conv2d_wgrad_workspace_bytes': (_sz, [_desc]),
     'p3d_conv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
+    'p3d_conv2d_bgrad_masked': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
     'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
     'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     'p3d_distill_fwd_bwd': (_i32, [_ptr] * 5 + [_i32, _i32, _i32, _i32, _f32, _ptr, _sz, _ptr]),
     'p3d_augment_colour': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr]),
     'p3d_augment_erase': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_augment_occlude': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_x3_enable': (_i32, [_i32]),
     'p3d_reproject_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),

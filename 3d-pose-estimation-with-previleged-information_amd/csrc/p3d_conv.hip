@@ -809,13 +809,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tapm_kernel(const float* __r
     for (int e = threadIdx.x; e < n; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
 }
 
-// db[k] = sum over n, hw of dy[n][k][hw]; one block per channel
-__global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int K, int HW, int accumulate) {
+// db[k] = sum over n, hw of dy[n][k][hw] (* mask_out[n][hw] of a partial conv, mask_out == (mult > 0): partial_conv.py:48-51); one block per channel
+__global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy, const float* __restrict__ mult, float* __restrict__ db, int N, int K, int HW,
+                                                    int accumulate) {
     const int k = blockIdx.x;
     double s = 0.0;
     for (int n = 0; n < N; ++n) {
         const float* src = dy + ((size_t)n * K + k) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += src[i];
+        if (mult) {
+            const float* mu = mult + (size_t)n * HW;
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) s += mu[i] > 0.f ? src[i] : 0.f;
+        } else {
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) s += src[i];
+        }
     }
     __shared__ double red[4];
     s = wave_sum(s);
@@ -1381,8 +1387,14 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
 
 int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream) {
     P3D_REQUIRE(dy && db && N > 0 && K > 0 && HW > 0, "conv2d_bgrad: bad argument");
-    hipLaunchKernelGGL(bgrad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, db, N, K, HW, accumulate);
+    hipLaunchKernelGGL(bgrad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, (const float*)nullptr, db, N, K, HW, accumulate);
     return check_launch("conv2d_bgrad");
+}
+
+int32_t p3d_conv2d_bgrad_masked(const float* dy, const float* mult, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream) {
+    P3D_REQUIRE(dy && mult && db && N > 0 && K > 0 && HW > 0, "conv2d_bgrad_masked: bad argument");
+    hipLaunchKernelGGL(bgrad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dy, mult, db, N, K, HW, accumulate);
+    return check_launch("conv2d_bgrad_masked");
 }
 
 int32_t p3d_mask_count_fwd(const p3d_conv_desc* d, const float* mask, float* mult, float* mask_out, void* stream) {

@@ -133,9 +133,16 @@ __global__ __launch_bounds__(256) void augment_colour_kernel(float* __restrict__
     float* pb = pg + HW;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
         float r = pr[i] / 255.0f, g = pg[i] / 255.0f, bl = pb[i] / 255.0f;
-        // augment_colour.py:6-12 brightness, :15-24 contrast
-        r = clip01(r + bright); g = clip01(g + bright); bl = clip01(bl + bright);
-        r = clip01((r - 0.5f) * contrast + 0.5f); g = clip01((g - 0.5f) * contrast + 0.5f); bl = clip01((bl - 0.5f) * contrast + 0.5f);
+        // augment_colour.py:6-12 brightness, :15-24 contrast.  numpy does `image -= 0.5; image *= u; image += 0.5` as three rounded fp32
+        // operations: no fused multiply-add here, so the uint8 result is bit-identical to the reference's (tests/golden/augment.npz)
+        r = clip01(__fadd_rn(r, bright)); g = clip01(__fadd_rn(g, bright)); bl = clip01(__fadd_rn(bl, bright));
+        r = clip01(__fadd_rn(__fmul_rn(__fadd_rn(r, -0.5f), contrast), 0.5f));
+        g = clip01(__fadd_rn(__fmul_rn(__fadd_rn(g, -0.5f), contrast), 0.5f));
+        bl = clip01(__fadd_rn(__fmul_rn(__fadd_rn(bl, -0.5f), contrast), 0.5f));
+        if (hue == 0.f && sat == 1.f) {        // no hue / saturation jitter drawn: the HSV round trip is the identity, skip its rounding
+            pr[i] = floorf(__fmul_rn(r, 255.f)); pg[i] = floorf(__fmul_rn(g, 255.f)); pb[i] = floorf(__fmul_rn(bl, 255.f));
+            continue;
+        }
         // RGB -> HSV
         const float vmax = fmaxf(r, fmaxf(g, bl)), vmin = fminf(r, fminf(g, bl));
         const float diff = vmax - vmin;
@@ -187,6 +194,29 @@ __global__ __launch_bounds__(256) void augment_erase_kernel(float* __restrict__ 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rw * rh; i += gridDim.x * blockDim.x) {
         const int yy = i / rw, xx = i - yy * rw;
         dst[(y0 + yy) * W + x0 + xx] = col;
+    }
+}
+
+// augment_occluder.paste_over (augment_occluder.py:7-55): alpha-blend a (pre-resized) occluder into the image.  One row of `plan` per image:
+// {dst_y0, dst_x0, src_y0, src_x0, h, w, occ_w, bank offset in pixels}; h <= 0 or w <= 0: nothing to paste.  The occluder bank holds interleaved
+// [pixel][C] values, alpha one value per pixel.  image = alpha * occluder + (1 - alpha) * image as three rounded fp32 operations (numpy's), then the
+// truncation of the assignment into a uint8 image.
+__global__ __launch_bounds__(256) void augment_occlude_kernel(float* __restrict__ img, const float* __restrict__ bank, const float* __restrict__ alpha,
+                                                              const int32_t* __restrict__ plan, int C, int H, int W, int truncate) {
+    const int b = blockIdx.y;
+    const int32_t* pl = plan + b * 8;
+    const int dy0 = pl[0], dx0 = pl[1], sy0 = pl[2], sx0 = pl[3], h = pl[4], w = pl[5], ow = pl[6], off = pl[7];
+    if (h <= 0 || w <= 0) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < h * w; i += gridDim.x * blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        const int src = off + (sy0 + yy) * ow + sx0 + xx;
+        const float a = alpha ? alpha[src] : 1.f;
+        const float na = __fadd_rn(1.f, -a);
+        for (int c = 0; c < C; ++c) {
+            float* d = img + (((size_t)b * C + c) * H + dy0 + yy) * W + dx0 + xx;
+            const float v = __fadd_rn(__fmul_rn(a, bank[(size_t)src * C + c]), __fmul_rn(na, *d));
+            *d = truncate ? truncf(fminf(fmaxf(v, 0.f), 255.f)) : v;
+        }
     }
 }
 
@@ -381,6 +411,15 @@ int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H
     const unsigned bx = (unsigned)(ceil_div(HW, 256) < 64 ? ceil_div(HW, 256) : 64);
     hipLaunchKernelGGL(augment_colour_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, img, params, HW);
     return check_launch("augment_colour");
+}
+
+int32_t p3d_augment_occlude(float* img, const float* bank, const float* alpha, const int32_t* plan, int32_t B, int32_t C, int32_t H, int32_t W,
+                            int32_t max_pixels, int32_t truncate, void* stream) {
+    P3D_REQUIRE(img && bank && plan && B > 0 && C > 0 && H > 0 && W > 0 && max_pixels >= 0, "augment_occlude: bad argument");
+    if (max_pixels == 0) return P3D_OK;
+    const unsigned bx = (unsigned)(ceil_div(max_pixels, 256) < 64 ? ceil_div(max_pixels, 256) : 64);
+    hipLaunchKernelGGL(augment_occlude_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, img, bank, alpha, plan, C, H, W, truncate);
+    return check_launch("augment_occlude");
 }
 
 int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C, int32_t H, int32_t W,

@@ -42,7 +42,10 @@ ENHANCE_THRESHOLD = dict(ntu=0.1, pku=0.5)                # enhance_ntu / enhanc
 def shard(samples, phase):
     """One process per GPU: under torchrun each rank trains on every WORLD_SIZE-th sample (nn.DataParallel split each batch instead)."""
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
-    return samples[rank::world] if (world > 1 and phase == 'train') else samples
+    if world > 1 and phase == 'train':
+        # equal shard lengths: a rank with one batch more than the others would wait forever in the gradient all-reduce
+        return samples[:len(samples) // world * world][rank::world]
+    return samples
 
 
 class Dataset(data.Dataset):

@@ -108,8 +108,9 @@ class Trainer:
             self.semi_worker = iter(self.semi_loader)
 
         self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
-        self.reducer = p3d_dist.GradReducer(self.optimizer, reducer_bucket_bytes)
+        self.reducer = p3d_dist.GradReducer(self.optimizer, reducer_bucket_bytes, model=model)
         self.world = self.reducer.world
+        p3d_dist.broadcast_state(self.optimizer, model)       # all ranks start from rank 0's replica (no-op without a process group)
         if self.half_acc:
             # depth_train.py:73-83: the reference halves the model and keeps fp32 `copy_params` for Adam.  Here the parameters stay
             # fp32 (they are those copies, already flat inside FlatAdam) and every convolution gets fp16 weight images beside them.
@@ -164,8 +165,11 @@ class Trainer:
     def attach_reducer(self, bucket_bytes=p3d_dist.DEFAULT_BUCKET_BYTES):
         """(Re)create the gradient reducer: call after the process group has been initialised if the trainer was built before it."""
         self.reducer.remove()
-        self.reducer = p3d_dist.GradReducer(self.optimizer, bucket_bytes)
+        self.reducer = p3d_dist.GradReducer(self.optimizer, bucket_bytes, model=self.model)
         self.world = self.reducer.world
+        p3d_dist.broadcast_state(self.optimizer, self.model)
+        if self.half_acc:
+            ops_half.refresh_weights(self.model, self.optimizer.flat_p)
 
     # ---- schedules ---------------------------------------------------------------------------
     def adapt_learn_rate(self, epoch):
@@ -219,14 +223,14 @@ class Trainer:
             # static loss scaling (depth_train.py:413-449): gradients carry grad_scaling through the fp16 backward, the optimizer
             # divides it out, and a step whose gradients overflowed is skipped
             loss.backward(torch.full_like(loss, self.grad_scaling))
-            assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
+            ops.check_joins()
             scale = self.reducer.finish()
             # overflow test, skip decision and step counter stay on the device (FlatAdam.clip_and_step_dev): no host read-back per step
             self.optimizer.clip_and_step_dev(self.grad_norm, grad_scale=scale / self.grad_scaling, skip_nonfinite=True)
             ops_half.refresh_weights(self.model, self.optimizer.flat_p)          # (a skipped step re-casts unchanged weights)
             return
         loss.backward()
-        assert ops.pending_joins() == 0, 'a shortcut gradient was produced but never joined (ops.GradJoin)'
+        ops.check_joins()
         scale = self.reducer.finish()
         self.optimizer.clip_and_step(self.grad_norm, grad_scale=scale)
 

@@ -1,7 +1,7 @@
 """Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI, overlapped with backward.
 
-Replaces nn.DataParallel (depth_main.py:72): no per-step parameter broadcast (every rank applies the
-identical clip + Adam update to identical weights), no output gather (head and loss run on each rank's
+Replaces nn.DataParallel (depth_main.py:72): ONE parameter broadcast when the reducer is attached (broadcast_state)
+instead of one per step (every rank then applies the identical clip + Adam update to identical weights), no output gather (head and loss run on each rank's
 shard), and the gradient reduce-add becomes a bucketed sum-all-reduce of the flat gradient buffer.
 BatchNorm statistics stay per rank, as under DataParallel.
 
@@ -67,9 +67,11 @@ FORCE_GROUP = bool(os.environ.get('P3D_FORCE_DIST'))
 class GradReducer:
     """Bucketed, backward-overlapped sum-all-reduce of a FlatAdam gradient buffer."""
 
-    def __init__(self, optimizer, bucket_bytes=DEFAULT_BUCKET_BYTES, group=None):
+    def __init__(self, optimizer, bucket_bytes=DEFAULT_BUCKET_BYTES, group=None, model=None):
         self.opt = optimizer
         self.group = group
+        self._forwards = 0
+        self._fwd_hook = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = plan_buckets(optimizer.slices(), bucket_bytes, optimizer.total)
         self._bucket_of = {}
@@ -85,9 +87,21 @@ class GradReducer:
                 hook = self._make_hook(idx)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))       # gradients that arrive through autograd
                 p._p3d_grad_ready = (lambda h=hook, q=p: h(q))                        # gradients the HIP kernels wrote in place (ops._grad_done)
+            if model is not None:
+                # A parameter's "gradient complete" report counts ONE use.  When the network runs forward more than once before a
+                # single backward (-semi_teach: labelled batch + unlabelled batch, depth_train.py:222-230) every parameter has several
+                # uses, the first report would start the bucket's all-reduce while later kernels still accumulate into the same range
+                # of flat_g.  Forward passes are counted per step; with more than one, no bucket is launched from a hook and finish()
+                # sends them all after backward has returned.
+                self._fwd_hook = model.register_forward_pre_hook(self._on_forward)
         self.reset()
 
+    def _on_forward(self, module, inputs):
+        if torch.is_grad_enabled():
+            self._forwards += 1
+
     def reset(self):
+        self._forwards = 0
         self._seen = [False] * len(self.opt.params)      # a parameter counts once per step, whichever path reports it first
         self._pending = [len(m) for _, _, m in self.buckets]
         self._launched = [False] * len(self.buckets)
@@ -97,7 +111,7 @@ class GradReducer:
         def hook(param):
             # Both paths can report one parameter: the HIP kernels signal as soon as they have written .grad in place
             # (ops._grad_done), and autograd still runs the post-accumulate hook of a parameter whose Function returned None.
-            if self._seen[idx]:
+            if self._seen[idx] or self._forwards > 1:     # several forward passes share this backward: finish() launches the buckets
                 return
             self._seen[idx] = True
             b = self._bucket_of[idx]
@@ -146,9 +160,30 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._fwd_hook is not None:
+            self._fwd_hook.remove()
+            self._fwd_hook = None
         for p in self.opt.params:
             if hasattr(p, '_p3d_grad_ready'):
                 del p._p3d_grad_ready
+
+
+def broadcast_state(optimizer, model, src=0, group=None):
+    """Make every rank start from rank `src`'s replica: the flat parameter buffer, the Adam moments and every module buffer (BatchNorm running
+    statistics).  nn.DataParallel re-broadcast the parameters before every forward (depth_main.py:72); here the replicas stay identical only
+    because every rank applies the same update to the same weights, so they must BE the same once: random initialisation (kaiming_normal_,
+    the regressor's default init) differs per process unless this runs.  No-op without a process group."""
+    if not dist.is_initialized() or dist.get_world_size(group) < 2:
+        return
+    with torch.no_grad():
+        for t in (optimizer.flat_p, optimizer.exp_avg, optimizer.exp_avg_sq):
+            dist.broadcast(t, src, group=group)
+        step = torch.tensor([optimizer.steps_taken()], dtype=torch.int64, device=optimizer.flat_p.device)
+        dist.broadcast(step, src, group=group)
+        optimizer.step_count = int(step.item())
+        optimizer.dev_state = None
+        for buf in model.buffers():
+            dist.broadcast(buf, src, group=group)
 
 
 def global_valid_divisor(true_val, group=None):

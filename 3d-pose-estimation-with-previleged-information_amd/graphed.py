@@ -35,12 +35,28 @@ class GraphedStep:
         tr = self.trainer
         self.static = tuple(None if t is None else t.clone() for t in batch)
         run = self._run
+        # the eager warm-up steps must not train: parameters, Adam moments, step counters and BatchNorm buffers are put back afterwards,
+        # so the first call of step() amounts to exactly one optimisation step (the first replay), like every later call
+        opt = tr.optimizer
+        if opt.dev_state is None:
+            opt.dev_state = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=opt.flat_p.device)
+            opt._dev_scratch = torch.zeros(4, dtype=torch.float32, device=opt.flat_p.device)
+        saved = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.dev_state)]
+        saved_buffers = [b.clone() for b in tr.model.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on a side stream, as the PyTorch capture recipe asks
             for _ in range(self.warmup):
                 run()
         torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for dst, src in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.dev_state), saved):
+                dst.copy_(src)
+            for dst, src in zip(tr.model.buffers(), saved_buffers):
+                dst.copy_(src)
+        if tr.half_acc:
+            from . import ops_half
+            ops_half.refresh_weights(tr.model, opt.flat_p)
         torch.cuda.synchronize()
         profile, ops.PROFILE = ops.PROFILE, None           # timing events cannot be recorded inside a capture
         self.graph = torch.cuda.CUDAGraph()
@@ -64,7 +80,7 @@ class GraphedStep:
         batch = (color_image, depth_image, true_cam, true_val)
         shapes = tuple(None if t is None else tuple(t.shape) for t in batch)
         if self.graph is None or shapes != self._shapes or self.trainer.optimizer.param_groups[0]['lr'] != self._lr:
-            self._capture(batch)                           # eager warm-up steps train on this batch; the capture pass only records
+            self._capture(batch)                           # warm-up steps are rolled back; the capture pass only records
             self.graph.replay()
             return self.loss
         for dst, src in zip(self.static, batch):

@@ -86,8 +86,9 @@ def main(argv=None):
     if world > 1 or p3d_dist.FORCE_GROUP:
         p3d_dist.init_from_env()
         trainer.reducer.remove()
-        trainer.reducer = p3d_dist.GradReducer(trainer.optimizer)
+        trainer.reducer = p3d_dist.GradReducer(trainer.optimizer, model=model)
         trainer.world = trainer.reducer.world
+        p3d_dist.broadcast_state(trainer.optimizer, model)        # random initialisation differs per process: start from rank 0's replica
     if args.test_only or args.val_only:
         return trainer.test(0, _test_tuples(test_loader, args.joint_space))
     for epoch in range(logger.state['epoch'] + 1, args.n_epochs + 1):

@@ -169,13 +169,17 @@ class GradJoin:
     produced FIRST (the shortcut's: residual gradient of the closing BN, or the dgrad of the downsample conv) to the op that runs
     LAST (the first conv of the main path, created first in forward, hence last in backward), whose dgrad kernel then accumulates
     into that buffer (`accumulate = 1`).  The producer returns None to autograd, the consumer returns the joined buffer.
-    If the consumer finds the slot empty it behaves normally, so a different execution order costs speed, never correctness;
-    `pending_joins()` lets the trainer assert that no produced gradient was left unconsumed."""
-    __slots__ = ('buf', '__weakref__')
+    Order independence: the consumer marks the join `taken` when its backward runs; a consumer that finds the slot empty behaves
+    normally, and a producer that runs AFTER the consumer (or whose consumer needs no input gradient) sees `taken` and returns its
+    gradient to autograd like any other Function, so the shortcut gradient is never dropped.  A gradient that was stashed but never
+    picked up (the consumer's backward did not run at all) is an error: the first stash of a pass queues an engine callback that
+    raises P3DError when the pass ends (`check_joins`), whoever called .backward()."""
+    __slots__ = ('buf', 'taken', '__weakref__')
     _live = None
 
     def __init__(self):
         self.buf = None
+        self.taken = False
         if GradJoin._live is None:
             import weakref
             GradJoin._live = weakref.WeakSet()
@@ -184,6 +188,33 @@ class GradJoin:
 
 def pending_joins():
     return 0 if GradJoin._live is None else sum(1 for j in GradJoin._live if j.buf is not None)
+
+
+_join_check_queued = False
+
+
+def check_joins():
+    """Raise if a shortcut gradient was stashed in a GradJoin and never consumed (it would silently be missing from the input gradient)."""
+    global _join_check_queued
+    _join_check_queued = False
+    n = pending_joins()
+    if n:
+        for j in GradJoin._live:
+            j.buf = None
+        raise P3DError('%d shortcut gradient(s) were produced but never joined (ops.GradJoin): the backward pass did not reach the first '
+                       'convolution of a residual block' % n)
+
+
+def _stash(join, grad):
+    """Producer side of a GradJoin: True if `grad` was handed to the join (return None to autograd), False if the consumer has already run."""
+    global _join_check_queued
+    if join is None or join.taken:
+        return False
+    join.buf = grad
+    if not _join_check_queued:
+        _join_check_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(check_joins)
+    return True
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -222,9 +253,13 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         # dy is complete at this point of the launch stream: the wgrad stream waits for THIS event, not for the dgrad launched below
         dy_ready = _mark_ready() if (WGRAD_STREAM and ctx.needs_input_grad[1]) else None
+        if join_take is not None:
+            join_take.taken = True                            # producers that run later return their gradient to autograd themselves
         if ctx.needs_input_grad[0]:
             joined = join_take.buf if join_take is not None else None
-            if joined is not None and joined.shape == x.shape:
+            if joined is not None:
+                if joined.shape != x.shape or joined.dtype != x.dtype:
+                    raise P3DError('GradJoin: the shortcut gradient %s does not match the block input %s' % (tuple(joined.shape), tuple(x.shape)))
                 dx, join_take.buf = joined, None              # accumulate onto the shortcut's gradient: no separate add pass
                 d.accumulate = 1
             else:
@@ -233,8 +268,8 @@ class Conv2dFn(torch.autograd.Function):
             with _Timed('dgrad', d):
                 check(L.p3d_conv2d_dgrad(ctypes.byref(d), _p(dy), _p(w), _p(mult), _p(mask_in), _p(dx), _p(ws), ws.numel(), st), 'p3d_conv2d_dgrad')
             d.accumulate = 0
-            if join_put is not None:
-                join_put.buf, dx = dx, None                   # the consumer returns it
+            if _stash(join_put, dx):
+                dx = None                                     # the consumer returns it
         w_param, b_param = ctx.params
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(w_param)
@@ -263,7 +298,10 @@ class Conv2dFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             sink = _grad_sink(b_param)
             db = torch.empty(d.K, dtype=torch.float32, device=x.device) if sink is None else sink
-            check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), 0 if sink is None else 1, st), 'p3d_conv2d_bgrad')
+            if mult is not None:      # PartialConv with bias: d out / d b = mask_out (partial_conv.py:48-51)
+                check(L.p3d_conv2d_bgrad_masked(_p(dy), _p(mult), d.N, d.K, d.Ho * d.Wo, _p(db), 0 if sink is None else 1, st), 'p3d_conv2d_bgrad_masked')
+            else:
+                check(L.p3d_conv2d_bgrad(_p(dy), d.N, d.K, d.Ho * d.Wo, _p(db), 0 if sink is None else 1, st), 'p3d_conv2d_bgrad')
             if sink is not None:
                 db = None
                 _grad_done(b_param)
@@ -406,8 +444,8 @@ class BatchNormActFn(torch.autograd.Function):
             dgamma = dbeta = None
             _grad_done(g_param)
             _grad_done(b_param)
-        if ctx.res_join is not None and dres is not None and relu:     # (without ReLU dres aliases dy: never hand that out)
-            ctx.res_join.buf, dres = dres, None
+        if dres is not None and relu and _stash(ctx.res_join, dres):    # (without ReLU dres aliases dy: never hand that out)
+            dres = None
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 
@@ -672,6 +710,17 @@ def augment_erase_(img, rects, colour):
     if rects.dtype != torch.int32 or not img.is_contiguous():
         raise P3DError('augment_erase: rects must be int32 and img contiguous')
     check(lib().p3d_augment_erase(_p(img), _p(rects.contiguous()), _p(colour.contiguous()), b, c, h, w, _stream()), 'p3d_augment_erase')
+    return img
+
+
+def augment_occlude_(img, bank, alpha, plan, max_pixels, truncate=True):
+    """In place: paste one occluder per image (augment_occluder.py:7-55).  bank [P,C] fp32, alpha [P] fp32 or None, plan [B,8] int32 (augment.plan_paste)."""
+    _need_gpu(img, bank, alpha)
+    b, c, h, w = img.shape
+    if plan.dtype != torch.int32 or not plan.is_cuda or tuple(plan.shape) != (b, 8) or not img.is_contiguous() or bank.shape[-1] != c:
+        raise P3DError('augment_occlude: plan must be int32 [B,8] on the device, img contiguous, bank [P,C]')
+    check(lib().p3d_augment_occlude(_p(img), _p(bank.contiguous()), _p(None if alpha is None else alpha.contiguous()), _p(plan.contiguous()), b, c, h, w,
+                                    int(max_pixels), int(bool(truncate)), _stream()), 'p3d_augment_occlude')
     return img
 
 

@@ -182,12 +182,16 @@ class HConv2dFn(torch.autograd.Function):
             scaled = torch.empty_like(dy, memory_format=CL)
             check(L.p3d_hscale_pixels(_p(dy), _p(mult), _p(scaled), n * d.Ho * d.Wo, k, st), 'p3d_hscale_pixels')
             dy = scaled
+        join_put, join_take = ctx.joins
+        if join_take is not None:
+            join_take.taken = True
         if ctx.needs_input_grad[0]:
             if images.crsk is None:
                 raise P3DError('hconv2d: this layer was built without a dgrad weight image')
-            join_put, join_take = ctx.joins
             joined = join_take.buf if join_take is not None else None
-            if joined is not None and joined.shape == x.shape and joined.dtype == torch.float16:
+            if joined is not None and (joined.shape != x.shape or joined.dtype != torch.float16):
+                raise P3DError('GradJoin: the shortcut gradient %s does not match the block input %s' % (tuple(joined.shape), tuple(x.shape)))
+            if joined is not None:
                 dx, join_take.buf = _cl(joined), None          # accumulate onto the shortcut's gradient (ops.GradJoin)
                 d.accumulate = 1
             else:
@@ -195,8 +199,8 @@ class HConv2dFn(torch.autograd.Function):
             with ops._Timed('dgrad', d):
                 check(L.p3d_hconv2d_dgrad(ctypes.byref(d), _p(dy), _p(images.crsk), _p(mask_in), _p(dx), st), 'p3d_hconv2d_dgrad')
             d.accumulate = 0
-            if join_put is not None:
-                join_put.buf, dx = dx, None
+            if ops._stash(join_put, dx):
+                dx = None
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(w_param)
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device) if sink is None else sink
@@ -293,8 +297,8 @@ class HBatchNormActFn(torch.autograd.Function):
             dgamma = dbeta = None
             _grad_done(g_param)
             _grad_done(b_param)
-        if ctx.res_join is not None and dres is not None and relu:     # (without ReLU dres aliases dy: never hand that out)
-            ctx.res_join.buf, dres = dres, None
+        if dres is not None and relu and ops._stash(ctx.res_join, dres):     # (without ReLU dres aliases dy: never hand that out)
+            dres = None
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 

@@ -10,8 +10,15 @@ offset), and so are their gradients and the Adam moments.  Consequences:
 The reference's two param groups carry identical hyper-parameters (wrap_by_name, depth_train.py:22-25,
 weight decay on BN and bias included), so one flat group reproduces it; `param_groups` keeps two dicts
 because adapt_learn_rate writes both (depth_train.py:637-638).
+
+Difference from torch.optim.Adam, by construction: the update runs over the WHOLE flat buffer, so a parameter that received no gradient
+in a step is still pulled by the weight decay (g = wd * p) and its moments decay, where optim.Adam skips parameters whose .grad is None.
+The two agree whenever every registered parameter takes part in every step, which holds for every network / flag combination of the
+reference (only `requires_grad` parameters are registered; frozen ones never enter the buffer).  `P3D_CHECK_GRADS=1` makes
+`clip_and_step*` verify that on the device (a parameter whose gradient range is exactly zero raises).
 """
 import math
+import os
 
 import torch
 
@@ -69,10 +76,18 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p)
 
+    def _check_all_touched(self):
+        if not os.environ.get('P3D_CHECK_GRADS'):
+            return
+        for name, p in zip(self.names, self.params):
+            if p.grad is not None and not bool(p.grad.ne(0).any()):
+                raise RuntimeError('FlatAdam: parameter %r received no gradient this step; the flat update would still apply weight decay to it' % name)
+
     def clip_and_step(self, max_norm, grad_scale=1.0, skip_nonfinite=False):
         """clip_grad_norm_(params, max_norm) followed by Adam.step(); grad_scale (1/world_size) is applied first.
         skip_nonfinite (the -half_acc overflow rule, depth_train.py:431-446): read the norm back and return False WITHOUT stepping
         when any gradient is inf / nan; otherwise returns True."""
+        self._check_all_touched()
         self.norm_sq.zero_()
         if (max_norm and max_norm > 0) or skip_nonfinite:
             ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
@@ -90,6 +105,7 @@ class FlatAdam:
         if self.dev_state is None:
             self.dev_state = torch.tensor([self.step_count, 0], dtype=torch.int32, device=self.flat_p.device)
             self._dev_scratch = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
+        self._check_all_touched()
         self.norm_sq.zero_()
         ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
         ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0], self.betas[1],

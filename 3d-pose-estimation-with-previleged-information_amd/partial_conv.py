@@ -27,8 +27,8 @@ class PartialConv(Conv2d):
         k, stride, pad, dil = _one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)
         with torch.no_grad():
             mult, mask_out = ops.mask_count(mask_in, k, stride, pad, dil)    # partial_conv.py:35-43
-        if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled():
-            raise ops.P3DError('PartialConv with a trainable bias: backward is not implemented (no reference network uses it)')
+        if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled() and input.dtype == torch.float16:
+            raise ops.P3DError('PartialConv with a trainable bias under -half_acc: backward is not implemented (no reference network uses it)')
         if input.dtype == torch.float16:                                    # -half_acc: masks stay fp32 [B,1,H,W], activations NHWC fp16
             from . import ops_half
             output = ops_half.conv2d(input, self, stride, pad, dil, join_put, join_take, mask_in=mask_in.contiguous(), mult=mult)

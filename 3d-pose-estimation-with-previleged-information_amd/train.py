@@ -33,8 +33,9 @@ class Trainer:
             raise NotImplementedError('-half_acc is not available in the legacy trainer (use depth_main -half_acc)')
         assert args.do_track <= args.joint_space                                  # main.py:72
         self.optimizer = FlatAdam(list(model.named_parameters()), args.learn_rate, weight_decay=args.weight_decay)
-        self.reducer = p3d_dist.GradReducer(self.optimizer)
+        self.reducer = p3d_dist.GradReducer(self.optimizer, model=model)
         self.world = self.reducer.world
+        p3d_dist.broadcast_state(self.optimizer, model)
         self.depth = args.depth
         self.num_joints = args.num_joints
         self.side_in = args.side_in

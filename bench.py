@@ -4,9 +4,12 @@
 Workload (BASELINE.json configs[1], the one the metric is quoted on): depthnet ResNet-50 RGB pose head,
 synthetic 256x256x3 crops, batch 64 per GPU, fp32: forward -> soft-argmax head -> SmoothL1 -> backward ->
 [RCCL gradient all-reduce, overlapped] -> global-norm clip -> Adam.  Inputs are resident in HBM before the
-timed region.  One process per GPU; for N > 1 launch with
+timed region.  One process per GPU.  Either launch N > 1 as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+or simply `python bench.py --gpus N`: with WORLD_SIZE unset the parent starts that launcher itself (before it touches the GPU, like the
+reference's own `-n_cudas N`, depth_main.py:72, needs no external launcher), relays rank 0's line and exits with the children's code.
 Rank 0 prints ONE JSON line (contract in the task statement; `roofline` and `cpu_baseline` described in DESIGN.md).
+Protocol of BASELINE.md section 4: >= 10 warm-up and >= 50 timed steps by default, device-synchronised at both ends.
 """
 import argparse
 import importlib
@@ -42,15 +45,47 @@ def cpu_baseline(pkg, model_name, batch, steps):
     for i in range(steps):
         port.train_step(*batches[i % 2], lr=1e-5)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit='crops/s', cores=cores, kind='port',
+    return dict(value=round(batch * steps / dt, 3), unit='crops/s', cores=cores, kind='port', cpu=cpu_model(),
                 sample='%s 256x256 bs=%d, %d timed steps after 1 warm-up (oracle/torch_port.py, fp32)' % (model_name, batch, steps))
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  Nothing here has touched the GPU (no HIP call, torch not
+    even imported), so the children are ordinary subprocesses; their stdout (rank 0's single JSON line) is relayed and their exit code
+    becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith('{') and '"metric"' in line:
+            print(line, flush=True)
+    return proc.returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=64, help='crops per GPU')
     ap.add_argument('--model', default='resnet50')
     ap.add_argument('--family', default='depthnet', choices=['depthnet', 'fusionnet', 'partial_depthnet', 'partial_fusionnet'],
@@ -58,8 +93,12 @@ def main():
     ap.add_argument('--augment', action='store_true', help='BASELINE config 5: colour + eraser augmentation and normalisation of a raw RGB batch on the GPU, inside the timed step')
     ap.add_argument('--half', action='store_true', help='informational: the -half_acc (fp16 NHWC) path; the contract line is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline sample (the bench config; 8 = the survey container\'s sample)')
     opt = ap.parse_args()
+
+    if opt.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(opt.gpus))
 
     import torch
     import torch.distributed as dist
@@ -71,7 +110,7 @@ def main():
     if os.environ.get('P3D_BENCH_SHARE_GPU'):      # rehearsal of the N > 1 flow on a one-GPU box (with P3D_DIST_BACKEND=gloo): all ranks on cuda:0
         local_rank = 0
     if world != opt.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 under torch.distributed.run)' % (opt.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (a launcher set a different world size)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
@@ -131,6 +170,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(loss)
+
+    # fwd + bwd only (the literal wording of BASELINE.json's metric; SURVEY 8(d) "also report fwd+bwd only"): the same steps with the
+    # clip + Adam launches left out (the gradient all-reduce stays: it is part of a data-parallel backward).  Never `value`.
+    opt_obj = trainer.optimizer
+    keep = (opt_obj.clip_and_step, opt_obj.clip_and_step_dev)
+    opt_obj.clip_and_step = opt_obj.clip_and_step_dev = (lambda *a, **k: True)
+    fsteps = min(opt.steps, 20)
+    trainer.train_step(*batches[0])
+    sync()
+    tf = time.perf_counter()
+    for i in range(fsteps):
+        trainer.train_step(*batches[i % nbuf])
+    sync()
+    fb_elapsed = time.perf_counter() - tf
+    opt_obj.clip_and_step, opt_obj.clip_and_step_dev = keep
+    if dist.is_initialized():
+        t = torch.tensor([fb_elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fb_elapsed = float(t.item())
 
     # Kernel pass (not part of `value`): the same steps once more with the weight-gradient kernels back on the launch stream.
     # In the product configuration they run concurrently with the dgrad / BN-backward chain on a second stream, so a HIP-event
@@ -198,6 +256,7 @@ def main():
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'fwd_bwd_crops_per_s': round(opt.batch * world * fsteps / fb_elapsed, 2), 'fwd_bwd_ms_per_step': round(fb_elapsed / fsteps * 1e3, 3),
             'vs_baseline': None, 'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
@@ -221,7 +280,7 @@ def main():
             out['roofline']['kernel'] = 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)'
             out['roofline']['traffic'] = None
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
-            out['cpu_baseline'] = cpu_baseline(pkg, opt.model, 8, opt.cpu_steps)
+            out['cpu_baseline'] = cpu_baseline(pkg, opt.model, opt.cpu_batch, opt.cpu_steps)
         if x3_line is not None:
             out['optin_x3'] = x3_line
         print(json.dumps(out), flush=True)

@@ -90,6 +90,9 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
  * Same results to fp32 rounding as the fp32 MFMA path; not used for the contract measurement.  Returns the previous setting. */
 int32_t p3d_x3_enable(int32_t on);
 int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream);
+/* bias gradient of a PartialConv with bias (partial_conv.py:48-51: out = ((raw - b) * mult + b) * mask_out, so d out / d b = mask_out):
+ * db[k] = sum over n, p of dy[n][k][p] * (mult[n][p] > 0);  mult [N,1,Ho,Wo] as written by p3d_mask_count_fwd. */
+int32_t p3d_conv2d_bgrad_masked(const float* dy, const float* mult, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream);
 
 /* partial_conv.py:35-43: cnt = boxsum(mask); mult = R*S/(cnt+1e-6)*clamp(cnt,0,1); mask_out = clamp(cnt,0,1).
  * mask [N,1,H,W] -> mult, mask_out [N,1,Ho,Wo]. */
@@ -211,6 +214,12 @@ int32_t p3d_distill_fwd_bwd(const float* teach, const float* student, const floa
 int32_t p3d_augment_colour(float* img, const float* params, int32_t B, int32_t H, int32_t W, void* stream);
 int32_t p3d_augment_erase(float* img, const int32_t* rects, const float* colour, int32_t B, int32_t C,
                           int32_t H, int32_t W, void* stream);
+/* augment_occluder.paste_over (augment_occluder.py:7-55): alpha-blend one pre-resized occluder per image into img [B,C,H,W] (0..255 values), in place.
+ * bank: the occluders' pixels, interleaved [pixel][C] fp32; alpha: one fp32 per bank pixel, or NULL (opaque); plan [B][8] int32 (device) =
+ * {dst_y0, dst_x0, src_y0, src_x0, h, w, occluder row length, bank offset in pixels} (the clipped rectangles of :31-50, computed on the host);
+ * max_pixels = the largest h*w of the batch; truncate != 0 reproduces the assignment into a uint8 image. */
+int32_t p3d_augment_occlude(float* img, const float* bank, const float* alpha, const int32_t* plan, int32_t B, int32_t C, int32_t H, int32_t W,
+                            int32_t max_pixels, int32_t truncate, void* stream);
 /* Crop re-projection of the loader (depth_datasets.py:153-193 -> cameralib.reproject_image_fast, cameralib.py:667-711) for a batch:
  * dst[b][c][y][x] = bilinear sample of src[b] ([Hs][Ws][C] interleaved, uint8 if src_is_u8 else fp32) at homography[b] * (x, y, 1),
  * constant border 0; uint8 sources are rounded like cv2's uint8 output.  homography: [B][3][3] fp32 (device), new image -> old image. */

@@ -515,3 +515,43 @@ def softargmax2d_bwd(dcoords, heat, coords, map_range):
     field = dc[:, :, 0, None, None] * (gx[None, None, None, :] - coords[:, :, 0, None, None]) + \
         dc[:, :, 1, None, None] * (gy[None, None, :, None] - coords[:, :, 1, None, None])
     return heat * field
+
+
+# --------------------------------------------------------------------------------------
+# augmentation (augment_occluder.py:7-55, augment_colour.py:6-24,48-67)
+# --------------------------------------------------------------------------------------
+
+def paste_over(occluder, image, alpha, center):
+    """augment_occluder.paste_over on a uint8 HWC image; float slice bounds truncate as in the numpy the reference was written for."""
+    shape_occ = np.array(occluder.shape[:2])
+    shape_image = np.array(image.shape[:2])
+    center = np.round(center).astype(int)
+    ideal_start_dst = center - shape_occ / 2
+    ideal_end_dst = ideal_start_dst + shape_occ
+    start_dst = np.maximum(ideal_start_dst, 0)
+    end_dst = np.minimum(ideal_end_dst, shape_image)
+    start_src = start_dst - ideal_start_dst
+    end_src = shape_occ + (end_dst - ideal_end_dst)
+    d0, d1 = [int(v) for v in start_dst], [int(v) for v in end_dst]
+    s0, s1 = [int(v) for v in start_src], [int(v) for v in end_src]
+    if alpha is None:
+        alpha = np.ones(occluder.shape[:2], dtype=np.float32)
+    if alpha.ndim < occluder.ndim:
+        alpha = np.expand_dims(alpha, -1)
+    alpha = alpha[s0[0]:s1[0], s0[1]:s1[1]]
+    occ = occluder[s0[0]:s1[0], s0[1]:s1[1]]
+    region = image[d0[0]:d1[0], d0[1]:d1[1]]
+    image[d0[0]:d1[0], d0[1]:d1[1]] = alpha * occ + (1 - alpha) * region
+    return image
+
+
+def brightness_contrast(image_u8, brightness, contrast):
+    """augment_colour.random_color with no hue / saturation jitter: (image/255) + b, clip, (x - .5) * c + .5, clip, * 255 -> uint8 (fp32 steps)."""
+    x = (image_u8 / 255.0).astype(np.float32)
+    x += brightness
+    x = np.clip(x, 0, 1)
+    x -= 0.5
+    x *= contrast
+    x += 0.5
+    x = np.clip(x, 0, 1)
+    return (x * 255).astype(np.uint8)

@@ -138,6 +138,11 @@ STEP_CASES = {
     'depth_r18_odd_b1': ('depthnet', 'resnet18', 257, 2, 1, 0.2, []),
     'depth_r50_b2': ('depthnet', 'resnet50', 256, 2, 1, 0.0, []),
     'depthonly_r18_b2': ('depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only']),
+    # the other stage geometries of depthnet.py:130-136: stride 8 -> layer3 dilation 2, layer4 dilation 4 at 32x32;
+    # stride 32 -> no dilation, layer4 at 8x8; stride 4 -> layer2 dilation 2, layer3 4, layer4 8 at 64x64 (128-pixel input)
+    'depth_r18_s8_b2': ('depthnet', 'resnet18', 256, 2, 1, 0.0, ['-stride', '8']),
+    'depth_r18_s32_b2': ('depthnet', 'resnet18', 256, 2, 1, 0.0, ['-stride', '32']),
+    'depth_r18_s4_b1': ('depthnet', 'resnet18', 128, 1, 1, 0.0, ['-stride', '4']),
     'fusion_r18_b2': ('fusionnet', 'resnet18', 256, 2, 1, 0.0, ['-do_fusion']),
     'fusion_r50_b1': ('fusionnet', 'resnet50', 256, 1, 1, 0.0, ['-do_fusion']),
     'partial_r18_b2': ('partial_depthnet', 'resnet18', 256, 2, 1, 0.0, ['-depth_only', '-partial_conv']),
@@ -250,6 +255,65 @@ def gen_step(case):
         out['grad_conv1_weight'] = grads['conv1.weight']
     np.savez_compressed(os.path.join(HERE, 'step_%s.npz' % case), **out)
     print('step_%s.npz' % case, 'losses', rec['losses'], 'clip_total', rec['clip_total'])
+
+
+class _OldIndexArray(np.ndarray):
+    """numpy < 1.12 accepted float slice bounds and truncated them; augment_occluder.paste_over (augment_occluder.py:38-52) relies on that."""
+
+    @staticmethod
+    def _fix(key):
+        def one(k):
+            if isinstance(k, slice):
+                return slice(*(None if v is None else int(v) for v in (k.start, k.stop, k.step)))
+            return k
+        return tuple(one(k) for k in key) if isinstance(key, tuple) else one(key)
+
+    def __getitem__(self, key):
+        return super().__getitem__(self._fix(key))
+
+    def __setitem__(self, key, value):
+        super().__setitem__(self._fix(key), value)
+
+
+def gen_augment():
+    """augment_occluder.paste_over (plain numpy, augment_occluder.py:7-55) on uint8 images, and augment_colour.random_color's brightness / contrast
+    leg (augment_colour.py:6-24,48-67) with the two cv2.cvtColor calls as the identity and no hue / saturation jitter drawn.  The HSV leg and
+    random_occlu's cv2.resize stay unpinned (cv2 absent)."""
+    import augment_occluder
+    import augment_colour
+    rng = np.random.Generator(np.random.PCG64(4242))
+    out, meta = {}, []
+    #        name        H   W   oh  ow  centre          alpha
+    cases = [('inside', 40, 48, 10, 14, (20.3, 22.6), True), ('topleft', 40, 48, 12, 16, (2.4, 3.5), True),
+             ('botright', 40, 48, 8, 20, (39.2, 46.8), True), ('opaque', 32, 32, 6, 6, (10.0, 30.0), False),
+             ('oddinside', 40, 48, 9, 13, (18.0, 25.0), True), ('bigger', 24, 24, 40, 30, (12.0, 3.0), True)]
+    for name, h, w, oh, ow, center, with_alpha in cases:
+        image = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+        occ = rng.integers(0, 256, size=(oh, ow, 3)).astype(np.uint8)
+        alpha = rng.random((oh, ow)).astype(np.float32) if with_alpha else None
+        # (alpha=None makes paste_over build a plain np.ones array, which it then slices with float bounds: passed explicitly instead)
+        ref_alpha = np.ones((oh, ow), dtype=np.float32) if alpha is None else alpha
+        res = augment_occluder.paste_over(occ.view(_OldIndexArray), image.copy().view(_OldIndexArray), ref_alpha.view(_OldIndexArray), np.array(center))
+        out.update({name + '.image': image, name + '.occ': occ, name + '.center': np.array(center), name + '.out': np.asarray(res)})
+        if with_alpha:
+            out[name + '.alpha'] = alpha
+        meta.append(dict(name=name, alpha=with_alpha))
+    # brightness / contrast
+    augment_colour.cv2.cvtColor = lambda img, code: img
+    draws = []
+    orig_uniform = np.random.uniform
+    for i, (b, c) in enumerate([(0.1, 1.2), (-0.11, 0.83), (0.0625, 1.0), (-0.125, 1.25)]):
+        seq = iter([b, c, 0.0, 1.0])
+        np.random.uniform = lambda lo, hi, _s=seq: next(_s)
+        image = rng.integers(0, 256, size=(24, 20, 3)).astype(np.uint8)
+        res = augment_colour.random_color(image.copy())
+        out.update({'bc%d.image' % i: image, 'bc%d.out' % i: res})
+        draws.append((b, c))
+    np.random.uniform = orig_uniform
+    out['bc_draws'] = np.array(draws)
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'augment.npz'), **out)
+    print('augment.npz', len(cases), 'paste cases,', len(draws), 'brightness/contrast cases')
 
 
 def gen_eval():
@@ -616,7 +680,7 @@ def gen_camera():
 if __name__ == '__main__':
     want = sys.argv[1:]
     sys.argv = sys.argv[:1]
-    todo = want or ['partial_conv', 'camera', 'joint', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi'] + list(STEP_CASES)
+    todo = want or ['partial_conv', 'camera', 'joint', 'head', 'legacy', 'keys', 'eval', 'distill', 'semi', 'augment'] + list(STEP_CASES)
     for t in todo:
         if t == 'partial_conv':
             gen_partial_conv()
@@ -638,5 +702,7 @@ if __name__ == '__main__':
             gen_semi()
         elif t == 'half_distill':
             gen_half_distill()
+        elif t == 'augment':
+            gen_augment()
         else:
             gen_step(t)

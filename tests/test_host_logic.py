@@ -194,3 +194,79 @@ def test_oracle_crop_warp_properties():
     assert np.allclose(got[0], 0.5 * (f[:, :10, 0] + f[:, 1:11, 0]))
     k = np.array([[100.0, 0, 50], [0, 100.0, 40], [0, 0, 1]])
     assert np.allclose(ref.crop_homography(k, np.eye(3), k, np.eye(3)), np.eye(3), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _replica_worker(rank, world, port, pkg_name, out_dir):
+    """Ranks start from DIFFERENT random initialisations (no shared seed, as under torchrun); Trainer-style set-up must make them one replica.
+    Then a step in which the network runs forward twice before one backward (-semi_teach): per-use "gradient ready" reports must not start a
+    bucket's all-reduce while a later use still accumulates into it."""
+    import importlib
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    pkg = importlib.import_module(pkg_name)
+    pkg.dist.init_from_env(backend='gloo')
+    torch.manual_seed(1234 + 77 * rank)                                     # a different model on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    with torch.no_grad():
+        net[1].running_mean.add_(float(rank + 1))
+    opt = pkg.optim.FlatAdam(list(net.named_parameters()), lr=1e-3)
+    before = opt.flat_p.clone()
+    red = pkg.dist.GradReducer(opt, bucket_bytes=32, model=net)
+    pkg.dist.broadcast_state(opt, net)
+    after, running_mean = opt.flat_p.clone(), net[1].running_mean.clone()
+    # two forward passes, one backward; the HIP kernels' in-place gradient writes are mimicked by calling the ready-callback once per use
+    g = torch.Generator().manual_seed(500 + rank)
+    xa, xb = torch.randn(8, 6, generator=g), torch.randn(8, 6, generator=g)
+    opt.zero_grad()
+    loss = net(xa).pow(2).sum() + net(xb).pow(2).sum()
+    assert red._forwards == 2
+    for p in opt.params:                                                   # "first use finished": must NOT launch anything
+        p._p3d_grad_ready()
+    launched_early = any(red._launched)
+    loss.backward()
+    for p in opt.params:
+        p._p3d_grad_ready()
+    scale = red.finish()
+    torch.save(dict(before=before, after=after, running_mean=running_mean, flat_g=opt.flat_g.clone(), xa=xa, xb=xb,
+                    launched_early=launched_early, scale=scale), os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_start_identical_and_two_forward_step_reduces_once(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_replica_worker, args=(2, port, pkg.__name__, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in (0, 1))
+    assert not torch.equal(r0['before'], r1['before'])                      # the ranks really started apart ...
+    assert torch.equal(r0['after'], r1['after']) and torch.equal(r0['after'], r0['before'])      # ... and continue from rank 0's replica
+    assert torch.equal(r0['running_mean'], r1['running_mean'])
+    assert not r0['launched_early'] and not r1['launched_early']
+    assert torch.equal(r0['flat_g'], r1['flat_g']) and r0['scale'] == 0.5
+    # single-process reference: both ranks' two-pass gradients summed, on rank 0's weights
+    torch.manual_seed(1234)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    total = None
+    for r in (r0, r1):
+        net.zero_grad()
+        (net(r['xa']).pow(2).sum() + net(r['xb']).pow(2).sum()).backward()
+        flat = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in net.parameters()])
+        total = flat if total is None else total + flat
+    assert torch.allclose(r0['flat_g'], total, rtol=1e-5, atol=1e-6)
+
+
+def test_shards_have_equal_length(pkg, monkeypatch):
+    """129 samples on 2 ranks, batch 64: unequal shards would give one rank a third batch and hang the other in the all-reduce."""
+    samples = list(range(129))
+    lens = []
+    for rank in (0, 1):
+        monkeypatch.setenv('WORLD_SIZE', '2')
+        monkeypatch.setenv('RANK', str(rank))
+        part = pkg.depth_datasets.shard(samples, 'train')
+        lens.append(len(part))
+        assert pkg.depth_datasets.shard(samples, 'valid') == samples          # evaluation is not sharded
+    assert lens == [64, 64]
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    monkeypatch.setenv('RANK', '0')
+    assert pkg.depth_datasets.shard(samples, 'train') == samples

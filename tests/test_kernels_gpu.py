@@ -77,15 +77,15 @@ def test_partial_conv_matches_reference_golden(pkg):
             conv.weight.copy_(dev(wt))
             if m['bias']:
                 conv.bias.copy_(dev(g[n + '.b']))
-                conv.bias.requires_grad_(False)
         x = dev(g[n + '.x']).requires_grad_(True)
         y, mo = conv(x, dev(g[n + '.mask']))
         assert np.array_equal(host(mo), g[n + '.mask_out']), n
         assert np.abs(host(y) - g[n + '.y']).max() < 1e-5 * max(np.abs(g[n + '.y']).max(), 1.0), n
-        if not m['bias']:
-            y.backward(dev(g[n + '.dy']))
-            assert np.abs(host(x.grad) - g[n + '.dx']).max() < 1e-5 * max(np.abs(g[n + '.dx']).max(), 1.0), n
-            assert np.abs(host(conv.weight.grad) - g[n + '.dw']).max() < 1e-5 * max(np.abs(g[n + '.dw']).max(), 1.0), n
+        y.backward(dev(g[n + '.dy']))
+        assert np.abs(host(x.grad) - g[n + '.dx']).max() < 1e-5 * max(np.abs(g[n + '.dx']).max(), 1.0), n
+        assert np.abs(host(conv.weight.grad) - g[n + '.dw']).max() < 1e-5 * max(np.abs(g[n + '.dw']).max(), 1.0), n
+        if m['bias']:       # the ((raw - b) * mult + b) * mask_out branch of partial_conv.py:48-51: d out / d b = mask_out
+            assert np.abs(host(conv.bias.grad) - g[n + '.db']).max() < 1e-5 * max(np.abs(g[n + '.db']).max(), 1.0), n
 
 
 def test_conv_cat_equals_conv_of_concat(pkg):
@@ -509,3 +509,27 @@ def test_x3_same_convolutions_match_fp32_path(pkg):
             assert torch.equal(res[False][2], res[True][2]) != (k >= 128 and c >= 128 and k * c >= 512 * 512 and h % 16 == 0)
     finally:
         ops.set_x3(False)
+
+
+def test_paste_over_and_brightness_contrast_match_reference_golden(pkg):
+    """p3d_augment_occlude against the reference's own augment_occluder.paste_over outputs, and the brightness / contrast leg of
+    p3d_augment_colour against augment_colour.random_color (no hue / saturation jitter drawn): bit-exact on 0..255 values."""
+    g = np.load(golden_path('augment.npz'))
+    for m in json.loads(str(g['meta'])):
+        n = m['name']
+        img = dev(g[n + '.image'].astype(np.float32).transpose(2, 0, 1)[None].copy())
+        alpha = g[n + '.alpha'] if m['alpha'] else None
+        pkg.augment.paste_over_(img, [g[n + '.occ']], [alpha], g[n + '.center'][None])
+        assert np.array_equal(host(img)[0].transpose(1, 2, 0), g[n + '.out'].astype(np.float32)), n
+    # a batch with a different occluder per image (and one image left alone) in one launch
+    names = ['inside', 'topleft', 'botright']
+    batch = dev(np.stack([g[n + '.image'].astype(np.float32).transpose(2, 0, 1) for n in names] + [g['inside.image'].astype(np.float32).transpose(2, 0, 1)]))
+    pkg.augment.paste_over_(batch, [g[n + '.occ'] for n in names] + [None], [g[n + '.alpha'] for n in names] + [None],
+                            np.stack([g[n + '.center'] for n in names] + [np.zeros(2)]))
+    for i, n in enumerate(names):
+        assert np.array_equal(host(batch)[i].transpose(1, 2, 0), g[n + '.out'].astype(np.float32)), n
+    assert np.array_equal(host(batch)[3].transpose(1, 2, 0), g['inside.image'].astype(np.float32))
+    for i, (b, c) in enumerate(g['bc_draws']):
+        img = dev(g['bc%d.image' % i].astype(np.float32).transpose(2, 0, 1)[None].copy())
+        pkg.ops.augment_colour_(img, dev(np.array([[b, c, 0.0, 1.0]], dtype=np.float32)))
+        assert np.array_equal(host(img)[0].transpose(1, 2, 0), g['bc%d.out' % i].astype(np.float32)), i

@@ -45,7 +45,12 @@ def test_head_matches_reference():
 
 
 STEP_CASES = ['depth_r18_b2', 'depth_r18_odd_b1', 'depthonly_r18_b2', 'fusion_r18_b2', 'partial_r18_b2',
-              'depth_r50_b2', 'fusion_r50_b1', 'partial_r50_b1', 'pfusion_r18_b2', 'pfusion_r50_b1']
+              'depth_r50_b2', 'fusion_r50_b1', 'partial_r50_b1', 'pfusion_r18_b2', 'pfusion_r50_b1',
+              'depth_r18_s8_b2', 'depth_r18_s32_b2', 'depth_r18_s4_b1']      # the other stage geometries of depthnet.py:130-136
+
+
+def net_stride(meta):
+    return int(meta['extra'][meta['extra'].index('-stride') + 1]) if '-stride' in meta['extra'] else 16
 
 
 @pytest.mark.parametrize('case', STEP_CASES)
@@ -64,7 +69,7 @@ def test_train_step_matches_reference(case, synth):
         c, d, tc, tv = synth.make_batch(meta['batch'], side=meta['side'], rank=0, step=it, invalid_frac=meta['invalid_frac'])
         out = np_net.train_step(sd, c, d, tc, tv, family=meta['family'], model=meta['model'],
                                 depth_only='-depth_only' in meta['extra'], lr=meta['lr'], adam_state=state,
-                                step=it + 1, acc=acc)
+                                step=it + 1, acc=acc, stride=net_stride(meta))
         assert abs(out['loss'] - g['losses'][it]) < 2e-4 * abs(g['losses'][it]), (it, out['loss'], g['losses'][it])
         assert abs(out['clip_total'] - g['clip_total'][it]) < 2e-3 * g['clip_total'][it]
         spec_sel = out['spec_cam'].reshape(-1, 3)[tv.reshape(-1)]
@@ -113,3 +118,20 @@ def test_torch_port_matches_reference(case, synth):
     st = port.state()
     ps = np.array([st[n].reshape(-1)[g['sample_idx'][i]] for i, n in enumerate(meta['names'])])
     assert np.abs(ps - g['param_samples']).max() < 3e-5
+
+
+def test_augment_restatements_match_reference(pkg):
+    """oracle.np_ops.paste_over / brightness_contrast and the host planner augment.plan_paste against the reference's own
+    augment_occluder.paste_over and augment_colour.random_color (brightness / contrast leg) outputs: bit-exact (uint8)."""
+    g = np.load(golden_path('augment.npz'))
+    for m in json.loads(str(g['meta'])):
+        n = m['name']
+        alpha = g[n + '.alpha'] if m['alpha'] else None
+        out = ops.paste_over(g[n + '.occ'], g[n + '.image'].copy(), alpha, g[n + '.center'])
+        assert np.array_equal(out, g[n + '.out']), n
+        dy, dx, sy, sx, h, w = pkg.augment.plan_paste(g[n + '.occ'].shape, g[n + '.image'].shape, g[n + '.center'])
+        changed = np.argwhere((g[n + '.out'] != g[n + '.image']).any(axis=2))
+        assert h > 0 and w > 0
+        assert changed[:, 0].min() >= dy and changed[:, 0].max() < dy + h and changed[:, 1].min() >= dx and changed[:, 1].max() < dx + w, n
+    for i, (b, c) in enumerate(g['bc_draws']):
+        assert np.array_equal(ops.brightness_contrast(g['bc%d.image' % i], b, c), g['bc%d.out' % i]), i
