@@ -555,3 +555,64 @@ def brightness_contrast(image_u8, brightness, contrast):
     x += 0.5
     x = np.clip(x, 0, 1)
     return (x * 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# convolution evaluated only at chosen outputs (float64): parity checks at BASELINE's full sizes,
+# where the dense oracle above would take minutes per layer
+# --------------------------------------------------------------------------------------
+
+def conv2d_fwd_at(x, w, bias, stride, pad, dil, idx):
+    """y[n, k, ho, wo] of conv2d_fwd at the rows of idx [S, 4] (n, k, ho, wo)."""
+    n, k, ho, wo = (idx[:, i] for i in range(4))
+    _, c, h, wd = x.shape
+    out = np.zeros(len(idx), dtype=np.float64)
+    for r in range(w.shape[2]):
+        for s in range(w.shape[3]):
+            hi, wi = ho * stride - pad + r * dil, wo * stride - pad + s * dil
+            ok = (hi >= 0) & (hi < h) & (wi >= 0) & (wi < wd)
+            xs = x[n[ok], :, hi[ok], wi[ok]].astype(np.float64)                 # [S', C]
+            out[ok] += (xs * w[k[ok], :, r, s].astype(np.float64)).sum(axis=1)
+    if bias is not None:
+        out += bias[k].astype(np.float64)
+    return out
+
+
+def conv2d_dgrad_at(dy, w, x_shape, stride, pad, dil, idx):
+    """dx[n, c, hi, wi] of conv2d_dgrad at the rows of idx [S, 4] (n, c, hi, wi)."""
+    n, c, hi, wi = (idx[:, i] for i in range(4))
+    ho_n, wo_n = dy.shape[2:]
+    out = np.zeros(len(idx), dtype=np.float64)
+    for r in range(w.shape[2]):
+        for s in range(w.shape[3]):
+            th, tw = hi + pad - r * dil, wi + pad - s * dil
+            ok = (th % stride == 0) & (tw % stride == 0)
+            ho, wo = th // stride, tw // stride
+            ok &= (ho >= 0) & (ho < ho_n) & (wo >= 0) & (wo < wo_n)
+            ds = dy[n[ok], :, ho[ok], wo[ok]].astype(np.float64)                # [S', K]
+            out[ok] += (ds * w[:, c[ok], r, s].T.astype(np.float64)).sum(axis=1)
+    return out
+
+
+def conv2d_wgrad_block(dy, x, ksel, csel, kh, kw, stride, pad, dil):
+    """dw[ksel][:, csel] of conv2d_wgrad: the [len(ksel), len(csel), kh, kw] block of filters ksel and input channels csel (all taps)."""
+    nb, _, h, wd = x.shape
+    ho_n, wo_n = dy.shape[2:]
+    dys = dy[:, ksel].astype(np.float64)                                        # [N, K', Ho, Wo]
+    xsel = x[:, csel].astype(np.float64)
+    out = np.zeros((len(ksel), len(csel), kh, kw), dtype=np.float64)
+    for r in range(kh):
+        for s in range(kw):
+            # output rows ho whose tap (r, s) lands inside the image: hi = ho*stride - pad + r*dil
+            ho_idx = np.arange(ho_n)
+            hi = ho_idx * stride - pad + r * dil
+            okh = (hi >= 0) & (hi < h)
+            wo_idx = np.arange(wo_n)
+            wi = wo_idx * stride - pad + s * dil
+            okw = (wi >= 0) & (wi < wd)
+            if not okh.any() or not okw.any():
+                continue
+            a = dys[:, :, ho_idx[okh]][:, :, :, wo_idx[okw]]                     # [N, K', h', w']
+            b = xsel[:, :, hi[okh]][:, :, :, wi[okw]]                            # [N, C', h', w']
+            out[:, :, r, s] = np.einsum('nkp,ncp->kc', a.reshape(nb, len(ksel), -1), b.reshape(nb, len(csel), -1), optimize=True)
+    return out

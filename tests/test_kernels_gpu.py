@@ -389,6 +389,93 @@ def test_conv_adjoint_identities_at_full_size(shape, pkg):
         assert abs(form - via_x) < 2e-5 * scale, (form, via_x)
 
 
+# Sampled-oracle parity at BASELINE's batch: the plans the bench runs (tile choice, split-K, parity classes, slab folds, weight images,
+# x3 kernels) are compared with the float64 oracle itself, evaluated only at randomly chosen outputs.  Beyond the ResNet-50 classes:
+# the shapes only the fusion / partial networks have (fusionnet.py:130-140: 2C -> C 1x1 over the concat at 32x32, batch 32; the 1-channel
+# 7x7 stride-2 depth stem) and the MASKED (partial_conv.py:32-57) variants of the layer1 / layer2 classes at batch 64.
+FULL_CASES = ([('r50', 64) + s + (False,) for s in R50_CLASSES]
+              + [('stem1', 32, 1, 256, 64, 7, 2, 1, False), ('stem1', 64, 1, 256, 64, 7, 2, 1, True)]
+              + [('masked', 64) + s + (True,) for s in R50_CLASSES[1:8] + R50_CLASSES[9:11]])
+
+
+def _sample_idx(rng, shape, count):
+    return np.stack([rng.integers(0, d, count) for d in shape], 1)
+
+
+@pytest.mark.parametrize('case', FULL_CASES, ids=['%s_n%d_c%d_h%d_k%d_%dx%d_s%d_d%d%s' % (c[0], c[1], c[2], c[3], c[4], c[5], c[5], c[6], c[7], '_masked' if c[8] else '')
+                                                  for c in FULL_CASES])
+def test_conv_sampled_oracle_at_full_size(case, pkg):
+    ops = pkg.ops
+    tag, n, c, h, k, ks, st, dil, masked = case
+    pad = dil * (ks - 1) // 2
+    gen = torch.Generator(device='cuda').manual_seed(c * 11 + k + ks)
+    rng = np.random.default_rng(c * 13 + k)
+    need_dx = c > 4
+    x = torch.randn(n, c, h, h, device='cuda', generator=gen).requires_grad_(need_dx)
+    w = (torch.randn(k, c, ks, ks, device='cuda', generator=gen) / (c * ks * ks) ** 0.5).requires_grad_(True)
+    mask = mult = None
+    if masked:
+        mask = (torch.rand(n, 1, h, h, device='cuda', generator=gen) >= 0.3).float()
+        mult, _ = ops.mask_count(mask, ks, st, pad, dil)
+    y = ops.conv2d(x, w, None, st, pad, dil, mask_in=mask, mult=mult)
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    xe = x.detach() * mask if masked else x.detach()              # the oracle sees the operands the reference would form (partial_conv.py:45-53)
+    dye = dy * mult if masked else dy
+    xh, wh, dyh = host(xe), host(w), host(dye)
+    count = 4096
+    # forward
+    idx = _sample_idx(rng, y.shape, count)
+    want = ref.conv2d_fwd_at(xh, wh, None, st, pad, dil, idx)
+    if masked:
+        want = want * host(mult)[idx[:, 0], 0, idx[:, 2], idx[:, 3]]
+    got = host(y)[tuple(idx.T)]
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max(), 'fwd'
+    # data gradient
+    if need_dx:
+        idx = _sample_idx(rng, x.shape, count)
+        want = ref.conv2d_dgrad_at(dyh, wh, x.shape, st, pad, dil, idx)
+        if masked:
+            want = want * host(mask)[idx[:, 0], 0, idx[:, 2], idx[:, 3]]
+        got = host(x.grad)[tuple(idx.T)]
+        assert np.abs(got - want).max() < 2e-5 * np.abs(want).max(), 'dgrad'
+    # weight gradient: a random block of filters x input channels, every tap (>= 4096 outputs)
+    nk = min(k, 64)
+    nc = min(c, max(4096 // (nk * ks * ks) + 1, min(c, 64)))
+    ksel, csel = np.sort(rng.choice(k, nk, replace=False)), np.sort(rng.choice(c, nc, replace=False))
+    want = ref.conv2d_wgrad_block(dyh, xh, ksel, csel, ks, ks, st, pad, dil)
+    assert want.size >= min(4096, k * c * ks * ks)
+    got = host(w.grad)[ksel][:, csel]
+    assert np.abs(got - want).max() < 5e-5 * np.abs(want).max(), 'wgrad'
+
+
+def test_conv_cat_sampled_oracle_at_fusion_size(pkg):
+    """fusionnet.Fusion's 1x1 over cat([rgb, depth]) (fusionnet.py:138-139) at BASELINE config 5's size: 2 x 512 -> 512 channels at 32x32, batch 32."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(77)
+    rng = np.random.default_rng(78)
+    xa = torch.randn(32, 512, 32, 32, device='cuda', generator=gen).requires_grad_(True)
+    xb = torch.randn(32, 512, 32, 32, device='cuda', generator=gen).requires_grad_(True)
+    w = (torch.randn(512, 1024, 1, 1, device='cuda', generator=gen) / 32.0).requires_grad_(True)
+    y = ops.conv_cat1x1(xa, xb, w)
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    cat = np.concatenate([host(xa), host(xb)], axis=1)
+    wh, dyh = host(w), host(dy)
+    idx = _sample_idx(rng, y.shape, 4096)
+    want = ref.conv2d_fwd_at(cat, wh, None, 1, 0, 1, idx)
+    assert np.abs(host(y)[tuple(idx.T)] - want).max() < 2e-5 * np.abs(want).max()
+    idx = _sample_idx(rng, cat.shape, 4096)
+    want = ref.conv2d_dgrad_at(dyh, wh, cat.shape, 1, 0, 1, idx)
+    got = np.concatenate([host(xa.grad), host(xb.grad)], axis=1)[tuple(idx.T)]
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    ksel, csel = np.sort(rng.choice(512, 64, replace=False)), np.sort(rng.choice(1024, 64, replace=False))
+    want = ref.conv2d_wgrad_block(dyh, cat, ksel, csel, 1, 1, 1, 0, 1)
+    assert np.abs(host(w.grad)[ksel][:, csel] - want).max() < 5e-5 * np.abs(want).max()
+
+
 @pytest.mark.parametrize('shape', [(64, 64, 128, 128), (64, 256, 64, 64), (64, 1024, 16, 16), (64, 2048, 16, 16)])
 def test_bn_properties_at_full_size(shape, pkg):
     """Size-independent BatchNorm properties at the contract's tensor sizes: the training output has zero mean / unit variance per channel,

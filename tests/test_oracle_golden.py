@@ -135,3 +135,20 @@ def test_augment_restatements_match_reference(pkg):
         assert changed[:, 0].min() >= dy and changed[:, 0].max() < dy + h and changed[:, 1].min() >= dx and changed[:, 1].max() < dx + w, n
     for i, (b, c) in enumerate(g['bc_draws']):
         assert np.array_equal(ops.brightness_contrast(g['bc%d.image' % i], b, c), g['bc%d.out' % i]), i
+
+
+def test_sampled_conv_oracle_equals_dense_oracle():
+    """conv2d_*_at / conv2d_wgrad_block (the checkers of the full-size GPU parity tests) against the dense oracle pinned above."""
+    rng = np.random.default_rng(0)
+    for (n, c, h, k, ks, st, pad, dil) in [(3, 5, 11, 7, 3, 2, 1, 1), (2, 4, 9, 6, 3, 1, 2, 2), (2, 6, 8, 5, 1, 2, 0, 1), (2, 3, 12, 4, 7, 2, 3, 1)]:
+        x = rng.standard_normal((n, c, h, h)).astype(np.float32)
+        w = rng.standard_normal((k, c, ks, ks)).astype(np.float32)
+        b = rng.standard_normal(k).astype(np.float32)
+        y = ops.conv2d_fwd(x, w, b, st, pad, dil)
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        idx = np.stack([rng.integers(0, d, 300) for d in y.shape], 1)
+        assert np.allclose(ops.conv2d_fwd_at(x, w, b, st, pad, dil, idx), y[tuple(idx.T)], atol=1e-4)
+        idx = np.stack([rng.integers(0, d, 300) for d in x.shape], 1)
+        assert np.allclose(ops.conv2d_dgrad_at(dy, w, x.shape, st, pad, dil, idx), ops.conv2d_dgrad(dy, w, x.shape, st, pad, dil)[tuple(idx.T)], atol=1e-4)
+        ksel, csel = np.array([0, k - 1, 2]), np.array([c - 1, 0])
+        assert np.allclose(ops.conv2d_wgrad_block(dy, x, ksel, csel, ks, ks, st, pad, dil), ops.conv2d_wgrad(dy, x, w.shape, st, pad, dil)[ksel][:, csel], atol=1e-4)
