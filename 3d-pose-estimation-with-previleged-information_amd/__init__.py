@@ -14,6 +14,6 @@ def __getattr__(name):
     import importlib
     if name in ('ops', 'nn', 'optim', 'dist', 'utils', 'opts', 'depthnet', 'resnet', 'fusionnet', 'partial_conv',
                 'partial_depthnet', 'partial_fusionnet', 'cameralib', 'crops', 'mat_utils', 'depth_train', 'depth_main', 'depth_datasets', 'datasets', 'joint_settings', '_lib', 'log', 'train', 'main',
-                'augment', 'graphed', 'ops_half'):
+                'augment', 'graphed', 'ops_half', 'ops_block', '_trunk'):
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

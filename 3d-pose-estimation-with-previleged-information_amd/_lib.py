@@ -40,6 +40,12 @@ SIGNATURES = {
     'p3d_conv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
     'p3d_conv2d_bgrad_masked': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
+    'p3d_block_supported': (_i32, [_ptr]),
+    'p3d_block_workspace_bytes': (_i32, [_ptr, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    'p3d_block_fwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr]),
+    'p3d_block_bwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr, _sz, _ptr, _ptr]),
+    'p3d_profile_enable': (_i32, [_i32]),
+    'p3d_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
     'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
     'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),
@@ -67,6 +73,7 @@ SIGNATURES = {
     'p3d_augment_occlude': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_x3_enable': (_i32, [_i32]),
+    'p3d_conv_path_stats': (None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), _i32]),
     'p3d_reproject_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_enhance_depth': (_i32, [_ptr, _ptr, _i64, _f32, _i32, _ptr]),
     'p3d_normalize_rgb': (_i32, [_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _ptr]),

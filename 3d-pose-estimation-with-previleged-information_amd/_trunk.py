@@ -10,9 +10,15 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+import os
+
+from . import ops, ops_block
 from .nn import BatchNorm2d, Conv2d, MaxPool2d, Sequential
 from .partial_conv import PartialConv
+
+
+# P3D_BLOCKS=0: every layer as its own autograd node (ops.py), BatchNorm as stand-alone passes -- the round-1 structure, kept as the general path
+FUSED_BLOCKS = os.environ.get('P3D_BLOCKS', '1') != '0'
 
 
 def stage_geometry(stride):
@@ -65,6 +71,8 @@ class _ResidualBlock(nn.Module):
         # the block input fans out to conv1 and the shortcut: join the two input gradients inside conv1's dgrad kernel (ops.GradJoin)
         if ops.can_fuse_eval(x, self.conv1, self.bn1):
             return self._forward_inference(x)
+        if FUSED_BLOCKS and ops_block.usable(self, x):          # training: the whole block is one C call per direction, BatchNorm inside the convolutions
+            return ops_block.residual_block(self, x)
         join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1

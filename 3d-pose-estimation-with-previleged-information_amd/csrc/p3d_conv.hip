@@ -30,27 +30,10 @@
 // padding / out-of-tile elements (offset 0x80000000), so the gather has no branches.
 // blockIdx.x is remapped so that blocks sharing an activation (B) tile land on one XCD and reuse its L2.
 #include "p3d_common.h"
+#include "p3d_fx.h"
 #include <stdlib.h>
 
 namespace p3d {
-
-// p3d_x3.hip (opt-in, P3D_X3=1)
-bool x3_wgrad_applies(const p3d_conv_desc* d);
-int x3_wgrad_splits(const p3d_conv_desc* d);
-void x3_wgrad_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
-bool x3_wgrad_rs_applies(const p3d_conv_desc* d);
-int x3_wgrad_rs_splits(const p3d_conv_desc* d);
-void x3_wgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, hipStream_t st);
-bool x3_fwd_applies(const p3d_conv_desc* d);
-bool x3_dgrad_applies(const p3d_conv_desc* d);
-void x3_fwd_launch(const p3d_conv_desc* d, const float* x, const float* w, float* y, hipStream_t st);
-void x3_dgrad_launch(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st);
-bool x3_fwd_rs_applies(const p3d_conv_desc* d);
-bool x3_dgrad_rs_applies(const p3d_conv_desc* d);
-size_t x3_rs_image_bytes(const p3d_conv_desc* d);
-void x3_fwd_rs_launch(const p3d_conv_desc* d, const float* x, const float* wt_image, const float* bias, float* y, hipStream_t st);
-void x3_dgrad_rs_launch(const p3d_conv_desc* d, const float* dy, const float* wt_image, float* dx, hipStream_t st);
-
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -1042,6 +1025,33 @@ static void fill_class(int par, int R, int stride, int pad, int dil, int* r0, in
 
 }  // namespace p3d
 
+namespace p3d {
+// second half of every weight-gradient call: deep splits are folded to <= 16 slabs by a chip-filling grid, then one pass sums them into dw
+// (tap-major slabs [k][tap][c] are transposed to the weight's [k][c][tap] order on the way)
+int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm, float* dw, hipStream_t st) {
+    const int M = d->K, Ncols = d->C * d->R * d->S;
+    const int ldw = d->c_total * d->R * d->S, woff = d->c_offset * d->R * d->S;
+    if (nslab > 16) {
+        const size_t total = (size_t)M * Ncols;
+        const int G = 16;
+        const int64_t bx = ceil_div((int64_t)ceil_div((int64_t)total, 4), 256);
+        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)(bx < 256 ? bx : 256), G), dim3(256), 0, st, slabs, total, nslab, G);
+        if (int32_t e = check_launch("conv2d_wgrad fold")) return e;
+        nslab = G;
+    }
+    if (tapm && d->R * d->S > 1) {
+        const int RS = d->R * d->S;
+        hipLaunchKernelGGL(wgrad_reduce_tapm_kernel, dim3(d->K, d->C / REDUCE_CH), dim3(256), RS * REDUCE_CH * sizeof(float), st, (const float*)slabs, dw, M, d->C, RS,
+                           nslab, ldw, woff, d->accumulate);
+    } else {
+        const size_t total = (size_t)M * Ncols;
+        const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 2048 ? ceil_div((int64_t)total, 256) : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, dw, M, Ncols, nslab, ldw, woff, d->accumulate);
+    }
+    return check_launch("conv2d_wgrad reduce");
+}
+}  // namespace p3d
+
 using namespace p3d;
 
 extern "C" {
@@ -1109,8 +1119,8 @@ size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     const FwdPlan pl = plan_fwd(d, false, true);
     const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
-    const size_t x3 = x3_fwd_rs_applies(d) ? x3_rs_image_bytes(d) : 0;
-    return base > x3 ? base : x3;
+    const size_t fx = fx_fwd_applies(d) ? fx_fwd_workspace(d) : 0;
+    return base > fx ? base : fx;
 }
 
 static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask_in, const float* mult,
@@ -1118,19 +1128,12 @@ static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const flo
                                const float* ep_res, int ep_relu) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
-    if (!bias && !mask_in && !mult && !ep_scale && !ep_res && !ep_relu && x3_fwd_applies(d) &&
-        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
-        x3_fwd_launch(d, x, w, y, (hipStream_t)stream);
-        return check_launch("conv2d_fwd x3");
+    if (!mask_in && !mult && !ep_scale && !ep_res && !ep_relu && fx_fwd_applies(d) && workspace_bytes >= fx_fwd_workspace(d) &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {
+        fx_count(0, d);          // exact fp32 on the bf16 matrix pipe (p3d_fx.hip), the default path of the dense layers
+        return fx_conv_fwd(d, x, w, bias, y, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
     }
-    if (!mask_in && !mult && !ep_scale && !ep_res && !ep_relu && x3_fwd_rs_applies(d) && workspace && workspace_bytes >= x3_rs_image_bytes(d) &&
-        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {      // opt-in, R x S taps: tap-major weight image first
-        const int64_t kc = (int64_t)d->K * d->C;
-        hipLaunchKernelGGL(weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, (hipStream_t)stream, w,
-                           (float*)workspace, d->K, d->C, d->R * d->S);
-        x3_fwd_rs_launch(d, x, (const float*)workspace, bias, y, (hipStream_t)stream);
-        return check_launch("conv2d_fwd x3 rs");
-    }
+    fx_count(3, d);
     IgemmParams p = base_params(d);
     p.A = w; p.B = x; p.Cout = y; p.bias = bias; p.mask_in = mask_in; p.mult = mult;
     p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
@@ -1161,6 +1164,8 @@ static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const flo
 
 int32_t p3d_conv2d_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias,
                        const float* mask_in, const float* mult, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d) { set_error("conv: null descriptor"); return P3D_EINVAL; }
+    ProfScope ps(0, d, (hipStream_t)stream);
     return conv2d_fwd_impl(d, x, w, bias, mask_in, mult, y, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, 0);
 }
 
@@ -1227,29 +1232,28 @@ size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (d->stride == 1) {
         const FwdPlan pl = plan_dgrad1(d, false);
         const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
-        const size_t x3 = x3_dgrad_rs_applies(d) ? x3_rs_image_bytes(d) : 0;
-        return base > x3 ? base : x3;
+        const size_t fx = fx_dgrad_applies(d) ? fx_dgrad_workspace(d) : 0;
+        return base > fx ? base : fx;
     }
     const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
-    return (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
+    const size_t staged = (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
+    const size_t fx = fx_dgrad_applies(d) ? fx_dgrad_workspace(d) : 0;
+    return staged > fx ? staged : fx;
 }
 
 int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, const float* mult,
                          const float* mask_in, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && w && dx, "conv2d_dgrad: null tensor");
-    if (!mask_in && !mult && x3_dgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {      // opt-in (p3d_x3.hip)
-        x3_dgrad_launch(d, dy, w, dx, (hipStream_t)stream);
-        return check_launch("conv2d_dgrad x3");
+    ProfScope ps(1, d, (hipStream_t)stream);
+    if (!mask_in && !mult && fx_dgrad_applies(d) && workspace_bytes >= fx_dgrad_workspace(d) &&
+        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {
+        fx_count(1, d);
+        if (fx_dgrad_has_dead_classes(d) && !d->accumulate)          // input pixels no tap reaches (1x1, stride 2) must read zero
+            (void)hipMemsetAsync(dx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), (hipStream_t)stream);
+        return fx_conv_dgrad(d, dy, w, dx, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
     }
-    if (!mask_in && !mult && x3_dgrad_rs_applies(d) && workspace && workspace_bytes >= x3_rs_image_bytes(d) &&
-        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {      // opt-in, R x S taps
-        const int64_t kc = (int64_t)d->K * d->C;
-        hipLaunchKernelGGL(weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, (hipStream_t)stream, w,
-                           (float*)workspace, d->K, d->C, d->R * d->S);
-        x3_dgrad_rs_launch(d, dy, (const float*)workspace, dx, (hipStream_t)stream);
-        return check_launch("conv2d_dgrad x3 rs");
-    }
+    fx_count(4, d);
     IgemmParams p = base_params(d);
     p.A = w; p.B = dy; p.Cout = dx; p.mask_in = mask_in; p.mult = mult;
     p.M = d->C; p.Kd = d->K * d->R * d->S;
@@ -1322,8 +1326,7 @@ size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d) {
     // the larger of the masked / unmasked plans, so one query serves both
     const WgradPlan a = plan_wgrad(d, false), b = plan_wgrad(d, true);
     int splits = a.splits > b.splits ? a.splits : b.splits;
-    if (x3_wgrad_applies(d) && x3_wgrad_splits(d) > splits) splits = x3_wgrad_splits(d);
-    if (x3_wgrad_rs_applies(d) && x3_wgrad_rs_splits(d) > splits) splits = x3_wgrad_rs_splits(d);
+    if (fx_wgrad_applies(d) && fx_wgrad_splits(d) > splits) splits = fx_wgrad_splits(d);
     return (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
@@ -1331,12 +1334,12 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
                          const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
     if (int32_t e = validate(d)) return e;
     P3D_REQUIRE(dy && x && dw, "conv2d_wgrad: null tensor");
+    ProfScope ps(2, d, (hipStream_t)stream);
     const bool masked = mask_in || mult;
     WgradPlan pl = plan_wgrad(d, masked);
-    const bool x3 = !masked && x3_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-    if (x3) { pl.splits = x3_wgrad_splits(d); pl.tapm = false; }
-    const bool x3rs = !masked && !x3 && x3_wgrad_rs_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-    if (x3rs) { pl.splits = x3_wgrad_rs_splits(d); pl.tapm = false; }
+    const bool fx = !masked && fx_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    if (fx) { pl.splits = fx_wgrad_splits(d); pl.tapm = d->R * d->S > 1; }      // slabs [split][k][tap][c]: the tap-major columns of wgrad_reduce_tapm_kernel
+    fx_count(fx ? 2 : 5, d);
     const size_t need = (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
     if (!workspace || workspace_bytes < need) {
         set_error("conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
@@ -1359,30 +1362,18 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
         if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && al16(x) && al16(mask_in)) wv = 2;
     }
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
-    if (x3) x3_wgrad_launch(d, dy, x, (float*)workspace, pl.splits, (hipStream_t)stream);      // opt-in exact-fp32 path on the bf16 pipe (p3d_x3.hip)
-    else if (x3rs) x3_wgrad_rs_launch(d, dy, x, (float*)workspace, pl.splits, (hipStream_t)stream);
+    if (fx) { if (int32_t e = fx_conv_wgrad_slabs(d, dy, x, (float*)workspace, pl.splits, nullptr, (hipStream_t)stream)) return e; }
     else launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
-    int nslab = pl.splits;
-    if (nslab > 16) {            // deep split: fold to <= 16 slabs with a grid that fills the chip, then the final (layout) pass
-        const size_t total = (size_t)p.M * p.Ncols;
-        const int G = 16;
-        const int64_t bx = ceil_div((int64_t)ceil_div((int64_t)total, 4), 256);
-        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)(bx < 256 ? bx : 256), G), dim3(256), 0, (hipStream_t)stream, (float*)workspace, total, nslab, G);
-        if (int32_t e = check_launch("conv2d_wgrad fold")) return e;
-        nslab = G;
-    }
-    if (pl.tapm && d->R * d->S > 1) {
-        const int RS = d->R * d->S;
-        hipLaunchKernelGGL(wgrad_reduce_tapm_kernel, dim3(d->K, d->C / REDUCE_CH), dim3(256), RS * REDUCE_CH * sizeof(float), (hipStream_t)stream,
-                           (const float*)workspace, dw, p.M, d->C, RS, nslab, p.ldw, p.woff, d->accumulate);
-    } else {
-        const size_t total = (size_t)p.M * p.Ncols;
-        const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 2048 ? ceil_div((int64_t)total, 256) : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                           p.M, p.Ncols, nslab, p.ldw, p.woff, d->accumulate);
-    }
-    return check_launch("conv2d_wgrad reduce");
+    return wgrad_finish(d, (float*)workspace, pl.splits, pl.tapm, dw, (hipStream_t)stream);
+}
+
+int32_t p3d_x3_enable(int32_t on) { return fx_set_enabled(on); }
+
+void p3d_conv_path_stats(uint64_t* counts, double* flops, int32_t reset) {
+    unsigned long long c[6];
+    fx_stats(c, flops, reset);
+    if (counts) for (int i = 0; i < 6; ++i) counts[i] = c[i];
 }
 
 int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream) {

@@ -1,0 +1,733 @@
+// Convolution forward / data gradient / weight gradient as exact-fp32 implicit GEMMs on the bf16 matrix pipe of gfx950, with the
+// BatchNorm of the residual blocks folded into them (depthnet.py:40-56,96-116 and the twins in resnet.py / fusionnet.py).
+//
+// Arithmetic ("x3"): every fp32 operand value is cut, on its way into LDS, into three bf16 pieces by mantissa truncation (x = hi + mid + lo
+// exactly, 8 + 8 + 8 bits).  Per K = 16 step the six piece products that can exceed 2^-24 |a b| (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
+// are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first: fp32-grade results (measured error <= the fp32-MFMA kernel's)
+// at 192 matrix-pipe cycles per 32x32x16 block instead of the 512 of v_mfma_f32_32x32x2_f32.
+//
+// GEMM view, NCHW kept end to end (the pixel index is the contiguous one in HBM):
+//   FWD    y [n][m][oh][ow]  = sum_tap sum_c  W[m][c][tap] * x [n][c][oh*s - pad + r*dil][ow*s - pad + q*dil]
+//   DGRAD  dx[n][m][ih][iw]  = sum_tap sum_k  W[k][m][tap] * dy[n][k][(ih + pad - r*dil)/s][(iw + pad - q*dil)/s]      (per stride^2 parity class)
+//   WGRAD  dw[k][c][tap]     = sum_n sum_p    dy[n][k][p]  * x [n][c][p at tap]                                       (split over (n, p) into slabs)
+// One block = 256 threads = 4 waves computes a 128 (channels) x 128 (pixels) tile; a wave owns 64 x 64 as 2 x 2 MFMA tiles.  The MFMA is
+// issued with the PIXEL operand in the A slot and the CHANNEL operand in the B slot, so in the accumulator a lane is an output channel and
+// its registers are pixels: four consecutive registers are four consecutive pixels (one 16-B store), and everything that is per output
+// channel -- bias, the BatchNorm batch statistics of the result, the sums of the BatchNorm backward -- is per lane, i.e. plain register
+// adds followed by one cross-lane step, not a 32-lane reduction per row.
+//
+// Fused BatchNorm (training mode).  A residual block is conv -> BN -> ReLU -> conv -> BN -> ReLU -> conv -> BN -> (+ shortcut) -> ReLU.
+// The BN + ReLU between two convolutions never exists in HBM:
+//   * the producing conv's epilogue leaves per-(pixel tile, channel) partial sums of y and y^2 (EPI_STATS); a few-block finalize kernel turns
+//     them into mean / invstd, updates the running statistics and writes the per-channel table {scale, shift} (scale = gamma*invstd);
+//   * the consuming conv applies relu(x*scale + shift) when it stages its activation operand (PRO_BNRELU), forward and weight gradient alike;
+//   * backward: the consumer's DGRAD epilogue accumulates, per channel of ITS result, sum(g) and sum(g * c) with g = dgrad * [bn(c) > 0]
+//     (EPI_BNRED: c is the producing conv's raw output, read once, tile-aligned with the stores); a finalize kernel turns the sums into dgamma /
+//     dbeta and the table {A, B, K} of   d c = A * g + B * c + K   (the BatchNorm backward as an affine map per channel), which the producer's
+//     DGRAD and WGRAD apply when they stage their dy operand (PRO_BNBWD).
+// Only the block-closing BN (add + ReLU, its output is the next block's input) is a pass over HBM of its own (p3d_block.hip).
+#include "p3d_common.h"
+#include "p3d_fx.h"
+
+namespace p3d {
+
+using bf8 = __bf16 __attribute__((ext_vector_type(8)));
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
+using s4t = short __attribute__((ext_vector_type(4)));
+using s8v = short __attribute__((ext_vector_type(8)));
+
+constexpr int FX_BM = 128, FX_BN = 128, FX_BK = 16;
+constexpr int FX_PIECE = 128 * FX_BK * 2;          // bytes of one bf16 piece of one operand tile (128 rows or columns x 16 k)
+
+// fp32 x4 -> three bf16 x4 pieces (hi, mid, lo) by mantissa truncation, written as 8-B chunks FX_PIECE apart
+__device__ __forceinline__ void fx_split_store(unsigned char* base, const f32x4 v) {
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];                         // (a bit_cast straight from an ext-vector element reads element 0 with this clang)
+        const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+        const float r1 = x - __builtin_bit_cast(float, hb);
+        const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, mb);
+        hi[e] = hb; mid[e] = mb; lo[e] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+    }
+    *reinterpret_cast<u32x2*>(base) = u32x2{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
+    *reinterpret_cast<u32x2*>(base + FX_PIECE) = u32x2{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
+    *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+}
+
+// LDS images of one piece of one operand tile:
+//  "rows are the reduction index" (NCHW activations, weights in [k][m] order): 16 rows x 128 bf16 columns, 256-B rows, the 16-B chunks of a row XOR-swizzled;
+//  MFMA fragments (8 consecutive k of one column per lane) come out of ds_read_b64_tr_b16 (two per fragment).
+__device__ __forceinline__ int fx_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+//  "reduction-contiguous" (weights in [m][k] order, both operands of WGRAD): 128 rows x 16 k, 32-B rows; the two 16-B halves of a row are swapped on rows with
+//  bit 3 set, which makes the 16-lane groups of a ds_read_b128 hit 16 different bank quads (unswizzled they collide two by two).
+__device__ __forceinline__ int fx_rc_off(int row, int half) { return 32 * row + 16 * (half ^ ((row >> 3) & 1)); }
+
+__device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int lane) {
+    // 16-lane group g reads the 4-row x 16-column block of rows 8 (g >> 1) + 4 half .. +3, columns cb + 16 (g & 1) .. +15 (see p3d_hconv.hip)
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+    const int c0 = (cb + 16 * (g & 1)) >> 3;
+    s8v v;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = 8 * (g >> 1) + 4 * half + q;
+        const unsigned char* addr = base + fx_tr_off(row, c0 + (pq >> 1)) + 8 * (pq & 1);
+        const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)addr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
+    }
+    return __builtin_bit_cast(bf8, v);
+}
+
+#define P3D_FX_PRODUCTS(ACC, PIX, CH)                                                                                   \
+    _Pragma("unroll") for (int pa = 0; pa < 6; ++pa) {                                                                 \
+        constexpr int PP[6] = {2, 0, 1, 1, 0, 0}, PC[6] = {0, 2, 1, 0, 1, 0};                                           \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                     \
+            ACC[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIX[PP[pa]][a], CH[PC[pa]][b], ACC[a][b], 0, 0, 0);    \
+    }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// FWD / DGRAD
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// WM = false: weight element (m, k) of tap t at W[t * w_ts + m * w_ld + k]   (forward: [K][C] or the tap-major image [tap][K][C])
+// WM = true : weight element (k, m) of tap t at W[t * w_ts + k * w_ld + m]   (dgrad:   [K][C] or [tap][K][C], m = input channel)
+// Every BatchNorm layer owns one table of 8 floats per channel: {sc, sh, mean, invstd, A, B, K, 0} (sc = gamma * invstd, sh = beta - mean * sc: written
+// by the forward finalize; A, B, K: the backward map d c = A * g + B * c + K, written by the backward finalize).
+// PRO: 0 none; 1 relu(x * sc + sh) per reduction channel; 2 A * (mask ? g : 0) + B * c + K per reduction channel with mask = (c * sc + sh > 0)
+//      (X = g, X2 = c); 3 the same without the mask (A * g + B * c + K)
+// EPI: 0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2; 2 store + partial sums of g, g * (c2 - mean) with g = y * [c2 * sc + sh > 0]
+//      (ep_c = c2 laid out like the output, ep_tab = its BatchNorm's table); under split-K the epilogue work is done by fx_reduce_kernel instead
+template <bool WM, int PRO, int EPI>
+__global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * 3 * FX_PIECE];      // pixel (activation) operand, double buffered
+    __shared__ __attribute__((aligned(16))) unsigned char Cs[2 * 3 * FX_PIECE];      // channel (weight) operand
+    __shared__ float red[2][2][128];                                                   // EPI 1 / 2: [wave along pixels][sum kind][channel]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    // XCD-aware remap (bijective): blocks b, b+8, ... share an XCD; give each XCD a contiguous run of logical ids (pixel tile outer, channel tile inner)
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+    const int m0 = tile_m * FX_BM, n0 = tile_n * FX_BN;
+    const int OHW = p.OH * p.OW;
+
+    // ---- staging maps ----
+    const int nrow = t >> 2, nkq = t & 3;          // reduction-contiguous operand: rows nrow, nrow + 64; floats 4 nkq .. 4 nkq + 3 of the K step
+    const int trow = t >> 5, tp4 = t & 31;         // row-is-reduction operand: reduction rows trow, trow + 8; columns 4 tp4 .. 4 tp4 + 3
+    // this thread's four consecutive output pixels (one output row: OW % 4 == 0)
+    const int col = n0 + 4 * tp4;
+    const bool col_ok = col < p.NP;
+    int pn = 0, hbase = 0, wbase = 0;
+    {
+        const int cc = col_ok ? col : 0;
+        pn = cc / OHW;
+        const int rem = cc - pn * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+        hbase = oh * p.hmul + p.hoff;
+        wbase = ow * p.wmul + p.woff;
+    }
+    const float* xb = p.X + (size_t)pn * p.Cred * p.Hi * p.Wi;
+    const float* x2b = (PRO >= 2) ? p.X2 + (size_t)pn * p.Cred * p.Hi * p.Wi : nullptr;
+    const int HWi = p.Hi * p.Wi;
+    const int csteps = p.Cred / FX_BK;
+    int nk = p.ntap * csteps, kt0 = 0;
+    if (p.kchunk > 0) {                            // split-K: this block reduces K steps [kt0, kt0 + nk) into slab blockIdx.y
+        kt0 = blockIdx.y * p.kchunk;
+        nk = min(nk - kt0, p.kchunk);
+    }
+    int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
+
+    f32x4 rw[2], rx[2], rx2[2];
+    f32x4 rtab[2][2];                              // PRO constants of this thread's two reduction rows
+    bool rvalid[2][4];
+    auto fetch = [&]() {
+        const int ir = f_tap / p.nS, is = f_tap - ir * p.nS;
+        const int wtap = (p.r0 + p.rstep * ir) * p.S + p.s0 + p.sstep * is;
+        const float* wt = p.W + (size_t)wtap * p.w_ts;
+        const int hi = hbase + ir * p.hstep, wshift = is * p.wstep, wi0 = wbase + wshift;
+        const bool row_ok = col_ok && (unsigned)hi < (unsigned)p.Hi;
+        const bool vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;       // wave-uniform: the four pixels are one aligned 16-B group, in or out together
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (WM) {
+                const int m = m0 + 4 * tp4;
+                rw[i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(wt + (size_t)(f_k + trow + 8 * i) * p.w_ld + m) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int m = m0 + nrow + 64 * i;
+                rw[i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(wt + (size_t)m * p.w_ld + f_k + 4 * nkq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int krow = f_k + trow + 8 * i;
+            const int off = krow * HWi + hi * p.Wi + wi0;
+            if (vec) {
+                const bool ok = row_ok && (unsigned)wi0 < (unsigned)p.Wi;
+                rx[i] = ok ? *reinterpret_cast<const f32x4*>(xb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (PRO >= 2) rx2[i] = ok ? *reinterpret_cast<const f32x4*>(x2b + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rvalid[i][e] = ok;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
+                    rx[i][e] = ok ? xb[off + e * p.wmul] : 0.f;
+                    if constexpr (PRO >= 2) rx2[i][e] = ok ? x2b[off + e * p.wmul] : 0.f;
+                    rvalid[i][e] = ok;
+                }
+            }
+            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = *reinterpret_cast<const f32x4*>(p.tab + 8 * krow);           // {sc, sh, mean, invstd}
+            if constexpr (PRO >= 2) rtab[i][0] = *reinterpret_cast<const f32x4*>(p.tab + 8 * krow + 4);                  // {A, B, K, 0}
+        }
+        f_k += FX_BK;
+        if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (WM) fx_split_store(Cs + buf * 3 * FX_PIECE + fx_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), rw[i]);
+            else fx_split_store(Cs + buf * 3 * FX_PIECE + fx_rc_off(nrow + 64 * i, nkq >> 1) + 8 * (nkq & 1), rw[i]);
+            f32x4 v = rx[i];
+            if constexpr (PRO == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rvalid[i][e] ? fmaxf(fmaf(rx[i][e], rtab[i][1][0], rtab[i][1][1]), 0.f) : 0.f;
+            }
+            if constexpr (PRO == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = rx2[i][e];
+                    const float g = fmaf(c, rtab[i][1][0], rtab[i][1][1]) > 0.f ? rx[i][e] : 0.f;
+                    v[e] = rvalid[i][e] ? fmaf(rtab[i][0][0], g, fmaf(rtab[i][0][1], c, rtab[i][0][2])) : 0.f;
+                }
+            }
+            if constexpr (PRO == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rvalid[i][e] ? fmaf(rtab[i][0][0], rx[i][e], fmaf(rtab[i][0][1], rx2[i][e], rtab[i][0][2])) : 0.f;
+            }
+            fx_split_store(Ps + buf * 3 * FX_PIECE + fx_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), v);
+        }
+    };
+
+    f32x16 acc[2][2];               // [pixel sub-tile a][channel sub-tile b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    if (nk > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch();
+        bf8 pf[3][2], cf[3][2];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                pf[pc][a] = fx_tr_frag(Ps + (buf * 3 + pc) * FX_PIECE, wn * 64 + a * 32, lane);
+                if (WM) cf[pc][a] = fx_tr_frag(Cs + (buf * 3 + pc) * FX_PIECE, wm * 64 + a * 32, lane);
+                else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wm * 64 + a * 32 + fr, fh));
+            }
+        P3D_FX_PRODUCTS(acc, pf, cf)
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = output channel (m), registers = pixels; acc[a][b][4 g + e] is pixel 32 a + 8 g + 4 fh + e of the wave's 64 ----
+    const bool split = p.kchunk > 0;
+    float* yout = p.Y + (split ? (size_t)blockIdx.y * p.slab_stride : 0);
+    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+    float esc[2] = {0.f, 0.f}, esh[2] = {0.f, 0.f}, emean[2] = {0.f, 0.f};
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wm * 64 + b * 32 + fr;
+            if (m < p.M) { esc[b] = p.ep_tab[8 * m]; esh[b] = p.ep_tab[8 * m + 1]; emean[b] = p.ep_tab[8 * m + 2]; }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c4 = n0 + wn * 64 + a * 32 + 8 * g + 4 * fh;         // first of this lane's 4 consecutive pixels
+            if (c4 >= p.NP) continue;
+            const int n = c4 / OHW, rem = c4 - n * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int m = m0 + wm * 64 + b * 32 + fr;
+                if (m >= p.M) continue;
+                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                if (!split) {
+                    if (p.bias) { const float bb = p.bias[m]; v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb; }
+                }
+                if (split || p.oxs == 1) {
+                    const size_t o = split ? ((size_t)n * p.M + m) * OHW + rem
+                                           : (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow;
+                    f32x4* dst = reinterpret_cast<f32x4*>(yout + o);
+                    if (!split && p.accumulate) { const f32x4 o4 = *dst; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                    *dst = v;
+                } else {
+                    float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e * p.oxs] = p.accumulate ? dst[e * p.oxs] + v[e] : v[e];
+                }
+                if constexpr (EPI == 1) {
+                    if (!split) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ssum[b] += v[e]; ssq[b] = fmaf(v[e], v[e], ssq[b]); }
+                    }
+                }
+                if constexpr (EPI == 2) {
+                    if (!split) {
+                        const f32x4 c2 = *reinterpret_cast<const f32x4*>(p.ep_c + ((size_t)n * p.M + m) * OHW + rem);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gg = fmaf(c2[e], esc[b], esh[b]) > 0.f ? v[e] : 0.f;
+                            ssum[b] += gg; ssq[b] = fmaf(gg, c2[e] - emean[b], ssq[b]);
+                        }
+                    }
+                }
+            }
+        }
+    if constexpr (EPI != 0) {
+        if (!split) {
+            // the two half-waves hold different pixels of the same channels; then the two waves along the pixel axis
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ssum[b] += __shfl_xor(ssum[b], 32, 64);
+                ssq[b] += __shfl_xor(ssq[b], 32, 64);
+                if (fh == 0) { red[wn][0][wm * 64 + b * 32 + fr] = ssum[b]; red[wn][1][wm * 64 + b * 32 + fr] = ssq[b]; }
+            }
+            __syncthreads();
+            if (t < 128 && m0 + t < p.M) {
+                float* dst = p.partial + ((size_t)tile_n * p.M + m0 + t) * 2;
+                dst[0] = red[0][0][t] + red[1][0][t];
+                dst[1] = red[0][1][t] + red[1][1][t];
+            }
+        }
+    }
+}
+
+// y (=|+=) sum over the split-K slabs (+ bias); EPI as in fx_conv_kernel: per-(chunk, channel) partial sums.  One block per (channel m, image group):
+// grid (M, ngroups), block z handles images n = z, z + ngroups, ...; the partial index is the group.
+template <int EPI>
+__global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ y, const float* __restrict__ bias, int nsplit,
+                                                        size_t slab_stride, int N, int M, int OHW, int accumulate, const float* __restrict__ ep_c,
+                                                        const float* __restrict__ ep_tab, float* __restrict__ partial) {
+    const int m = blockIdx.x, grp = blockIdx.y, ngrp = gridDim.y;
+    const float bb = bias ? bias[m] : 0.f;
+    float esc = 0.f, esh = 0.f, emean = 0.f;
+    if constexpr (EPI == 2) { esc = ep_tab[8 * m]; esh = ep_tab[8 * m + 1]; emean = ep_tab[8 * m + 2]; }
+    float s1 = 0.f, s2 = 0.f;
+    const int q4 = OHW >> 2;
+    for (int n = grp; n < N; n += ngrp) {
+        const size_t base = ((size_t)n * M + m) * OHW;
+        for (int i = threadIdx.x; i < q4; i += 256) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(slabs + base + 4 * i);
+            for (int z = 1; z < nsplit; ++z) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_stride + base + 4 * i);
+                v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+            }
+            v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb;
+            f32x4* dst = reinterpret_cast<f32x4*>(y + base + 4 * i);
+            if (accumulate) { const f32x4 o = *dst; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+            *dst = v;
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+            }
+            if constexpr (EPI == 2) {
+                const f32x4 c2 = *reinterpret_cast<const f32x4*>(ep_c + base + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float gg = fmaf(c2[e], esc, esh) > 0.f ? v[e] : 0.f; s1 += gg; s2 = fmaf(gg, c2[e] - emean, s2); }
+            }
+        }
+    }
+    if constexpr (EPI != 0) {
+        __shared__ float r1[4], r2[4];
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* dst = partial + ((size_t)grp * M + m) * 2;
+            dst[0] = r1[0] + r1[1] + r1[2] + r1[3];
+            dst[1] = r2[0] + r2[1] + r2[2] + r2[3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// WGRAD: dw[k][c][tap] = sum over images n and output pixels p of dyeff[n][k][p] * xeff[n][c][p at tap]
+// Both operands are contiguous along the reduction (pixel) index; a K step is 16 consecutive output pixels of one image (OHW % 16 == 0), a thread fetches
+// 4 of them for two rows of each operand.  grid (C tiles, K tiles, taps * splits); slabs [split][k][tap][c] ("tap-major columns", what
+// wgrad_reduce_tapm_kernel of p3d_conv.hip sums and transposes) or, for 1x1, [split][k][c].
+// PA: 0 none; 2 / 3 the BatchNorm-backward map of fx_conv_kernel on dy (per row k: constants live in registers; DY2 = the raw conv output c)
+// PB: 0 none; 1 relu(x * sc + sh) per row c
+template <int PA, int PB>
+__global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * FX_BM, n0 = blockIdx.x * FX_BN;
+    const int tap = blockIdx.z / p.nsplit, split = blockIdx.z - tap * p.nsplit;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int dh = tr * p.dil - p.pad, dw = ts * p.dil - p.pad;             // input coordinate = output coordinate * stride + (dh, dw)
+    const int OHW = p.OH * p.OW, HWi = p.Hi * p.Wi;
+    const int steps_per_img = OHW / FX_BK;
+    const int total = p.N * steps_per_img;
+    const int s0 = split * p.spb, s1 = (s0 + p.spb < total) ? s0 + p.spb : total;
+    const int nk = s1 - s0;
+    const int row = t >> 2, kq = t & 3;
+    const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
+    f32x4 atab[2][2], btab[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        atab[i][0] = atab[i][1] = btab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PA >= 2) {
+            if (a_ok[i]) {
+                atab[i][0] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i) + 4);      // {A, B, K, 0}
+                atab[i][1] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i));          // {sc, sh, mean, invstd}
+            }
+        }
+        if constexpr (PB == 1) {
+            if (b_ok[i]) btab[i] = *reinterpret_cast<const f32x4*>(p.btab + 8 * (n0 + row + 64 * i));
+        }
+    }
+    const bool vec = p.stride == 1 && (dw & 3) == 0;        // uniform: the four input pixels are one aligned 16-B group, in or out together
+    f32x4 ra[2], ra2[2], rb[2];
+    bool bvalid[4];
+    int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
+    auto fetch = [&]() {
+        const int pp = f_p + 4 * kq;
+        const size_t aoff = ((size_t)f_img * p.K + m0 + row) * OHW + pp;
+        const int oh = pp / p.OW, ow = pp - oh * p.OW;
+        const int hi = oh * p.stride + dh, wi0 = ow * p.stride + dw;
+        const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
+        const size_t boff = ((size_t)f_img * p.C + n0 + row) * HWi + hi * p.Wi + wi0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bvalid[e] = row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.DY + aoff + (size_t)i * 64 * OHW) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PA >= 2) ra2[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.DY2 + aoff + (size_t)i * 64 * OHW) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = p.X + boff + (size_t)i * 64 * HWi;
+            if (vec) {
+                rb[i] = (b_ok[i] && bvalid[0]) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = (b_ok[i] && bvalid[e]) ? src[e * p.stride] : 0.f;
+            }
+        }
+        f_p += FX_BK;
+        if (f_p == OHW) { f_p = 0; ++f_img; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 va = ra[i], vb = rb[i];
+            if constexpr (PA == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = ra2[i][e];
+                    const float g = fmaf(c, atab[i][1][0], atab[i][1][1]) > 0.f ? ra[i][e] : 0.f;
+                    va[e] = fmaf(atab[i][0][0], g, fmaf(atab[i][0][1], c, atab[i][0][2]));      // (rows k >= K have all-zero constants)
+                }
+            }
+            if constexpr (PA == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) va[e] = fmaf(atab[i][0][0], ra[i][e], fmaf(atab[i][0][1], ra2[i][e], atab[i][0][2]));
+            }
+            if constexpr (PB == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && bvalid[e]) ? fmaxf(fmaf(rb[i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
+            }
+            fx_split_store(As + buf * 3 * FX_PIECE + fx_rc_off(row + 64 * i, kq >> 1) + 8 * (kq & 1), va);
+            fx_split_store(Bs + buf * 3 * FX_PIECE + fx_rc_off(row + 64 * i, kq >> 1) + 8 * (kq & 1), vb);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    if (nk > 0) { fetch(); stage(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch();
+        bf8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wm * 64 + a * 32 + fr, fh));
+                bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wn * 64 + a * 32 + fr, fh));
+            }
+        P3D_FX_PRODUCTS(acc, af, bf)
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
+    const int RS = p.R * p.S;
+    float* out = p.slabs + (size_t)split * p.K * p.C * RS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = n0 + wn * 64 + b * 32 + fr;
+            if (c >= p.C) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (k < p.K) out[((size_t)k * RS + tap) * p.C + c] = acc[a][b][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------------------------
+static int g_fx = -1;       // -1: not decided yet (environment), 0 / 1: set
+bool fx_enabled() {
+    if (g_fx < 0) { const char* e = getenv("P3D_X3"); g_fx = (e && atoi(e) == 0) ? 0 : 1; }      // default ON; P3D_X3=0 keeps everything on the fp32-MFMA kernels
+    return g_fx == 1;
+}
+int fx_set_enabled(int on) { const int before = fx_enabled() ? 1 : 0; g_fx = on ? 1 : 0; return before; }
+
+// coverage counters (launches routed here vs to the fp32-MFMA kernel), read by bench.py so that no fallback goes uncounted
+static unsigned long long g_fx_count[6];      // fwd / dgrad / wgrad on this path, then fwd / dgrad / wgrad on the fp32-MFMA path
+static double g_fx_flops[6];
+void fx_count(int kind, const p3d_conv_desc* d) {
+    g_fx_count[kind] += 1;
+    g_fx_flops[kind] += 2.0 * d->N * d->K * d->Ho * d->Wo * (double)d->C * d->R * d->S;
+}
+void fx_stats(unsigned long long* counts, double* flops, int reset) {
+    for (int i = 0; i < 6; ++i) { if (counts) counts[i] = g_fx_count[i]; if (flops) flops[i] = g_fx_flops[i]; }
+    if (reset) for (int i = 0; i < 6; ++i) { g_fx_count[i] = 0; g_fx_flops[i] = 0.0; }
+}
+
+static bool fx_common(const p3d_conv_desc* d) {
+    return fx_enabled() && d->c_offset == 0 && d->c_total == d->C && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
+           (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31);
+}
+// forward: reduction channels C in steps of 16, four consecutive output pixels in one row, a reasonably filled channel tile
+bool fx_fwd_applies(const p3d_conv_desc* d, int min_m) {
+    return fx_common(d) && d->C % FX_BK == 0 && d->C >= 32 && d->Wo % 4 == 0 && d->W % 4 == 0 && d->K >= min_m;
+}
+// dgrad: reduction channels K in steps of 16; the GEMM columns are the pixels of one stride^2 parity class of the input
+bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m) {
+    if (!(fx_common(d) && d->K % FX_BK == 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= min_m && d->Wo % 4 == 0)) return false;
+    if (d->stride == 1) return d->W % 4 == 0;
+    return d->H % 2 == 0 && d->W % 8 == 0 && d->pad == d->dil * (d->R - 1) / 2 && (d->R == 1 || d->dil == 1);      // stride 2: classes of equal size
+}
+bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
+    return fx_common(d) && d->K >= min_m && d->C >= min_m && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
+}
+
+struct FxSplit { int splits, kchunk; };
+static FxSplit fx_plan_split(int64_t tiles, int nk) {
+    FxSplit s{1, 0};
+    static const bool nosplit = getenv("P3D_FX_NOSPLIT") != nullptr;      // debugging aid
+    if (nosplit || tiles > 400 || nk < 64) return s;
+    int64_t want = ceil_div(768, tiles);
+    if (want > nk / 32) want = nk / 32;
+    if (want > 8) want = 8;
+    if (want < 2) return s;
+    s.kchunk = (int)ceil_div(nk, want);
+    s.splits = (int)ceil_div(nk, s.kchunk);
+    if (s.splits < 2) { s.splits = 1; s.kchunk = 0; }
+    return s;
+}
+
+size_t fx_image_bytes(const p3d_conv_desc* d) { return d->R * d->S > 1 ? ((((size_t)d->K * d->C * d->R * d->S * sizeof(float)) + 255) & ~(size_t)255) : 0; }
+
+static FxSplit fx_fwd_split(const p3d_conv_desc* d) {
+    return fx_plan_split(ceil_div(d->K, FX_BM) * ceil_div((int64_t)d->N * d->Ho * d->Wo, FX_BN), d->R * d->S * (d->C / FX_BK));
+}
+static FxSplit fx_dgrad_split(const p3d_conv_desc* d) {
+    if (d->stride != 1) return FxSplit{1, 0};
+    return fx_plan_split(ceil_div(d->C, FX_BM) * ceil_div((int64_t)d->N * d->H * d->W, FX_BN), d->R * d->S * (d->K / FX_BK));
+}
+size_t fx_fwd_workspace(const p3d_conv_desc* d) {
+    const FxSplit s = fx_fwd_split(d);
+    return fx_image_bytes(d) + (s.splits > 1 ? (size_t)s.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
+}
+size_t fx_dgrad_workspace(const p3d_conv_desc* d) {
+    const FxSplit s = fx_dgrad_split(d);
+    return fx_image_bytes(d) + (s.splits > 1 ? (size_t)s.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
+}
+int fx_partial_rows_fwd(const p3d_conv_desc* d) {
+    const FxSplit s = fx_fwd_split(d);
+    return s.splits > 1 ? (d->N < 16 ? d->N : 16) : (int)ceil_div((int64_t)d->N * d->Ho * d->Wo, FX_BN);
+}
+int fx_partial_rows_dgrad(const p3d_conv_desc* d) {
+    const FxSplit s = fx_dgrad_split(d);
+    return s.splits > 1 ? (d->N < 16 ? d->N : 16) : (int)ceil_div((int64_t)d->N * d->H * d->W, FX_BN);
+}
+
+__global__ __launch_bounds__(256) void fx_weight_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ wT, int K, int C, int RS) {
+    const size_t KC = (size_t)K * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < KC; i += (size_t)gridDim.x * 256)
+        for (int tap = 0; tap < RS; ++tap) wT[(size_t)tap * KC + i] = w[i * RS + tap];
+}
+
+template <bool WM>
+static void fx_launch_conv(const FxConvParams& p, int pro, int epi, dim3 grid, hipStream_t st) {
+#define P3D_FX_CASE(PRO, EPI) if (pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<WM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
+    if constexpr (!WM) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) }
+    else { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
+#undef P3D_FX_CASE
+}
+
+static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* slabs, float* y, const float* bias, int nsplit, size_t slab_stride, int N, int M,
+                             int OHW, int accumulate, const float* ep_c, const float* ep_tab, float* partial) {
+    if (epi == 1) hipLaunchKernelGGL(fx_reduce_kernel<1>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
+    else if (epi == 2) hipLaunchKernelGGL(fx_reduce_kernel<2>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
+    else hipLaunchKernelGGL(fx_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
+}
+
+// y = conv(pro(x), w) (+ bias); fuse may be null (plain convolution)
+int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                    const FxFuse* fuse, hipStream_t st) {
+    const size_t need = fx_fwd_workspace(d);
+    if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    FxConvParams p{};
+    p.X = x; p.Y = y; p.bias = bias;
+    p.N = d->N; p.Cred = d->C; p.Hi = d->H; p.Wi = d->W; p.M = d->K; p.OH = d->Ho; p.OW = d->Wo; p.NP = d->N * d->Ho * d->Wo;
+    p.YH = d->Ho; p.YW = d->Wo; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
+    p.R = d->R; p.S = d->S; p.nR = d->R; p.nS = d->S; p.ntap = d->R * d->S; p.r0 = 0; p.rstep = 1; p.s0 = 0; p.sstep = 1;
+    p.hmul = d->stride; p.hoff = -d->pad; p.hstep = d->dil; p.wmul = d->stride; p.woff = -d->pad; p.wstep = d->dil;
+    p.accumulate = d->accumulate;
+    const int RS = d->R * d->S;
+    char* ws = (char*)workspace;
+    if (RS > 1) {
+        const int64_t kc = (int64_t)d->K * d->C;
+        hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
+        p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
+        ws += fx_image_bytes(d);
+    } else { p.W = w; p.w_ts = 0; p.w_ld = d->C; }
+    int pro = 0, epi = 0;
+    if (fuse) {
+        if (fuse->pro_tab) { pro = 1; p.tab = fuse->pro_tab; }
+        if (fuse->partial) { epi = 1; p.partial = fuse->partial; }
+    }
+    p.tiles_m = (int)ceil_div(d->K, FX_BM);
+    const int tiles_n = (int)ceil_div(p.NP, FX_BN);
+    const FxSplit sp = fx_fwd_split(d);
+    if (sp.splits > 1) {
+        p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
+        fx_launch_conv<false>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        fx_launch_reduce(epi, dim3((unsigned)d->K, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, y, bias, sp.splits, p.slab_stride, d->N, d->K,
+                         d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial);
+    } else {
+        fx_launch_conv<false>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+    }
+    return check_launch("fx_conv_fwd");
+}
+
+// dx (=|+=) dgrad(pro(dy), w); strided: one launch per parity class of the input, written straight into dx
+int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,
+                      hipStream_t st) {
+    const size_t need = fx_dgrad_workspace(d);
+    if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    FxConvParams p{};
+    p.X = dy; p.Y = dx;
+    p.N = d->N; p.Cred = d->K; p.Hi = d->Ho; p.Wi = d->Wo; p.M = d->C;
+    p.YH = d->H; p.YW = d->W;
+    p.R = d->R; p.S = d->S;
+    p.accumulate = d->accumulate;
+    const int RS = d->R * d->S;
+    char* ws = (char*)workspace;
+    if (RS > 1) {
+        const int64_t kc = (int64_t)d->K * d->C;
+        hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
+        p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
+        ws += fx_image_bytes(d);
+    } else { p.W = w; p.w_ts = 0; p.w_ld = d->C; }
+    int pro = 0, epi = 0;
+    if (fuse) {
+        if (fuse->pro_tab) { pro = fuse->pro_masked ? 2 : 3; p.tab = fuse->pro_tab; p.X2 = fuse->pro_c; }
+        if (fuse->partial) { epi = 2; p.partial = fuse->partial; p.ep_c = fuse->ep_c; p.ep_tab = fuse->ep_tab; }
+    }
+    p.tiles_m = (int)ceil_div(d->C, FX_BM);
+    if (d->stride == 1) {
+        p.OH = d->H; p.OW = d->W; p.NP = d->N * d->H * d->W; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
+        p.nR = d->R; p.nS = d->S; p.ntap = RS; p.r0 = 0; p.rstep = 1; p.s0 = 0; p.sstep = 1;
+        p.hmul = 1; p.hoff = d->pad; p.hstep = -d->dil; p.wmul = 1; p.woff = d->pad; p.wstep = -d->dil;
+        const int tiles_n = (int)ceil_div(p.NP, FX_BN);
+        const FxSplit sp = fx_dgrad_split(d);
+        if (sp.splits > 1) {
+            p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
+            fx_launch_conv<true>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
+                             d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
+        } else {
+            fx_launch_conv<true>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+        }
+        return check_launch("fx_conv_dgrad");
+    }
+    // stride 2: input pixel (ph + 2 i, pw + 2 j) of class (ph, pw) gathers dy at (i + off0 - ir * offstep, ...) over the taps r = r0 + rstep * ir that reach it
+    if (epi != 0) { set_error("fx_conv_dgrad: the BatchNorm-backward epilogue is not available for strided data gradients"); return P3D_EINVAL; }
+    const int st2 = d->stride;
+    p.OH = d->H / st2; p.OW = d->W / st2; p.NP = d->N * p.OH * p.OW; p.oys = st2; p.oxs = st2;
+    p.hmul = 1; p.wmul = 1;
+    const int tiles_n = (int)ceil_div(p.NP, FX_BN);
+    bool any_dead = false;
+    for (int ph = 0; ph < st2; ++ph)
+        for (int pw = 0; pw < st2; ++pw) {
+            int nr = 0, ns = 0, r0 = -1, r1 = -1, q0 = -1, q1 = -1;
+            for (int r = 0; r < d->R; ++r) { const int tt = ph + d->pad - r * d->dil; if (((tt % st2) + st2) % st2 == 0) { if (r0 < 0) r0 = r; else if (r1 < 0) r1 = r; ++nr; } }
+            for (int s = 0; s < d->S; ++s) { const int tt = pw + d->pad - s * d->dil; if (((tt % st2) + st2) % st2 == 0) { if (q0 < 0) q0 = s; else if (q1 < 0) q1 = s; ++ns; } }
+            if (nr == 0 || ns == 0) { any_dead = true; continue; }
+            FxConvParams c = p;
+            c.nR = nr; c.nS = ns; c.ntap = nr * ns; c.r0 = r0; c.rstep = r1 < 0 ? 1 : r1 - r0; c.s0 = q0; c.sstep = q1 < 0 ? 1 : q1 - q0;
+            const int th = ph + d->pad - r0 * d->dil, tw = pw + d->pad - q0 * d->dil;       // divisible by the stride
+            c.hoff = th >= 0 ? th / st2 : -((-th) / st2); c.hstep = -(c.rstep * d->dil) / st2;
+            c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
+            c.oy0 = ph; c.ox0 = pw;
+            fx_launch_conv<true>(c, pro, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+        }
+    (void)any_dead;      // classes no tap reaches keep what dx held: the caller zero-fills dx first unless it accumulates (p3d_conv2d_dgrad does)
+    return check_launch("fx_conv_dgrad");
+}
+
+bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 && d->R == 1; }
+
+int fx_wgrad_splits(const p3d_conv_desc* d) {
+    const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
+    const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
+    int64_t splits = ceil_div(1024, tiles);
+    if (splits > total / 32) splits = total / 32;           // at least 32 K steps per block
+    if (splits < 1) splits = 1;
+    const int64_t spb = ceil_div(total, splits);
+    return (int)ceil_div(total, spb);
+}
+
+// slabs [split][k][tap][c]
+int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, const FxFuse* fuse, hipStream_t st) {
+    FxWgradParams p{};
+    p.DY = dy; p.X = x; p.slabs = slabs;
+    p.N = d->N; p.K = d->K; p.C = d->C; p.Hi = d->H; p.Wi = d->W; p.OH = d->Ho; p.OW = d->Wo; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.nsplit = splits;
+    p.spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / FX_BK), splits);
+    int pa = 0, pb = 0;
+    if (fuse) {
+        if (fuse->pro_tab) { pa = fuse->pro_masked ? 2 : 3; p.atab = fuse->pro_tab; p.DY2 = fuse->pro_c; }
+        if (fuse->x_tab) { pb = 1; p.btab = fuse->x_tab; }
+    }
+    const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
+#define P3D_FX_WCASE(PA, PB) if (pa == PA && pb == PB) hipLaunchKernelGGL((fx_wgrad_kernel<PA, PB>), grid, dim3(256), 0, st, p);
+    P3D_FX_WCASE(0, 0) P3D_FX_WCASE(0, 1) P3D_FX_WCASE(2, 0) P3D_FX_WCASE(2, 1) P3D_FX_WCASE(3, 0) P3D_FX_WCASE(3, 1)
+#undef P3D_FX_WCASE
+    return check_launch("fx_conv_wgrad");
+}
+
+}  // namespace p3d

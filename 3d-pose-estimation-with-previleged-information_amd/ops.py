@@ -78,6 +78,18 @@ _side_streams = {}
 _side_workspaces = {}
 
 
+_second_workspaces = {}
+
+
+def _second_workspace(device, nbytes):
+    """A second grow-only scratch buffer on the launch stream (the block executor's weight-gradient slabs when no second stream is used)."""
+    ws = _second_workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _second_workspaces[device] = ws
+    return ws
+
+
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
@@ -756,8 +768,35 @@ def warp_crops(frames, homography, out_hw):
 
 
 def set_x3(on):
-    """Opt-in exact-fp32 kernels on the bf16 MFMA pipe for the dense 1x1 stride-1 layers (forward, dgrad, wgrad; csrc/p3d_x3.hip); returns the previous setting."""
+    """Exact-fp32 convolution kernels on the bf16 matrix pipe (csrc/p3d_fx.hip), ON by default; set_x3(False) (or P3D_X3=0) keeps every layer on the
+    fp32-MFMA kernels.  Returns the previous setting."""
+    global X3_EPOCH
+    X3_EPOCH += 1                       # (ops_block caches per-block plans that depend on it)
     return bool(lib().p3d_x3_enable(int(bool(on))))
+
+
+X3_EPOCH = 0
+
+
+def profile_convs(on):
+    """HIP-event brackets around every conv launch inside the library (p3d_profile_enable); returns the previous setting."""
+    return bool(lib().p3d_profile_enable(int(bool(on))))
+
+
+def collect_conv_profile():
+    """Synchronises; dict(kind -> (ms, algorithmic flops, launches)) for 'fwd', 'dgrad', 'wgrad' since the last collect."""
+    ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+    check(lib().p3d_profile_collect(ms, fl, n), 'p3d_profile_collect')
+    return {k: (float(ms[i]), float(fl[i]), int(n[i])) for i, k in enumerate(('fwd', 'dgrad', 'wgrad'))}
+
+
+def conv_path_stats(reset=False):
+    """Conv launches and algorithmic flops per path since the last reset: dict(x3=dict(fwd, dgrad, wgrad), fp32=dict(...)), each (launches, flops)."""
+    counts, flops = (ctypes.c_uint64 * 6)(), (ctypes.c_double * 6)()
+    lib().p3d_conv_path_stats(counts, flops, int(bool(reset)))
+    names = ('fwd', 'dgrad', 'wgrad')
+    return dict(x3={n: (int(counts[i]), float(flops[i])) for i, n in enumerate(names)},
+                fp32={n: (int(counts[3 + i]), float(flops[3 + i])) for i, n in enumerate(names)})
 
 
 def reproject_crops(frames, params20, out_hw, round_u8=True):

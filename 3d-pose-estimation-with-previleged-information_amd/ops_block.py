@@ -1,0 +1,198 @@
+"""One autograd node per residual block: `residual_block(block, x)` runs depthnet.BasicBlock / Bottleneck.forward (depthnet.py:40-56,96-116)
+through p3d_block_fwd / p3d_block_bwd (csrc/p3d_block.hip): the BatchNorm layers between two convolutions live inside the convolution kernels,
+and the host makes one C call per block and direction instead of a dozen per-layer autograd nodes.
+
+Used by _trunk._ResidualBlock.forward for dense fp32 blocks whose BatchNorm layers are in training mode; everything else (partial convolutions,
+-half_acc, frozen / evaluation BatchNorm, shapes the fused kernels do not take) stays on the per-layer path of ops.py.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import ConvDesc, P3DError, check, lib
+
+_vp = ctypes.c_void_p
+
+
+class BlockDesc(ctypes.Structure):
+    """struct p3d_block_desc"""
+    _fields_ = [('nconv', ctypes.c_int32), ('has_downsample', ctypes.c_int32), ('relu_out', ctypes.c_int32), ('need_dx', ctypes.c_int32),
+                ('accumulate_grads', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3), ('eps', ctypes.c_float * 4), ('momentum', ctypes.c_float * 4),
+                ('conv', ConvDesc * 4)]
+
+
+class BlockIO(ctypes.Structure):
+    """struct p3d_block_io"""
+    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('c', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
+                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
+                ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
+
+
+def _one(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+def _layers(block):
+    """[(slot, conv, bn)]: slots 0..nconv-1 the main chain, slot 3 the downsample pair."""
+    pairs = [(i, getattr(block, c), getattr(block, b)) for i, (c, b) in enumerate(block._chain)]
+    if block.downsample is not None:
+        pairs.append((3, block.downsample[0], block.downsample[1]))
+    return pairs
+
+
+class _Plan:
+    """Per (block, input shape): the descriptor, workspace sizes and output shapes.  None if the fused executor does not take the block."""
+
+    def __init__(self, block, x_shape):
+        d = BlockDesc()
+        d.nconv = len(block._chain)
+        d.has_downsample = int(block.downsample is not None)
+        d.relu_out = int(not block.skip_relu)
+        shape = tuple(x_shape)
+        self.shapes = {}
+        for slot, conv, bn in _layers(block):
+            src = tuple(x_shape) if slot in (0, 3) else shape
+            cd = ops._desc(src, conv.weight.shape, _one(conv.stride), _one(conv.padding), _one(conv.dilation))
+            d.conv[slot] = cd
+            d.eps[slot] = bn.eps
+            d.momentum[slot] = 0.1 if bn.momentum is None else bn.momentum
+            self.shapes[slot] = (cd.N, cd.K, cd.Ho, cd.Wo)
+            if slot != 3:
+                shape = self.shapes[slot]
+        self.desc = d
+        self.out_shape = shape
+        self.ok = bool(lib().p3d_block_supported(ctypes.byref(d))) and (block.downsample is not None or not block.skip_relu)
+        if self.ok and block.downsample is not None and self.shapes[3] != shape:
+            self.ok = False
+        self.main_bytes = self.side_bytes = 0
+        if self.ok:
+            m, s = ctypes.c_size_t(), ctypes.c_size_t()
+            check(lib().p3d_block_workspace_bytes(ctypes.byref(d), ctypes.byref(m), ctypes.byref(s)), 'p3d_block_workspace_bytes')
+            self.main_bytes, self.side_bytes = m.value, s.value
+        ks = [self.shapes[slot][1] for slot, _, _ in _layers(block)]
+        self.table_rows = sum(ks)
+
+
+def plan_for(block, x):
+    cache = block.__dict__.setdefault('_blk_plans', {})
+    key = (tuple(x.shape), ops.X3_EPOCH)
+    plan = cache.get(key)
+    if plan is None:
+        plan = cache[key] = _Plan(block, x.shape)
+    return plan
+
+
+def usable(block, x):
+    """The fused executor takes this call: dense fp32 block on the GPU, every BatchNorm computing batch statistics, supported shapes."""
+    if block.partial or x.dtype != torch.float32 or not x.is_cuda:
+        return False
+    for _, conv, bn in _layers(block):
+        if not bn.training or not (bn.affine and bn.track_running_stats) or conv.bias is not None or type(conv).__name__ != 'Conv2d':
+            return False
+    return plan_for(block, x).ok
+
+
+class ResidualBlockFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, block, *params):
+        x = x.contiguous()
+        plan = plan_for(block, x)
+        layers = _layers(block)
+        L = lib()
+        io = BlockIO()
+        io.x = x.data_ptr()
+        out = torch.empty(plan.out_shape, dtype=torch.float32, device=x.device)
+        io.out = out.data_ptr()
+        tables = torch.empty((plan.table_rows, 8), dtype=torch.float32, device=x.device)
+        cs, row = {}, 0
+        for slot, conv, bn in layers:
+            c = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
+            cs[slot] = c
+            io.w[slot], io.c[slot] = conv.weight.data_ptr(), c.data_ptr()
+            io.table[slot] = tables.data_ptr() + row * 32
+            row += plan.shapes[slot][1]
+            io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
+            io.running_mean[slot], io.running_var[slot] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            if getattr(bn, '_ticked', False):             # counted by the network's pre-hook (_trunk._tick_batchnorm)
+                bn._ticked = False
+            else:
+                bn.num_batches_tracked.add_(1)
+        ws = ops.workspace(x.device, plan.main_bytes)
+        check(L.p3d_block_fwd(ctypes.byref(plan.desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._stream()), 'p3d_block_fwd')
+        ctx.block, ctx.plan = block, plan
+        ctx.saved = (x, out, cs, tables)                   # (plain attributes: these tensors are never inputs / outputs of another node, save for x and out)
+        ctx.save_for_backward(x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        block, plan = ctx.block, ctx.plan
+        x, out = ctx.saved_tensors
+        _, _, cs, tables = ctx.saved
+        ctx.saved = None
+        layers = _layers(block)
+        L = lib()
+        dout = dout.contiguous()
+        d = plan.desc
+        need_dx = bool(ctx.needs_input_grad[0])
+        params = []
+        for slot, conv, bn in layers:
+            params += [(slot, 'dw', conv.weight), (slot, 'dgamma', bn.weight), (slot, 'dbeta', bn.bias)]
+        sinks = [ops._grad_sink(p) for _, _, p in params]
+        direct = all(s is not None for s in sinks)
+        grads = sinks if direct else [torch.empty_like(p) for _, _, p in params]
+        io = BlockIO()
+        io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
+        row = 0
+        for slot, conv, bn in layers:
+            io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
+            io.table[slot] = tables.data_ptr() + row * 32
+            row += plan.shapes[slot][1]
+            io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
+        for (slot, kind, _), g in zip(params, grads):
+            getattr(io, kind)[slot] = g.data_ptr()
+        keep = []
+        gbuf = torch.empty_like(out)
+        io.gbuf = gbuf.data_ptr()
+        for slot, _, _ in layers:
+            if slot < d.nconv - 1:
+                da = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
+                keep.append(da)
+                io.da[slot] = da.data_ptr()
+        dx = None
+        if need_dx:
+            if d.has_downsample:
+                dx = torch.empty_like(x)
+                io.dx = dx.data_ptr()
+            else:
+                dx = gbuf                                   # identity shortcut: conv1's data gradient is added onto g in place
+        desc = BlockDesc.from_buffer_copy(d)
+        desc.need_dx, desc.accumulate_grads = int(need_dx), int(direct)
+        ws = ops.workspace(x.device, plan.main_bytes)
+        two = ops.WGRAD_STREAM and direct
+        if two:
+            side = ops._side_stream(x.device)
+            ops._queue_join()
+            sws = ops._side_workspace(x.device, plan.side_bytes)
+            side_handle = _vp(side.cuda_stream)
+        else:
+            sws = ops._second_workspace(x.device, plan.side_bytes)
+            side_handle = None
+        check(L.p3d_block_bwd(ctypes.byref(desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._p(sws), sws.numel(), ops._stream(), side_handle), 'p3d_block_bwd')
+        if two:
+            for t in [x, dout, gbuf, tables] + list(cs.values()) + keep:      # freed by autograd while the second stream may still read them
+                t.record_stream(side)
+        if direct:
+            for _, _, p in params:
+                ops._grad_done(p)
+            return (dx, None) + (None,) * len(params)
+        return (dx, None) + tuple(grads)
+
+
+def residual_block(block, x):
+    params = []
+    for _, conv, bn in _layers(block):
+        params += [conv.weight, bn.weight, bn.bias]
+    return ResidualBlockFn.apply(x, block, *params)

@@ -84,11 +84,15 @@ size_t p3d_conv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x, const float* mult,
                          const float* mask_in, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
-/* db[k] (=|+=) sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
-/* OPT-IN, default off (also P3D_X3=1 in the environment): the dense stride-1 convolutions -- 1x1: forward, data and weight gradient; R x R "same": forward and data
- * gradient when the grid fills the chip -- (pixels per image a multiple of 128) as exact-fp32 GEMMs on the bf16 MFMA pipe (three-piece operand split, six piece products, fp32 accumulation; csrc/p3d_x3.hip).
- * Same results to fp32 rounding as the fp32 MFMA path; not used for the contract measurement.  Returns the previous setting. */
+/* The dense convolutions (whole weight tensor, odd square filters, stride 1 or 2, channel counts in steps of 16 and four-pixel-aligned rows: every layer of
+ * the reference networks but the 3- / 1-channel stems and odd-sized inputs) run by DEFAULT as exact-fp32 implicit GEMMs on the bf16 matrix pipe
+ * (three-piece operand split, six piece products, fp32 accumulation; csrc/p3d_fx.hip): fp32-grade results, measured error <= the
+ * fp32-MFMA kernel's.  p3d_x3_enable(0) (or P3D_X3=0 in the environment) keeps every layer on the v_mfma_f32_32x32x2_f32 kernels.  Returns the previous setting. */
 int32_t p3d_x3_enable(int32_t on);
+/* How many conv launches took which path since the last reset: counts / flops [0..2] = forward, data gradient, weight gradient on the bf16-pipe kernels,
+ * [3..5] = the same three on the fp32-MFMA kernels (algorithmic flops 2*N*K*Ho*Wo*C*R*S).  Host-side bookkeeping only. */
+void p3d_conv_path_stats(uint64_t* counts, double* flops, int32_t reset);
+/* db[k] (=|+=) sum_{n,h,w} dy[n,k,h,w]  (bias gradient of the regressor conv, depthnet.py:156). */
 int32_t p3d_conv2d_bgrad(const float* dy, int32_t N, int32_t K, int32_t HW, float* db, int32_t accumulate, void* stream);
 /* bias gradient of a PartialConv with bias (partial_conv.py:48-51: out = ((raw - b) * mult + b) * mask_out, so d out / d b = mask_out):
  * db[k] = sum over n, p of dy[n][k][p] * (mult[n][p] > 0);  mult [N,1,Ho,Wo] as written by p3d_mask_count_fwd. */
@@ -100,6 +104,63 @@ int32_t p3d_mask_count_fwd(const p3d_conv_desc* d, const float* mask, float* mul
 
 /* veil = (x != 0).float()  (partial_depthnet.py:215) */
 int32_t p3d_nonzero_mask(const float* x, float* mask, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One residual block per call, training mode: BasicBlock / Bottleneck forward and backward
+ *   depthnet.py:10-56 (BasicBlock), :59-116 (Bottleneck); twins resnet.py:21-119, fusionnet.py:21-127
+ * conv -> BN -> ReLU -> conv -> BN -> ReLU [-> conv -> BN] -> (+ identity | downsample conv -> BN) -> [ReLU], with the BatchNorm layers between two
+ * convolutions folded into the convolutions' operand fetch and epilogue (batch statistics from the producer's epilogue, normalise + ReLU in the consumer's
+ * fetch, the BatchNorm backward as a per-channel affine map in the producer's dgrad / wgrad fetch).  Replaces ~12 p3d_conv2d_* / p3d_bn_* calls per direction.
+ * Layouts: NCHW fp32.  conv[0..nconv-1] is the main chain, conv[3] the 1x1 downsample conv (has_downsample); every conv is bias-free.
+ * Per conv i the caller owns: c[i] (raw conv output, kept for backward), table[i] ([K_i][8] floats: the BN's forward constants {sc, sh, mean, invstd}
+ * written by forward, its backward map {A, B, K, 0} written by backward), and for backward da[i] (gradient w.r.t. the ReLU output that feeds conv i+1; i < nconv-1),
+ * gbuf (like out: dout * [out > 0]; with an identity shortcut it becomes dx in place) and dx (input gradient; only with a downsample branch).
+ * Parameter gradients dw / dgamma / dbeta are written, or added onto what is there when accumulate_grads != 0 (the flat gradient buffer).  Running statistics
+ * are updated in forward (momentum, unbiased variance), as p3d_bn_train_fwd does. */
+typedef struct p3d_block_desc {
+    int32_t nconv;              /* 2: BasicBlock (3x3, 3x3); 3: Bottleneck (1x1, 3x3 carrying stride / dilation, 1x1) */
+    int32_t has_downsample;
+    int32_t relu_out;           /* 0: -skip_relu on the last block of a stage (depthnet.py:176-186) */
+    int32_t need_dx;
+    int32_t accumulate_grads;
+    int32_t reserved[3];
+    float eps[4];
+    float momentum[4];
+    p3d_conv_desc conv[4];
+} p3d_block_desc;
+
+typedef struct p3d_block_io {
+    const float* x;             /* block input  [N, C_in, H, W] */
+    float* out;                 /* block output [N, K_last, Ho, Wo] */
+    const float* w[4];
+    float* c[4];
+    float* table[4];
+    const float* gamma[4];
+    const float* beta[4];
+    float* running_mean[4];     /* may be NULL (no running statistics) */
+    float* running_var[4];
+    /* backward only */
+    const float* dout;
+    float* gbuf;
+    float* da[4];
+    float* dx;
+    float* dw[4];
+    float* dgamma[4];
+    float* dbeta[4];
+} p3d_block_io;
+
+/* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 64, four-pixel-aligned rows, stride <= 2) */
+int32_t p3d_block_supported(const p3d_block_desc* b);
+int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
+int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* stream);
+/* side_stream: NULL, or a second stream for the weight-gradient kernels (ordered by events inside the call; the caller joins the streams before it reads dw) */
+int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
+                      void* stream, void* side_stream);
+
+/* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
+ * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */
+int32_t p3d_profile_enable(int32_t on);
+int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d (+ fused residual add and ReLU): nn.BatchNorm2d, F.relu, out + res

@@ -1,0 +1,130 @@
+"""The fused residual-block executor (p3d_block_fwd / p3d_block_bwd: one C call per block and direction, BatchNorm inside the convolution kernels)
+against the per-layer path (one autograd node per conv / BN, stand-alone BatchNorm passes) on the same module and data, and against float64 PyTorch:
+block output, input gradient, every parameter gradient and the BatchNorm running statistics (depthnet.py:40-56,96-116)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+#        kind          inplanes planes stride dil  N  H   downsample
+CASES = [('bottleneck', 256, 64, 1, 1, 4, 16, False),        # identity shortcut (layerN.1+)
+         ('bottleneck', 64, 64, 1, 1, 3, 32, True),          # layer1.0: 64 -> 256 with a stride-1 downsample
+         ('bottleneck', 256, 128, 2, 1, 4, 32, True),        # layer2.0 / layer3.0: stride 2 on the 3x3, strided 1x1 downsample
+         ('bottleneck', 256, 128, 1, 2, 2, 16, True),        # layer4.0 at -stride 16: dilation 2, stride-1 downsample
+         ('basic', 128, 128, 1, 1, 4, 16, False),
+         ('basic', 64, 128, 2, 1, 4, 32, True),
+         ('basic', 128, 256, 1, 4, 2, 32, True),             # -stride 8 geometry: dilation 4
+         ('bottleneck', 1024, 256, 1, 1, 64, 16, False)]      # a BASELINE-size layer3 block at batch 64 (split-K forward / dgrad of the 3x3)
+
+
+def build(pkg, kind, inplanes, planes, stride, dil, with_ds, seed):
+    tr = pkg._trunk
+    block_cls = tr.Bottleneck if kind == 'bottleneck' else tr.BasicBlock
+    ds = None
+    if with_ds:
+        ds = tr.Sequential(pkg.nn.Conv2d(inplanes, planes * block_cls.expansion, kernel_size=1, stride=stride, bias=False),
+                           pkg.nn.BatchNorm2d(planes * block_cls.expansion))
+    torch.manual_seed(seed)
+    block = block_cls(inplanes, planes, stride, dil, ds)
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    return block.cuda().train()
+
+
+def run(pkg, block, x0, dy, fused):
+    pkg._trunk.FUSED_BLOCKS = fused
+    try:
+        state = {k: v.clone() for k, v in block.state_dict().items()}
+        block.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = block(x)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res = dict(y=y.detach().clone(), dx=x.grad.clone(), grads={n: p.grad.clone() for n, p in block.named_parameters()},
+                   buffers={k: v.clone() for k, v in block.state_dict().items() if 'running' in k or 'tracked' in k})
+        block.load_state_dict(state)
+        return res
+    finally:
+        pkg._trunk.FUSED_BLOCKS = True
+
+
+@pytest.mark.parametrize('case', CASES, ids=['%s_c%d_p%d_s%d_d%d_n%d_h%d%s' % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], '_ds' if c[7] else '') for c in CASES])
+def test_fused_block_matches_per_layer_path_and_float64(case, pkg):
+    kind, inplanes, planes, stride, dil, n, h, with_ds = case
+    block = build(pkg, kind, inplanes, planes, stride, dil, with_ds, seed=inplanes + planes)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    x0 = torch.randn(n, inplanes, h, h, device='cuda', generator=gen).relu_()           # a block input is a ReLU output
+    assert pkg.ops_block.usable(block, x0)
+    with torch.no_grad():
+        shape = block(x0).shape
+    dy = torch.randn(shape, device='cuda', generator=gen)
+    plain = run(pkg, block, x0, dy, fused=False)
+    fused = run(pkg, block, x0, dy, fused=True)
+    assert not torch.equal(plain['y'], fused['y'])                                      # the other path really ran
+
+    # float64 reference of the same module (torch.nn semantics are the reference's: depthnet.py builds exactly these layers)
+    import copy
+    ref = copy.deepcopy(block).double()
+    for m in ref.modules():                                                             # plain torch forward, not the HIP one
+        if isinstance(m, torch.nn.Conv2d):
+            m.forward = lambda inp, _m=m: torch.nn.functional.conv2d(inp, _m.weight, None, _m.stride, _m.padding, _m.dilation)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.forward = lambda inp, _m=m: torch.nn.functional.batch_norm(inp, _m.running_mean, _m.running_var, _m.weight, _m.bias, True, 0.1, _m.eps)
+    xr = x0.double().requires_grad_(True)
+    out = xr
+    chain = block._chain
+    for i, (cname, bname) in enumerate(chain):
+        out = getattr(ref, bname)(getattr(ref, cname)(out))
+        if i < len(chain) - 1:
+            out = out.relu()
+    res = xr if not with_ds else ref.downsample[1](ref.downsample[0](xr))
+    yr = (out + res).relu()
+    yr.backward(dy.double())
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+    def rel2(a, b):
+        """Relative L2 error.  Gradients sit behind three ReLUs: an activation within fp32 rounding of zero has its mask decided differently by
+        two correct implementations (one element in 4 M at batch 64), which moves single gradient entries by O(1) but the norm by nothing."""
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    for name, got in (('fused', fused), ('per-layer', plain)):
+        assert rel(got['y'], yr.detach()) < 2e-5, (name, 'y')
+        assert rel2(got['dx'], xr.grad) < 1e-4, (name, 'dx', rel2(got['dx'], xr.grad))
+        for pname, p in ref.named_parameters():
+            assert rel2(got['grads'][pname], p.grad) < 2e-4, (name, pname, rel2(got['grads'][pname], p.grad))
+        for k, v in ref.state_dict().items():
+            if 'running' in k:
+                assert rel(got['buffers'][k], v) < 1e-5, (name, k)
+            if 'tracked' in k:
+                assert int(got['buffers'][k]) == int(v) + 1          # (the float64 copy runs functional batch_norm, which does not count)
+    # and the two HIP paths agree with each other at fp32 rounding level
+    assert rel(fused['y'], plain['y']) < 1e-5 and rel2(fused['dx'], plain['dx']) < 1e-4
+
+
+def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
+    """With FlatAdam the executor accumulates straight into the flat gradient buffer, weight gradients on the second stream."""
+    block = build(pkg, 'bottleneck', 256, 64, 1, 1, False, seed=9)
+    opt = pkg.optim.FlatAdam(list(block.named_parameters()), lr=1e-3)
+    gen = torch.Generator(device='cuda').manual_seed(4)
+    x0 = torch.randn(4, 256, 16, 16, device='cuda', generator=gen).relu_()
+    dy = torch.randn(4, 256, 16, 16, device='cuda', generator=gen)
+    res = []
+    for fused in (False, True):
+        pkg._trunk.FUSED_BLOCKS = fused
+        try:
+            opt.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            block(x).backward(dy)
+            pkg.ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append((opt.flat_g.clone(), x.grad.clone()))
+        finally:
+            pkg._trunk.FUSED_BLOCKS = True
+    scale = res[0][0].abs().max()
+    assert ((res[0][0] - res[1][0]).abs().max() / scale).item() < 2e-4
+    assert ((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max()).item() < 1e-4

@@ -500,102 +500,88 @@ def test_bn_properties_at_full_size(shape, pkg):
     assert (beta.grad.double() - dy.double().sum(dim=(0, 2, 3))).abs().max() < 1e-3 * dy.double().sum(dim=(0, 2, 3)).abs().max()
 
 
-def test_x3_wgrad_matches_fp32_path(pkg):
-    """Opt-in p3d_x3 path (exact fp32 through the bf16 MFMA pipe): weight gradients of 1x1 convolutions agree with float64 as closely as the fp32 MFMA
-    kernel does, for full, ragged (channel counts that are not multiples of the 128 tile) and accumulate-into-gradient cases."""
+X3_CASES = [
+    # n, c, k, h, r, stride, dil, bias     (pad = dil * (r - 1) // 2)
+    (8, 256, 128, 16, 1, 1, 1, False), (5, 192, 320, 8, 1, 1, 1, False), (64, 512, 128, 32, 1, 1, 1, False), (3, 1024, 256, 16, 1, 1, 1, False),
+    (2, 64, 256, 64, 1, 1, 1, False), (2, 256, 64, 16, 1, 1, 1, False), (64, 2048, 512, 16, 1, 1, 1, False),
+    (64, 128, 128, 32, 3, 1, 1, False), (64, 256, 272 + 64, 16, 3, 1, 1, True), (64, 128, 512, 16, 3, 1, 2, False), (2, 64, 64, 64, 3, 1, 1, False),
+    (4, 512, 512, 16, 3, 1, 2, False), (3, 2048, 272, 16, 3, 1, 1, True), (64, 128, 128, 32, 5, 1, 1, True),
+    (8, 128, 128, 64, 3, 2, 1, False), (4, 256, 512, 64, 1, 2, 1, False), (6, 256, 256, 32, 3, 2, 1, False), (2, 128, 256, 32, 3, 1, 4, False),
+    (3, 256, 128, 8, 3, 1, 1, False), (64, 256, 256, 16, 3, 1, 1, False),
+]
+
+
+def _x3_covers(n, c, k, h, r, stride, dil):
+    """Mirror of fx_fwd_applies / fx_dgrad_applies / fx_wgrad_applies (csrc/p3d_fx.hip) for the square shapes above."""
+    ho = (h - 1) // stride + 1
+    fwd = c % 16 == 0 and c >= 32 and ho % 4 == 0 and h % 4 == 0 and k >= 96
+    dgrad = k % 16 == 0 and k >= 32 and c % 4 == 0 and c >= 96 and ho % 4 == 0 and (h % 4 == 0 if stride == 1 else (h % 8 == 0 and (r == 1 or dil == 1)))
+    wgrad = k >= 96 and c >= 96 and (ho * ho) % 16 == 0 and ho % 4 == 0 and h % 4 == 0 and (r == 1 or c % 64 == 0)
+    return fwd, dgrad, wgrad
+
+
+@pytest.mark.parametrize('case', X3_CASES, ids=['n%d_c%d_k%d_h%d_%dx%d_s%d_d%d%s' % (c[0], c[1], c[2], c[3], c[4], c[4], c[5], c[6], '_bias' if c[7] else '') for c in X3_CASES])
+def test_x3_kernels_match_fp32_kernels(case, pkg):
+    """The default conv path (exact fp32 through the bf16 matrix pipe, csrc/p3d_fx.hip) against float64, next to the fp32-MFMA kernels on the same
+    data: forward, data gradient and weight gradient, for 1x1 / 3x3 / 5x5, stride 1 and 2, dilation 1 / 2 / 4, bias, output channel counts that are
+    not multiples of the 128-row tile (272, 320, 336) and split-K grids.  Its error is bounded by the fp32 kernel's; where the shape is covered the
+    other kernel really ran, where it is not both settings give the same bits."""
     ops = pkg.ops
-    gen = torch.Generator(device='cuda').manual_seed(9)
-    try:
-        for (n, c, k, h) in [(8, 256, 128, 16), (5, 192, 320, 8), (64, 512, 128, 32), (3, 1024, 256, 16)]:
-            x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 6 - 3).exp2()
-            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
-            ref = torch.einsum('nkp,ncp->kc', dy.double().flatten(2), x.double().flatten(2))
-            outs = {}
-            for on in (False, True):
-                ops.set_x3(on)
-                w = torch.zeros(k, c, 1, 1, device='cuda', requires_grad=True)
-                y = ops.conv2d(x, w, None, 1, 0, 1)
-                y.backward(dy)
-                outs[on] = w.grad.view(k, c).double()
-            scale = ref.abs().max()
-            err_fp32, err_x3 = ((outs[False] - ref).abs().max() / scale).item(), ((outs[True] - ref).abs().max() / scale).item()
-            assert err_x3 < 3e-6 and err_x3 < 4 * err_fp32 + 2e-7, (n, c, k, h, err_fp32, err_x3)        # both at fp32 rounding level (split counts differ)
-            assert not torch.equal(outs[False], outs[True])                      # the other kernel really ran
-    finally:
-        ops.set_x3(False)
-
-
-def test_x3_forward_and_dgrad_match_fp32_path(pkg):
-    """Opt-in p3d_x3 path for the forward and data-gradient passes of dense 1x1 / stride-1 convolutions (transposing LDS reads for the NCHW operand and
-    the transposed weight): error against float64 at the fp32 kernel's level; shapes the path does not cover fall back to the fp32 kernel."""
-    ops = pkg.ops
-    gen = torch.Generator(device='cuda').manual_seed(10)
-    try:
-        for (n, c, k, h, covered) in [(4, 256, 128, 16, (True, True)), (3, 128, 512, 32, (True, True)), (64, 2048, 512, 16, (True, True)), (2, 64, 256, 64, (True, False)),
-                                      (2, 256, 64, 16, (False, True)), (2, 192, 128, 8, (False, False))]:
-            x = (torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 6 - 3).exp2())
-            w0 = torch.randn(k, c, 1, 1, device='cuda', generator=gen) / c ** 0.5
-            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
-            y_ref = torch.einsum('kc,ncp->nkp', w0.view(k, c).double(), x.double().flatten(2)).view(n, k, h, h)
-            dx_ref = torch.einsum('kc,nkp->ncp', w0.view(k, c).double(), dy.double().flatten(2)).view(n, c, h, h)
-            res = {}
-            for on in (False, True):
-                ops.set_x3(on)
-                xr = x.clone().requires_grad_(True)
-                w = w0.clone().requires_grad_(True)
-                y = ops.conv2d(xr, w, None, 1, 0, 1)
-                y.backward(dy)
-                res[on] = (y.detach().double(), xr.grad.double(), w.grad.double())
-            for i, ref in ((0, y_ref), (1, dx_ref)):
-                scale = ref.abs().max()
-                e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
-                assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, i, e32, e3)
-                assert torch.equal(res[False][i], res[True][i]) != covered[i]       # covered passes really ran the other kernel
-    finally:
-        ops.set_x3(False)
-
-
-def test_x3_same_convolutions_match_fp32_path(pkg):
-    """Opt-in p3d_x3 path for R x R "same" convolutions (stride 1, pad = dil (R - 1) / 2): forward (with and without bias, ragged 272-channel output) and data
-    gradient and (for the large weights) weight gradient against float64, at the fp32 kernel's error level."""
-    ops = pkg.ops
-    gen = torch.Generator(device='cuda').manual_seed(11)
+    n, c, k, h, r, stride, dil, with_bias = case
+    pad = dil * (r - 1) // 2
+    gen = torch.Generator(device='cuda').manual_seed(11 + c + k)
     F = torch.nn.functional
+    x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 4 - 2).exp2()
+    w0 = torch.randn(k, c, r, r, device='cuda', generator=gen) / (c * r * r) ** 0.5
+    b0 = torch.randn(k, device='cuda', generator=gen) if with_bias else None
+    xd = x.double().requires_grad_(True)
+    y_ref = F.conv2d(xd, w0.double(), None if b0 is None else b0.double(), stride, pad, dil)
+    dy = torch.randn(y_ref.shape, device='cuda', generator=gen)
+    y_ref.backward(dy.double())
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w0.shape, dy.double(), stride, pad, dil)
+    res = {}
+    before = ops.set_x3(True)
     try:
-        for (n, c, k, h, r, dil, with_bias) in [(64, 128, 128, 32, 3, 1, False), (64, 256, 272 + 64, 16, 3, 1, True), (64, 128, 512, 16, 3, 2, False), (2, 64, 64, 64, 3, 1, False), (4, 512, 512, 16, 3, 2, False), (3, 2048, 272, 16, 3, 1, True),
-                                                (64, 128, 128, 32, 5, 1, True)]:
-            x = torch.randn(n, c, h, h, device='cuda', generator=gen) * (torch.rand(n, c, h, h, device='cuda', generator=gen) * 4 - 2).exp2()
-            w0 = torch.randn(k, c, r, r, device='cuda', generator=gen) / (c * r * r) ** 0.5
-            b0 = torch.randn(k, device='cuda', generator=gen) if with_bias else None
-            dy = torch.randn(n, k, h, h, device='cuda', generator=gen)
-            pad = dil * (r - 1) // 2
-            xd = x.double().requires_grad_(True)
-            y_ref = F.conv2d(xd, w0.double(), None if b0 is None else b0.double(), 1, pad, dil)
-            y_ref.backward(dy.double())
-            res = {}
-            for on in (False, True):
-                ops.set_x3(on)
-                xr = x.clone().requires_grad_(True)
-                w = w0.clone().requires_grad_(True)
-                b = None if b0 is None else b0.clone().requires_grad_(True)
-                y = ops.conv2d(xr, w, b, 1, pad, dil)
-                y.backward(dy)
-                res[on] = (y.detach().double(), xr.grad.double(), w.grad.double())
-            tiles = n * h * h // 128                                               # the path takes grids of >= 512 blocks with full-enough row tiles
-            fwd_covered = k >= 128 and -(-k // 128) * tiles >= 512
-            dgrad_covered = c % 128 == 0 and (c // 128) * tiles >= 512
-            for i, ref, covered in ((0, y_ref.detach(), fwd_covered), (1, xd.grad, dgrad_covered)):
-                scale = ref.abs().max()
-                e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
-                assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, r, dil, i, e32, e3)
-                assert torch.equal(res[False][i], res[True][i]) != covered, (n, c, k, h, r, dil, i)
-            dw_ref = torch.nn.grad.conv2d_weight(x.double(), w0.shape, dy.double(), 1, pad, dil)
-            scale = dw_ref.abs().max()
-            e32, e3 = ((res[False][2] - dw_ref).abs().max() / scale).item(), ((res[True][2] - dw_ref).abs().max() / scale).item()
-            assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (n, c, k, h, r, dil, 'wgrad', e32, e3)
-            assert torch.equal(res[False][2], res[True][2]) != (k >= 128 and c >= 128 and k * c >= 512 * 512 and h % 16 == 0)
+        for on in (False, True):
+            ops.set_x3(on)
+            xr = x.clone().requires_grad_(True)
+            w = w0.clone().requires_grad_(True)
+            b = None if b0 is None else b0.clone().requires_grad_(True)
+            y = ops.conv2d(xr, w, b, stride, pad, dil)
+            y.backward(dy)
+            res[on] = (y.detach().double(), xr.grad.double(), w.grad.double())
     finally:
-        ops.set_x3(False)
+        ops.set_x3(before)
+    covered = _x3_covers(n, c, k, h, r, stride, dil)
+    for i, ref, name in ((0, y_ref.detach(), 'fwd'), (1, xd.grad, 'dgrad'), (2, dw_ref, 'wgrad')):
+        scale = ref.abs().max()
+        e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
+        assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (name, e32, e3)
+        assert torch.equal(res[False][i], res[True][i]) != covered[i], name
+
+
+def test_x3_accumulates_into_existing_gradients(pkg):
+    """accumulate = 1 on the default path: a weight gradient added onto an existing .grad, and a data gradient joined onto the shortcut's (GradJoin)."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(4, 256, 16, 16, device='cuda', generator=gen)
+    w = (torch.randn(128, 256, 3, 3, device='cuda', generator=gen) / 48).requires_grad_(True)
+    dy = torch.randn(4, 128, 16, 16, device='cuda', generator=gen)
+    d = ops._desc(x.shape, w.shape, 1, 1, 1, accumulate=1)
+    import ctypes
+    L = pkg._lib.lib()
+    dx = torch.randn(x.shape, device='cuda', generator=gen)
+    dx0 = dx.clone()
+    ws = ops.workspace(x.device, L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)))
+    pkg._lib.check(L.p3d_conv2d_dgrad(ctypes.byref(d), ops._p(dy), ops._p(w.detach()), None, None, ops._p(dx), ops._p(ws), ws.numel(), ops._stream()), 'dgrad')
+    want = torch.nn.grad.conv2d_input(x.shape, w.detach().double(), dy.double(), 1, 1, 1) + dx0.double()
+    assert ((dx.double() - want).abs().max() / want.abs().max()).item() < 3e-6
+    dw = torch.randn(w.shape, device='cuda', generator=gen)
+    dw0 = dw.clone()
+    ws = ops.workspace(x.device, L.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+    pkg._lib.check(L.p3d_conv2d_wgrad(ctypes.byref(d), ops._p(dy), ops._p(x), None, None, ops._p(dw), ops._p(ws), ws.numel(), ops._stream()), 'wgrad')
+    want = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, 1, 1) + dw0.double()
+    assert ((dw.double() - want).abs().max() / want.abs().max()).item() < 3e-6
 
 
 def test_paste_over_and_brightness_contrast_match_reference_golden(pkg):
