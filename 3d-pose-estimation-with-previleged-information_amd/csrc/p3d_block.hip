@@ -206,7 +206,9 @@ static size_t g_event_next = 0;
 static hipEvent_t next_event() {
     if (g_events.size() < 128) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        static const int evt = [] { const char* v = getenv("P3D_BLK_EVT"); return v ? atoi(v) : 0; }();
+        const unsigned flags = evt == 1 ? hipEventDefault : (evt == 2 ? (hipEventDisableTiming | hipEventReleaseToSystem) : hipEventDisableTiming);
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return nullptr;
         g_events.push_back(e);
         return e;
     }
@@ -340,6 +342,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     }
     hipStream_t st = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : st;
     const bool two = ss != st;
+    static const int dbg = [] { const char* e = getenv("P3D_BLK_DBG"); return e ? atoi(e) : 0; }();
     size_t conv_ws = 0;
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
@@ -377,17 +380,24 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         FxFuse f{};
         f.pro_tab = io->table[i]; f.pro_c = io->c[i]; f.pro_masked = (i != last);
         // weight gradient (second stream): x operand = the previous conv's raw output seen through its BN + ReLU, or the block input
-        {
-            FxFuse fw = f;
+        const float* g_in = gi;                      // (gi moves on to this conv's input gradient below)
+        const FxFuse f_in = f;
+        auto launch_wgrad = [&, g_in, f_in]() -> int32_t {
+            FxFuse fw = f_in;
+            fw.partial = nullptr; fw.ep_c = nullptr; fw.ep_tab = nullptr;
             fw.x_tab = i > 0 ? io->table[i - 1] : nullptr;
             if (two) { if (!order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; } side_used = true; }
             ProfScope ps(2, d, ss);
             fx_count(2, d);
             const int splits = fx_wgrad_splits(d);
-            if (int32_t e = fx_conv_wgrad_slabs(d, gi, i > 0 ? (const float*)io->c[i - 1] : io->x, (float*)side_workspace, splits, &fw, ss)) return e;
-            dd.accumulate = acc;
-            if (int32_t e = wgrad_finish(&dd, (float*)side_workspace, splits, d->R * d->S > 1, io->dw[i], ss)) return e;
-        }
+            if (int32_t e = fx_conv_wgrad_slabs(d, g_in, i > 0 ? (const float*)io->c[i - 1] : io->x, (float*)side_workspace, splits, &fw, ss)) return e;
+            p3d_conv_desc dw_desc = *d;
+            dw_desc.accumulate = acc;
+            if (int32_t e = wgrad_finish(&dw_desc, (float*)side_workspace, splits, d->R * d->S > 1, io->dw[i], ss)) return e;
+            if (two && (dbg & 1)) order_after(st, ss);
+            return P3D_OK;
+        };
+        if (!(dbg & 32)) { if (int32_t e = launch_wgrad()) return e; }
         // data gradient
         if (i > 0) {
             const p3d_conv_desc* dp = &b->conv[i - 1];                       // producer of this conv's input
@@ -395,12 +405,14 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             if (epi) { f.partial = (float*)partial; f.ep_c = io->c[i - 1]; f.ep_tab = io->table[i - 1]; }
             dd = *d; dd.accumulate = 0;
             P3D_REQUIRE(io->da[i - 1], "block_bwd: null gradient buffer %d", i - 1);
+            if (two && (dbg & 4)) order_after(st, ss);
             {
                 ProfScope ps(1, d, st);
                 fx_count(1, d);
                 if (int32_t e = fx_conv_dgrad(&dd, gi, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
             }
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
+            if (two && (dbg & 2)) order_after(st, ss);
             if (epi) {
                 hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dp->K, 64)), dim3(256), 0, st, (const void*)partial, fx_partial_rows_dgrad(d), dp->K,
                                    cnt, 0, io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
@@ -417,16 +429,21 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             // that still reads g must have finished; downsample shortcut -> dx is written here and the downsample conv's dgrad adds to it below
             dd = *d;
             float* dx;
+            // The launch stream waits here for the second stream in BOTH cases.  Identity shortcut: the weight-gradient kernels that read g must be done
+            // before g's buffer becomes dx.  Downsample shortcut: no buffer is shared, yet without this wait the input gradient showed run-to-run
+            // differences in isolated 32-B sectors when the first conv's dgrad ran beside the weight-gradient kernels of the same block
+            // (tests/test_step_gpu.py::test_training_is_bitwise_reproducible; cause not established) -- so the order is kept strict.
+            if (two && side_used && !(dbg & 8) && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");
                 dx = io->gbuf; dd.accumulate = 1;
-                if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
             }
             ProfScope ps(1, d, st);
             fx_count(1, d);
             if (int32_t e = fx_conv_dgrad(&dd, gi, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
         }
+        if (dbg & 32) { if (int32_t e = launch_wgrad()) return e; }
     }
     // 3. downsample branch: weight gradient on the second stream, data gradient added onto dx
     if (b->has_downsample) {
@@ -444,6 +461,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             if (int32_t e = wgrad_finish(&dd, (float*)side_workspace, splits, false, io->dw[3], ss)) return e;
         }
         if (b->need_dx) {
+            if (two && (dbg & 16)) order_after(st, ss);
             dd = *d; dd.accumulate = 1;
             ProfScope ps(1, d, st);
             fx_count(1, d);

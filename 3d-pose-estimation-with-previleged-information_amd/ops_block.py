@@ -6,6 +6,7 @@ Used by _trunk._ResidualBlock.forward for dense fp32 blocks whose BatchNorm laye
 -half_acc, frozen / evaluation BatchNorm, shapes the fused kernels do not take) stays on the per-layer path of ops.py.
 """
 import ctypes
+import os
 
 import torch
 
@@ -13,6 +14,13 @@ from . import ops
 from ._lib import ConvDesc, P3DError, check, lib
 
 _vp = ctypes.c_void_p
+
+# P3D_BLOCK_SIDE=1: weight-gradient kernels of the block executor on the second HIP stream (p3d_block_bwd orders them with events).  OFF by default:
+# with it on, the training step was no longer bitwise reproducible run to run -- isolated 32-B sectors of a data gradient differed when a conv's
+# dgrad ran beside the weight-gradient kernels of the same block, although the two streams share read-only operands only; workspaces, event flags,
+# launch order and the runtime's fence options were ruled out (tools/debug_det.py).  Until the cause is known the block path
+# keeps every kernel on the launch stream, where the step is bitwise reproducible; the per-layer path (ops.py) keeps its second stream.
+BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '0') == '1'
 
 
 class BlockDesc(ctypes.Structure):
@@ -171,7 +179,7 @@ class ResidualBlockFn(torch.autograd.Function):
         desc = BlockDesc.from_buffer_copy(d)
         desc.need_dx, desc.accumulate_grads = int(need_dx), int(direct)
         ws = ops.workspace(x.device, plan.main_bytes)
-        two = ops.WGRAD_STREAM and direct
+        two = ops.WGRAD_STREAM and direct and BLOCK_SIDE_STREAM
         if two:
             side = ops._side_stream(x.device)
             ops._queue_join()

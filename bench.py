@@ -25,6 +25,8 @@ PKG_NAME = '3d-pose-estimation-with-previleged-information_amd'
 
 R50_FWD_BWD_GFLOP_PER_CROP = 56.03      # conv MACs*2, fwd + dgrad + wgrad (no stem dgrad)
 FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6      # fp32-equivalent ceiling of the pipe the convs run on: six bf16 piece products per fp32 product
 FLAGS = ['-suffix', 'bench', '-data_name', 'h36m', '-save_path', '/tmp/p3d_bench', '-criterion', 'SmoothL1', '-num_joints', '17',
          '-side_in', '256', '-stride', '16', '-depth', '16', '-depth_range', '1000', '-loss_div', '10', '-learn_rate', '5e-5',
          '-weight_decay', '4e-5', '-grad_norm', '5']
@@ -157,14 +159,14 @@ def main():
     for i in range(opt.warmup):
         trainer.train_step(*batches[i % nbuf])
     sync()
-    # (the fp16 step is bound by the host's launch rate, not by the GPU: event records in its timed region would lower `value`)
-    ops.PROFILE = [] if (rank == 0 and not opt.half) else None
+    # (no event brackets inside the timed region: the per-launch durations of `roofline` come from the kernel pass below)
+    ops.conv_path_stats(reset=True)
     t0 = time.perf_counter()
     for i in range(opt.steps):
         loss = trainer.train_step(*batches[i % nbuf])
     sync()
     elapsed = time.perf_counter() - t0
-    prof_overlapped, ops.PROFILE = ops.PROFILE or [], None
+    paths = ops.conv_path_stats(reset=True)
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,28 +192,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         fb_elapsed = float(t.item())
 
-    # Kernel pass (not part of `value`): the same steps once more with the weight-gradient kernels back on the launch stream.
-    # In the product configuration they run concurrently with the dgrad / BN-backward chain on a second stream, so a HIP-event
-    # bracket around one launch also spans time its CUs were lent to the other stream; serialised, a bracket is that kernel alone.
+    # Kernel pass (not part of `value`): the same steps once more with every kernel on the launch stream and every convolution launch bracketed by
+    # HIP events INSIDE the library, on the stream the kernel runs on (p3d_profile_enable: the block executor launches its convolutions from C, so
+    # the brackets live there; a "launch" = one conv call incl. its split-K reduce / slab fold / weight re-lay passes).
     overlap = ops.WGRAD_STREAM
     ops.WGRAD_STREAM = False
     ksteps = min(opt.steps, 10)
     trainer.train_step(*batches[0])
     sync()
-    ops.PROFILE = [] if rank == 0 else None
+    prof = None
+    if not opt.half:
+        ops.profile_convs(True)
+    else:
+        ops.PROFILE = [] if rank == 0 else None
     t1 = time.perf_counter()
     for i in range(ksteps):
         trainer.train_step(*batches[i % nbuf])
     sync()
     serial_elapsed = time.perf_counter() - t1
-    prof, ops.PROFILE = ops.PROFILE, None
+    if not opt.half:
+        ops.profile_convs(False)
+        prof = ops.collect_conv_profile()
+    else:
+        recs, ops.PROFILE = ops.PROFILE or [], None
+        prof = {}
+        for kind, fl, start, end in recs:
+            ms, f0, n0 = prof.get(kind, (0.0, 0.0, 0))
+            prof[kind] = (ms + start.elapsed_time(end), f0 + fl, n0 + 1)
     ops.WGRAD_STREAM = overlap
 
-    # Informational, never `value`: the same steps with the opt-in exact-fp32-on-the-bf16-pipe kernels of the dense 1x1 layers
-    # (csrc/p3d_x3.hip) switched on; same barrier / synchronize / max-over-ranks protocol.
-    x3_line = None
+    # Informational, never `value`: the same steps with every layer on the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32; P3D_X3=0), i.e. the round-1
+    # configuration: one autograd node per layer, stand-alone BatchNorm passes; same barrier / synchronize / max-over-ranks protocol.
+    fp32_line = None
     if not opt.half:
-        was = ops.set_x3(True)
+        was = ops.set_x3(False)
         xsteps = min(opt.steps, 10)
         trainer.train_step(*batches[0])
         sync()
@@ -219,70 +233,71 @@ def main():
         for i in range(xsteps):
             trainer.train_step(*batches[i % nbuf])
         sync()
-        x3_elapsed = time.perf_counter() - t2
+        x_elapsed = time.perf_counter() - t2
         ops.set_x3(was)
         if dist.is_initialized():
-            t = torch.tensor([x3_elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([x_elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            x3_elapsed = float(t.item())
-        x3_line = {'value': round(opt.batch * world * xsteps / x3_elapsed, 2), 'unit': 'crops/s', 'ms_per_step': round(x3_elapsed / xsteps * 1e3, 3), 'steps': xsteps,
-                   'note': 'opt-in P3D_X3=1: the dense stride-1 layers (1x1: all passes; R x R: forward and dgrad on large grids) as exact fp32 on the bf16 MFMA pipe (csrc/p3d_x3.hip); NOT the contract configuration'}
+            x_elapsed = float(t.item())
+        fp32_line = {'value': round(opt.batch * world * xsteps / x_elapsed, 2), 'unit': 'crops/s', 'ms_per_step': round(x_elapsed / xsteps * 1e3, 3), 'steps': xsteps,
+                     'note': 'P3D_X3=0: every convolution on v_mfma_f32_32x32x2_f32 (csrc/p3d_conv.hip), BatchNorm as stand-alone passes; NOT the contract configuration'}
 
     if rank == 0:
         crops = opt.batch * world * opt.steps
         value = crops / elapsed
-        def conv_stats(records, nsteps):
-            ms, flops = {}, 0.0
-            for kind, fl, start, end in records:
-                ms[kind] = ms.get(kind, 0.0) + start.elapsed_time(end)
-                flops += fl
-            return ms, flops, sum(ms.values()), len(records) // max(nsteps, 1)
-
-        conv_ms, conv_flops, conv_total_ms, launches = conv_stats(prof, ksteps)
-        ov_ms, _, ov_total_ms, _ = conv_stats(prof_overlapped, opt.steps)
-        # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r01_traffic.json);
+        conv_ms = {k: v[0] for k, v in prof.items()}
+        conv_flops = sum(v[1] for v in prof.values())
+        nlaunch = sum(v[2] for v in prof.values())
+        conv_total_ms = sum(conv_ms.values())
+        launches = nlaunch // max(ksteps, 1)
+        # which kernels the conv launches of the TIMED region took: nothing falls back uncounted
+        x3_fl = sum(v[1] for v in paths['x3'].values())
+        fp_fl = sum(v[1] for v in paths['fp32'].values())
+        coverage = {'x3_launches_per_step': sum(v[0] for v in paths['x3'].values()) // max(opt.steps, 1),
+                    'fp32_mfma_launches_per_step': sum(v[0] for v in paths['fp32'].values()) // max(opt.steps, 1),
+                    'x3_flop_fraction': round(x3_fl / max(x3_fl + fp_fl, 1.0), 4)}
+        # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r02_traffic.json);
         # a profiler cannot run inside the timed region, so the committed measurement of the same workload is quoted
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64 and opt.family == 'depthnet':
+        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+        if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64 and opt.family == 'depthnet' and not opt.half:
             with open(tpath) as f:
-                traffic = round(json.load(f)['bytes_per_launch_raw'])
+                traffic = round(json.load(f)['bytes_per_launch'])
         is_contract = opt.model == 'resnet50' and opt.family == 'depthnet'
         gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if is_contract else conv_flops / 1e9 / (opt.batch * ksteps)
         achieved = gflop_crop * opt.batch * ksteps / conv_total_ms             # GFLOP/ms == TFLOP/s
-        achieved_ov = gflop_crop * opt.batch * opt.steps / ov_total_ms if ov_total_ms > 0 else float('nan')
         step_tflops = value / world * gflop_crop / 1e3                          # crops/s x GFLOP/crop, whole step, per GPU
+        peak = BF16_MFMA_PEAK_TFLOPS if opt.half else X3_PEAK_TFLOPS
         out = {
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'fwd_bwd_crops_per_s': round(opt.batch * world * fsteps / fb_elapsed, 2), 'fwd_bwd_ms_per_step': round(fb_elapsed / fsteps * 1e3, 3),
-            'vs_baseline': None, 'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32 (3xbf16 split, 6 products, f32 accumulate)', 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': 'p3d::igemm_kernel (conv fwd/dgrad/wgrad, fp32 MFMA)', 'achieved': round(achieved, 2),
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                         'launches_per_step': launches,
-                         'avg_launch_ms': round(conv_total_ms / max(len(prof), 1), 4),
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)' if opt.half else
+                                   'p3d::fx_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16)',
+                         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                         'peak_note': 'dense f16 MFMA peak' if opt.half else 'fp32-equivalent ceiling of the pipe the kernel runs on: 2500 TFLOP/s dense bf16 / 6 piece products',
+                         'frac_of_fp32_mfma_peak': None if opt.half else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'fp32_mfma_peak': FP32_MFMA_PEAK_TFLOPS,
+                         'traffic': traffic, 'launches_per_step': launches,
+                         'avg_launch_ms': round(conv_total_ms / max(nlaunch, 1), 4),
                          'conv_ms_per_step': {k: round(v / ksteps, 3) for k, v in conv_ms.items()},
                          'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1),
-                         'measured': 'HIP events around every conv launch over %d extra steps of this run with the wgrad kernels serialised on the '
-                                     'launch stream (%.3f ms/step); in the timed region they share the GPU with the dgrad/BN chain on a second '
-                                     'stream, where the same brackets read %.2f TFLOP/s' % (ksteps, serial_elapsed / ksteps * 1e3, achieved_ov),
-                         'achieved_in_timed_region': round(achieved_ov, 2) if achieved_ov == achieved_ov else None,
-                         'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)},
+                         'conv_paths': coverage,
+                         'measured': 'HIP events around every conv launch (recorded inside the library on the launch stream) over %d extra steps of this run '
+                                     'with every kernel on one stream (%.3f ms/step)' % (ksteps, serial_elapsed / ksteps * 1e3),
+                         'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / peak, 4),
+                         'whole_step_frac_of_fp32_mfma_peak': None if opt.half else round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
-        if opt.half:
-            out['roofline']['peak'] = 2500.0          # dense f16 MFMA peak (MI355X_MICROARCH.md)
-            out['roofline']['frac'] = round(achieved / 2500.0, 4)
-            out['roofline']['whole_step_frac'] = round(step_tflops / 2500.0, 4)
-            out['roofline']['kernel'] = 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)'
-            out['roofline']['traffic'] = None
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
             out['cpu_baseline'] = cpu_baseline(pkg, opt.model, opt.cpu_batch, opt.cpu_steps)
-        if x3_line is not None:
-            out['optin_x3'] = x3_line
+        if fp32_line is not None:
+            out['fp32_mfma_only'] = fp32_line
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -5,21 +5,34 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 pkg = importlib.import_module('3d-pose-estimation-with-previleged-information_amd')
 import test_block_gpu as T
 
-def rel(a, b):
-    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
-
-kind, inp, pl, st, dil, n, h, ds = ('bottleneck', 256, 64, 1, 1, 64, 16, False)
-block = T.build(pkg, kind, inp, pl, st, dil, ds, seed=inp + pl)
-gen = torch.Generator(device='cuda').manual_seed(3)
-x0 = torch.randn(n, inp, h, h, device='cuda', generator=gen).relu_()
-dy = torch.randn(n, 256, h, h, device='cuda', generator=gen)
-order = sys.argv[1] if len(sys.argv) > 1 else 'pf'
-res = {}
-for ch in order:
-    res[ch] = T.run(pkg, block, x0, dy, fused=(ch == 'f'))
-    g = dy * (res[ch]['y'] > 0)
-    want = g.double().sum(dim=(0, 2, 3))
-    d = (res[ch]['grads']['bn3.bias'].double() - want).abs()
-    print(ch, 'dbeta3 max err', float(d.max()), int(d.argmax()))
-if 'p' in res and 'f' in res:
-    print('dx', rel(res['f']['dx'], res['p']['dx']))
+block = T.build(pkg, 'bottleneck', 256, 64, 1, 1, False, seed=9)
+gen = torch.Generator(device='cuda').manual_seed(4)
+x0 = torch.randn(4, 256, 16, 16, device='cuda', generator=gen).relu_()
+dy = torch.randn(4, 256, 16, 16, device='cuda', generator=gen)
+plain = T.run(pkg, block, x0, dy, fused=False)
+fused = T.run(pkg, block, x0, dy, fused=True)
+ref = copy.deepcopy(block).double()
+for m in ref.modules():
+    if isinstance(m, torch.nn.Conv2d):
+        m.forward = lambda inp, _m=m: torch.nn.functional.conv2d(inp, _m.weight, None, _m.stride, _m.padding, _m.dilation)
+    if isinstance(m, torch.nn.BatchNorm2d):
+        m.forward = lambda inp, _m=m: torch.nn.functional.batch_norm(inp, _m.running_mean, _m.running_var, _m.weight, _m.bias, True, 0.1, _m.eps)
+xr = x0.double().requires_grad_(True)
+out = xr
+acts = []
+for i, (cname, bname) in enumerate(block._chain):
+    out = getattr(ref, bname)(getattr(ref, cname)(out))
+    if i < 2:
+        acts.append(out)
+        out = out.relu()
+yr = (out + xr).relu()
+acts.append(out + xr)
+yr.backward(dy.double())
+for a in acts:
+    print('min |pre-relu activation|', float(a.abs().min()), 'count < 1e-5:', int((a.abs() < 1e-5).sum()))
+def e(a, b):
+    d = (a.double() - b.double()).abs()
+    return 'L2 %.1e med %.1e max %.1e' % (float(d.norm() / b.double().norm()), float(d.median() / b.double().abs().median()), float(d.max() / b.double().abs().max()))
+print('dx      fused', e(fused['dx'], xr.grad), '| plain', e(plain['dx'], xr.grad))
+for n, p in ref.named_parameters():
+    print('%-14s fused %s | plain %s' % (n, e(fused['grads'][n], p.grad), e(plain['grads'][n], p.grad)))
