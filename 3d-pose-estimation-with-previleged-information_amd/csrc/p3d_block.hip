@@ -16,6 +16,9 @@ namespace p3d {
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int CLOSE_MAX_SPLIT = 64;
+// channel counts below 96 leave the 128-row tile of the x3 kernels too empty (64-channel layers measured 72-82 TF there against 88-99 TF on the fp32-MFMA
+// kernel, weight gradient 37 against 80): blocks with such layers (ResNet layer1) stay on the per-layer path
+constexpr int BLOCK_MIN_M = 96;
 
 __device__ __forceinline__ void blk_sum3(double& a, double& b, double& c, double* red /*[12]*/) {
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
@@ -193,6 +196,56 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
     }
 }
 
+// a = relu(c * sc + sh): the BatchNorm + ReLU between two convolutions as a pass of its own (p3d_block mode 0; the statistics still come from the
+// producing conv's epilogue).  Same grid as the closing pass.
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ c, const float* __restrict__ tab, float* __restrict__ a, int N, int C, int HW) {
+    const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const float sc = tab[ch * FX_TAB], sh = tab[ch * FX_TAB + 1];
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + ch) * HW;
+        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
+        f32x4* av = reinterpret_cast<f32x4*>(a + off);
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            f32x4 q = cv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = fmaxf(fmaf(q[e], sc, sh), 0.f);
+            av[i] = q;
+        }
+    }
+}
+
+// d c = A * (masked ? g * [c * sc + sh > 0] : g) + B * c + K: the BatchNorm backward as a pass of its own (p3d_block mode 0; its channel sums still come
+// from the consuming conv's dgrad epilogue / the block-opening pass).  dc may alias g.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* g, const float* __restrict__ c, const float* __restrict__ tab, float* dc, int N, int C,
+                                                           int HW, int masked) {
+    const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const float sc = tab[ch * FX_TAB], sh = tab[ch * FX_TAB + 1], A = tab[ch * FX_TAB + 4], B = tab[ch * FX_TAB + 5], K = tab[ch * FX_TAB + 6];
+    for (int n = s; n < N; n += split) {
+        const size_t off = ((size_t)n * C + ch) * HW;
+        const f32x4* gv = reinterpret_cast<const f32x4*>(g + off);
+        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
+        f32x4* dv = reinterpret_cast<f32x4*>(dc + off);
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            f32x4 q = gv[i];
+            const f32x4 x = cv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = (!masked || fmaf(x[e], sc, sh) > 0.f) ? q[e] : 0.f;
+                q[e] = fmaf(A, gg, fmaf(B, x[e], K));
+            }
+            dv[i] = q;
+        }
+    }
+}
+
+// 0 (default): BatchNorm apply / backward-apply as passes of their own, statistics and sums in the conv epilogues; 1: everything in the conv operand
+// fetch (PRO variants of p3d_fx.hip).  The x3 kernels are bound by their staging VALU work, not by the matrix pipe, so the fetch-side arithmetic of mode 1
+// costs more conv time than the passes it removes (measured: DESIGN.md section 3); it is kept for when the kernels have VALU slack.
+static int fuse_mode() {
+    static const int m = [] { const char* e = getenv("P3D_BLOCK_FUSE"); return e ? atoi(e) : 0; }();
+    return m;
+}
+
 static int close_split(int N, int C) {
     int split = (int)ceil_div(2048, C);
     if (split > N) split = N;
@@ -237,7 +290,7 @@ static int32_t check_block(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        P3D_REQUIRE(fx_fwd_applies(d, 64) && fx_wgrad_applies(d, 64) && (d->C < 16 || fx_dgrad_applies(d, 64)),
+        P3D_REQUIRE(fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M),
                     "block: convolution %d (C=%d K=%d %dx%d stride %d, %dx%d input) is outside the fused path", i, d->C, d->K, d->R, d->S, d->stride, d->H, d->W);
         P3D_REQUIRE((d->Ho * d->Wo) % 4 == 0, "block: conv %d output rows are not 16-B groups", i);
     }
@@ -255,7 +308,7 @@ int32_t p3d_block_supported(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        if (!(fx_fwd_applies(d, 64) && fx_wgrad_applies(d, 64) && fx_dgrad_applies(d, 64))) return 0;
+        if (!(fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M))) return 0;
     }
     return 1;
 }
@@ -301,13 +354,14 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     conv_ws = align256(conv_ws);
     float* partial = (float*)((char*)workspace + conv_ws);
     const float* in = io->x;
+    const bool fused = fuse_mode() == 1;
     for (int i = 0; i < 4; ++i) {
         const bool ds = i == 3;
         if (i >= b->nconv && !(ds && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
         P3D_REQUIRE(io->w[i] && io->c[i] && io->table[i] && io->gamma[i] && io->beta[i], "block_fwd: null tensor of conv %d", i);
         FxFuse f{};
-        f.pro_tab = (!ds && i > 0) ? io->table[i - 1] : nullptr;
+        f.pro_tab = (fused && !ds && i > 0) ? io->table[i - 1] : nullptr;
         f.partial = partial;
         {
             ProfScope ps(0, d, st);
@@ -316,7 +370,15 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         }
         hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, 64)), dim3(256), 0, st, (const float*)partial, fx_partial_rows_fwd(d), d->K,
                            (double)d->N * d->Ho * d->Wo, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
-        if (!ds) in = io->c[i];
+        if (!ds) {
+            in = io->c[i];
+            if (!fused && i < b->nconv - 1) {
+                P3D_REQUIRE(io->a[i], "block_fwd: null activation buffer %d", i);
+                hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(d->K, close_split(d->N, d->K)), dim3(256), 0, st, (const float*)io->c[i], (const float*)io->table[i], io->a[i],
+                                   d->N, d->K, d->Ho * d->Wo);
+                in = io->a[i];
+            }
+        }
     }
     const int last = b->nconv - 1;
     const p3d_conv_desc* dl = &b->conv[last];
@@ -342,7 +404,6 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     }
     hipStream_t st = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : st;
     const bool two = ss != st;
-    static const int dbg = [] { const char* e = getenv("P3D_BLK_DBG"); return e ? atoi(e) : 0; }();
     size_t conv_ws = 0;
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
@@ -370,34 +431,48 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                            io->dgamma[3], io->dbeta[3], acc, io->table[3]);
     if (int32_t e = check_launch("block_bwd open")) return e;
 
-    // 2. the main chain, last conv first.  The gradient that enters conv i is `gi` taken through BN i's backward map (masked by its ReLU, except
-    //    the closing BN whose ReLU went into g already); what leaves it is the gradient w.r.t. the previous ReLU's output.
+    // 2. the main chain, last conv first.  The gradient that enters conv i is the upstream gradient taken through BN i's backward map (masked by its
+    //    ReLU, except the closing BN whose ReLU went into g already); what leaves it is the gradient w.r.t. the previous ReLU's output.
+    //    mode 0: that map is applied by a pass of its own (in place on da[i]; the closing BN's into io->dcl, because g is still needed), mode 1: inside
+    //    the operand fetch of the dgrad / wgrad kernels.
+    const bool fused = fuse_mode() == 1;
     const float* gi = g;
     bool side_used = false;
+    auto bwd_apply = [&](const float* gin, int slot, float* dst, int masked) {
+        const p3d_conv_desc* dc = &b->conv[slot];
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dc->K, close_split(dc->N, dc->K)), dim3(256), 0, st, gin, (const float*)io->c[slot], (const float*)io->table[slot], dst,
+                           dc->N, dc->K, dc->Ho * dc->Wo, masked);
+    };
+    auto launch_wgrad = [&](int slot, const float* dy, const float* xin, const FxFuse* fw, bool tapm) -> int32_t {
+        const p3d_conv_desc* d = &b->conv[slot];
+        if (two) { if (!order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; } side_used = true; }
+        ProfScope ps(2, d, ss);
+        fx_count(2, d);
+        const int splits = fx_wgrad_splits(d);
+        if (int32_t e = fx_conv_wgrad_slabs(d, dy, xin, (float*)side_workspace, splits, fw, ss)) return e;
+        p3d_conv_desc dw_desc = *d;
+        dw_desc.accumulate = acc;
+        return wgrad_finish(&dw_desc, (float*)side_workspace, splits, tapm, io->dw[slot], ss);
+    };
+    if (!fused) P3D_REQUIRE(io->dcl, "block_bwd: null buffer for the closing BatchNorm's input gradient");
     for (int i = last; i >= 0; --i) {
         const p3d_conv_desc* d = &b->conv[i];
         p3d_conv_desc dd = *d;
         FxFuse f{};
-        f.pro_tab = io->table[i]; f.pro_c = io->c[i]; f.pro_masked = (i != last);
-        // weight gradient (second stream): x operand = the previous conv's raw output seen through its BN + ReLU, or the block input
-        const float* g_in = gi;                      // (gi moves on to this conv's input gradient below)
-        const FxFuse f_in = f;
-        auto launch_wgrad = [&, g_in, f_in]() -> int32_t {
-            FxFuse fw = f_in;
-            fw.partial = nullptr; fw.ep_c = nullptr; fw.ep_tab = nullptr;
-            fw.x_tab = i > 0 ? io->table[i - 1] : nullptr;
-            if (two) { if (!order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; } side_used = true; }
-            ProfScope ps(2, d, ss);
-            fx_count(2, d);
-            const int splits = fx_wgrad_splits(d);
-            if (int32_t e = fx_conv_wgrad_slabs(d, g_in, i > 0 ? (const float*)io->c[i - 1] : io->x, (float*)side_workspace, splits, &fw, ss)) return e;
-            p3d_conv_desc dw_desc = *d;
-            dw_desc.accumulate = acc;
-            if (int32_t e = wgrad_finish(&dw_desc, (float*)side_workspace, splits, d->R * d->S > 1, io->dw[i], ss)) return e;
-            if (two && (dbg & 1)) order_after(st, ss);
-            return P3D_OK;
-        };
-        if (!(dbg & 32)) { if (int32_t e = launch_wgrad()) return e; }
+        const float* dy = gi;                                                 // what the conv kernels read as "dy"
+        if (fused) { f.pro_tab = io->table[i]; f.pro_c = io->c[i]; f.pro_masked = (i != last); }
+        else if (i == last) { bwd_apply(gi, i, io->dcl, 0); dy = io->dcl; }
+        else { bwd_apply(gi, i, io->da[i], 1); dy = io->da[i]; }              // in place: da[i] now holds d c_i
+        // weight gradient: x operand = the previous ReLU's output (mode 1: the previous conv's raw output seen through its BN + ReLU), or the block input
+        {
+            FxFuse fw = f;
+            const float* xin = io->x;
+            if (i > 0) {
+                if (fused) { xin = io->c[i - 1]; fw.x_tab = io->table[i - 1]; }
+                else { P3D_REQUIRE(io->a[i - 1], "block_bwd: null activation buffer %d", i - 1); xin = io->a[i - 1]; }
+            }
+            if (int32_t e = launch_wgrad(i, dy, xin, &fw, d->R * d->S > 1)) return e;
+        }
         // data gradient
         if (i > 0) {
             const p3d_conv_desc* dp = &b->conv[i - 1];                       // producer of this conv's input
@@ -405,14 +480,12 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             if (epi) { f.partial = (float*)partial; f.ep_c = io->c[i - 1]; f.ep_tab = io->table[i - 1]; }
             dd = *d; dd.accumulate = 0;
             P3D_REQUIRE(io->da[i - 1], "block_bwd: null gradient buffer %d", i - 1);
-            if (two && (dbg & 4)) order_after(st, ss);
             {
                 ProfScope ps(1, d, st);
                 fx_count(1, d);
-                if (int32_t e = fx_conv_dgrad(&dd, gi, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
+                if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
             }
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
-            if (two && (dbg & 2)) order_after(st, ss);
             if (epi) {
                 hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dp->K, 64)), dim3(256), 0, st, (const void*)partial, fx_partial_rows_dgrad(d), dp->K,
                                    cnt, 0, io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
@@ -425,15 +498,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             }
             gi = io->da[i - 1];
         } else if (b->need_dx) {
-            // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad), so every kernel of the second stream
-            // that still reads g must have finished; downsample shortcut -> dx is written here and the downsample conv's dgrad adds to it below
+            // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
+            // the downsample conv's dgrad adds to it below.  With a second stream the launch stream waits for it here in BOTH cases.  Identity: the
+            // weight-gradient kernels that read g must be done before g's buffer becomes dx.  Downsample: no buffer is shared, yet without the wait the
+            // input gradient showed run-to-run differences; the two-stream mode is off by default for that reason.
             dd = *d;
             float* dx;
-            // The launch stream waits here for the second stream in BOTH cases.  Identity shortcut: the weight-gradient kernels that read g must be done
-            // before g's buffer becomes dx.  Downsample shortcut: no buffer is shared, yet without this wait the input gradient showed run-to-run
-            // differences in isolated 32-B sectors when the first conv's dgrad ran beside the weight-gradient kernels of the same block
-            // (tests/test_step_gpu.py::test_training_is_bitwise_reproducible; cause not established) -- so the order is kept strict.
-            if (two && side_used && !(dbg & 8) && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
+            if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");
@@ -441,31 +512,27 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             }
             ProfScope ps(1, d, st);
             fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, gi, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
+            if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
         }
-        if (dbg & 32) { if (int32_t e = launch_wgrad()) return e; }
     }
-    // 3. downsample branch: weight gradient on the second stream, data gradient added onto dx
+    // 3. downsample branch: its BN's backward map applied to g, weight gradient, data gradient added onto dx
     if (b->has_downsample) {
         const p3d_conv_desc* d = &b->conv[3];
         FxFuse f{};
-        f.pro_tab = io->table[3]; f.pro_c = io->c[3]; f.pro_masked = 0;
-        p3d_conv_desc dd = *d;
-        {
-            if (two && !order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
-            ProfScope ps(2, d, ss);
-            fx_count(2, d);
-            const int splits = fx_wgrad_splits(d);
-            if (int32_t e = fx_conv_wgrad_slabs(d, g, io->x, (float*)side_workspace, splits, &f, ss)) return e;
-            dd.accumulate = acc;
-            if (int32_t e = wgrad_finish(&dd, (float*)side_workspace, splits, false, io->dw[3], ss)) return e;
+        const float* dy = g;
+        if (fused) { f.pro_tab = io->table[3]; f.pro_c = io->c[3]; f.pro_masked = 0; }
+        else {
+            if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }      // (dcl is still read by the closing conv's wgrad)
+            bwd_apply(g, 3, io->dcl, 0);
+            dy = io->dcl;
         }
+        if (int32_t e = launch_wgrad(3, dy, io->x, &f, false)) return e;
         if (b->need_dx) {
-            if (two && (dbg & 16)) order_after(st, ss);
-            dd = *d; dd.accumulate = 1;
+            p3d_conv_desc dd = *d;
+            dd.accumulate = 1;
             ProfScope ps(1, d, st);
             fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, g, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
+            if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
         }
     }
     return check_launch("block_bwd");

@@ -513,22 +513,27 @@ void fx_stats(unsigned long long* counts, double* flops, int reset) {
     if (reset) for (int i = 0; i < 6; ++i) { g_fx_count[i] = 0; g_fx_flops[i] = 0.0; }
 }
 
+static int fx_min_m(int asked) {      // tuning aid: P3D_FX_MIN_M lowers the channel-tile fill the per-layer entry points ask for (default 96 of 128 rows)
+    static const int forced = [] { const char* e = getenv("P3D_FX_MIN_M"); return e ? atoi(e) : 0; }();
+    return forced > 0 && forced < asked ? forced : asked;
+}
+
 static bool fx_common(const p3d_conv_desc* d) {
     return fx_enabled() && d->c_offset == 0 && d->c_total == d->C && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
            (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31);
 }
 // forward: reduction channels C in steps of 16, four consecutive output pixels in one row, a reasonably filled channel tile
 bool fx_fwd_applies(const p3d_conv_desc* d, int min_m) {
-    return fx_common(d) && d->C % FX_BK == 0 && d->C >= 32 && d->Wo % 4 == 0 && d->W % 4 == 0 && d->K >= min_m;
+    return fx_common(d) && d->C % FX_BK == 0 && d->C >= 32 && d->Wo % 4 == 0 && d->W % 4 == 0 && d->K >= fx_min_m(min_m);
 }
 // dgrad: reduction channels K in steps of 16; the GEMM columns are the pixels of one stride^2 parity class of the input
 bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m) {
-    if (!(fx_common(d) && d->K % FX_BK == 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= min_m && d->Wo % 4 == 0)) return false;
+    if (!(fx_common(d) && d->K % FX_BK == 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= fx_min_m(min_m) && d->Wo % 4 == 0)) return false;
     if (d->stride == 1) return d->W % 4 == 0;
     return d->H % 2 == 0 && d->W % 8 == 0 && d->pad == d->dil * (d->R - 1) / 2 && (d->R == 1 || d->dil == 1);      // stride 2: classes of equal size
 }
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
-    return fx_common(d) && d->K >= min_m && d->C >= min_m && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
+    return fx_common(d) && d->K >= fx_min_m(min_m) && d->C >= fx_min_m(min_m) && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
 }
 
 struct FxSplit { int splits, kchunk; };

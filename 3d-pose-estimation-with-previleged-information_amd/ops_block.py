@@ -32,8 +32,8 @@ class BlockDesc(ctypes.Structure):
 
 class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
-    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('c', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
-                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
+    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
+                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcl', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
                 ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
 
 
@@ -114,11 +114,14 @@ class ResidualBlockFn(torch.autograd.Function):
         out = torch.empty(plan.out_shape, dtype=torch.float32, device=x.device)
         io.out = out.data_ptr()
         tables = torch.empty((plan.table_rows, 8), dtype=torch.float32, device=x.device)
-        cs, row = {}, 0
+        cs, acts, row = {}, {}, 0
         for slot, conv, bn in layers:
             c = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
             cs[slot] = c
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), c.data_ptr()
+            if slot < plan.desc.nconv - 1:
+                acts[slot] = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
+                io.a[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32
             row += plan.shapes[slot][1]
             io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -130,7 +133,7 @@ class ResidualBlockFn(torch.autograd.Function):
         ws = ops.workspace(x.device, plan.main_bytes)
         check(L.p3d_block_fwd(ctypes.byref(plan.desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._stream()), 'p3d_block_fwd')
         ctx.block, ctx.plan = block, plan
-        ctx.saved = (x, out, cs, tables)                   # (plain attributes: these tensors are never inputs / outputs of another node, save for x and out)
+        ctx.saved = (x, out, cs, tables, acts)             # (plain attributes: these tensors are never inputs / outputs of another node, save for x and out)
         ctx.save_for_backward(x, out)
         return out
 
@@ -138,7 +141,7 @@ class ResidualBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         block, plan = ctx.block, ctx.plan
         x, out = ctx.saved_tensors
-        _, _, cs, tables = ctx.saved
+        _, _, cs, tables, acts = ctx.saved
         ctx.saved = None
         layers = _layers(block)
         L = lib()
@@ -156,6 +159,8 @@ class ResidualBlockFn(torch.autograd.Function):
         row = 0
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
+            if slot in acts:
+                io.a[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32
             row += plan.shapes[slot][1]
             io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -163,7 +168,8 @@ class ResidualBlockFn(torch.autograd.Function):
             getattr(io, kind)[slot] = g.data_ptr()
         keep = []
         gbuf = torch.empty_like(out)
-        io.gbuf = gbuf.data_ptr()
+        dcl = torch.empty_like(out)
+        io.gbuf, io.dcl = gbuf.data_ptr(), dcl.data_ptr()
         for slot, _, _ in layers:
             if slot < d.nconv - 1:
                 da = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
@@ -190,7 +196,7 @@ class ResidualBlockFn(torch.autograd.Function):
             side_handle = None
         check(L.p3d_block_bwd(ctypes.byref(desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._p(sws), sws.numel(), ops._stream(), side_handle), 'p3d_block_bwd')
         if two:
-            for t in [x, dout, gbuf, tables] + list(cs.values()) + keep:      # freed by autograd while the second stream may still read them
+            for t in [x, dout, gbuf, dcl, tables] + list(cs.values()) + list(acts.values()) + keep:      # freed by autograd while the second stream may still read them
                 t.record_stream(side)
         if direct:
             for _, _, p in params:

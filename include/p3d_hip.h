@@ -112,7 +112,7 @@ int32_t p3d_nonzero_mask(const float* x, float* mask, int64_t n, void* stream);
  * convolutions folded into the convolutions' operand fetch and epilogue (batch statistics from the producer's epilogue, normalise + ReLU in the consumer's
  * fetch, the BatchNorm backward as a per-channel affine map in the producer's dgrad / wgrad fetch).  Replaces ~12 p3d_conv2d_* / p3d_bn_* calls per direction.
  * Layouts: NCHW fp32.  conv[0..nconv-1] is the main chain, conv[3] the 1x1 downsample conv (has_downsample); every conv is bias-free.
- * Per conv i the caller owns: c[i] (raw conv output, kept for backward), table[i] ([K_i][8] floats: the BN's forward constants {sc, sh, mean, invstd}
+ * Per conv i the caller owns: c[i] (raw conv output, kept for backward), a[i] (the ReLU output that feeds conv i+1, kept for backward; i < nconv-1), table[i] ([K_i][8] floats: the BN's forward constants {sc, sh, mean, invstd}
  * written by forward, its backward map {A, B, K, 0} written by backward), and for backward da[i] (gradient w.r.t. the ReLU output that feeds conv i+1; i < nconv-1),
  * gbuf (like out: dout * [out > 0]; with an identity shortcut it becomes dx in place) and dx (input gradient; only with a downsample branch).
  * Parameter gradients dw / dgamma / dbeta are written, or added onto what is there when accumulate_grads != 0 (the flat gradient buffer).  Running statistics
@@ -134,6 +134,7 @@ typedef struct p3d_block_io {
     float* out;                 /* block output [N, K_last, Ho, Wo] */
     const float* w[4];
     float* c[4];
+    float* a[4];                /* a[i] = relu(bn_i(c[i])), i < nconv-1: written by forward, read by backward (the x operand of conv i+1's weight gradient) */
     float* table[4];
     const float* gamma[4];
     const float* beta[4];
@@ -142,6 +143,7 @@ typedef struct p3d_block_io {
     /* backward only */
     const float* dout;
     float* gbuf;
+    float* dcl;                 /* like out: scratch for the input gradient of the closing BatchNorm (then of the downsample BatchNorm) */
     float* da[4];
     float* dx;
     float* dw[4];
@@ -149,7 +151,7 @@ typedef struct p3d_block_io {
     float* dbeta[4];
 } p3d_block_io;
 
-/* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 64, four-pixel-aligned rows, stride <= 2) */
+/* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 96, four-pixel-aligned rows, stride <= 2) */
 int32_t p3d_block_supported(const p3d_block_desc* b);
 int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
 int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* stream);

@@ -8,12 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 #        kind          inplanes planes stride dil  N  H   downsample
-CASES = [('bottleneck', 256, 64, 1, 1, 4, 16, False),        # identity shortcut (layerN.1+)
-         ('bottleneck', 64, 64, 1, 1, 3, 32, True),          # layer1.0: 64 -> 256 with a stride-1 downsample
+CASES = [('bottleneck', 512, 128, 1, 1, 4, 16, False),       # identity shortcut (layerN.1+)
+         ('bottleneck', 128, 128, 1, 1, 3, 32, True),        # a stride-1 downsample (the layer1.0 pattern at 128 channels)
          ('bottleneck', 256, 128, 2, 1, 4, 32, True),        # layer2.0 / layer3.0: stride 2 on the 3x3, strided 1x1 downsample
          ('bottleneck', 256, 128, 1, 2, 2, 16, True),        # layer4.0 at -stride 16: dilation 2, stride-1 downsample
          ('basic', 128, 128, 1, 1, 4, 16, False),
-         ('basic', 64, 128, 2, 1, 4, 32, True),
+         ('basic', 128, 256, 2, 1, 4, 32, True),
          ('basic', 128, 256, 1, 4, 2, 32, True),             # -stride 8 geometry: dilation 4
          ('bottleneck', 1024, 256, 1, 1, 64, 16, False)]      # a BASELINE-size layer3 block at batch 64 (split-K forward / dgrad of the 3x3)
 
@@ -124,9 +124,14 @@ def test_fused_block_matches_per_layer_path_and_float64(case, pkg):
     assert rel(fused['y'], plain['y']) < 1e-5 and err(fused['dx'], plain['dx']) < tol
 
 
+def test_blocks_with_64_channel_layers_stay_on_the_per_layer_path(pkg):
+    block = build(pkg, 'bottleneck', 256, 64, 1, 1, False, seed=1)
+    assert not pkg.ops_block.usable(block, torch.zeros(2, 256, 16, 16, device='cuda'))
+
+
 def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
     """With FlatAdam the executor accumulates straight into the flat gradient buffer, weight gradients on the second stream."""
-    block, x0, dy, (ref, xr, yr, closest) = make_case(pkg, 'bottleneck', 256, 64, 1, 1, 4, 16, False, want_clean=True)
+    block, x0, dy, (ref, xr, yr, closest) = make_case(pkg, 'bottleneck', 512, 128, 1, 1, 4, 16, False, want_clean=True)
     opt = pkg.optim.FlatAdam(list(block.named_parameters()), lr=1e-3)
     res = []
     for fused in (False, True):
