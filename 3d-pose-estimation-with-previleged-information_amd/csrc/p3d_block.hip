@@ -363,6 +363,7 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         FxFuse f{};
         f.pro_tab = (fused && !ds && i > 0) ? io->table[i - 1] : nullptr;
         f.partial = partial;
+        f.wimg = io->wimg[i];
         {
             ProfScope ps(0, d, st);
             fx_count(0, d);
@@ -460,6 +461,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         p3d_conv_desc dd = *d;
         FxFuse f{};
         const float* dy = gi;                                                 // what the conv kernels read as "dy"
+        f.wimg = io->wimgT[i];
         if (fused) { f.pro_tab = io->table[i]; f.pro_c = io->c[i]; f.pro_masked = (i != last); }
         else if (i == last) { bwd_apply(gi, i, io->dcl, 0); dy = io->dcl; }
         else { bwd_apply(gi, i, io->da[i], 1); dy = io->da[i]; }              // in place: da[i] now holds d c_i
@@ -519,6 +521,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     if (b->has_downsample) {
         const p3d_conv_desc* d = &b->conv[3];
         FxFuse f{};
+        f.wimg = io->wimgT[3];
         const float* dy = g;
         if (fused) { f.pro_tab = io->table[3]; f.pro_c = io->c[3]; f.pro_masked = 0; }
         else {
@@ -536,6 +539,20 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         }
     }
     return check_launch("block_bwd");
+}
+
+// Pre-split weight images (csrc/p3d_fx.hip): three bf16 pieces of every weight, laid out as the conv kernels' LDS tiles, one image for the forward pass
+// (rows = output channels) and one for the data gradient (rows = input channels).  Rebuilt by the caller whenever the weight changes.
+int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_bytes, size_t* bwd_bytes) {
+    P3D_REQUIRE(K > 0 && C > 0 && RS > 0 && C % 16 == 0 && K % 16 == 0, "weight_image_bytes: channel counts must be positive multiples of 16 (K=%d C=%d)", K, C);
+    if (fwd_bytes) *fwd_bytes = fx_weight_image_bytes(K, C, RS, false);
+    if (bwd_bytes) *bwd_bytes = fx_weight_image_bytes(K, C, RS, true);
+    return P3D_OK;
+}
+
+int32_t p3d_fx_weight_images(const float* w, int32_t K, int32_t C, int32_t RS, void* img_fwd, void* img_bwd, void* stream) {
+    P3D_REQUIRE(w && img_fwd && img_bwd && K > 0 && C > 0 && RS > 0 && C % 16 == 0 && K % 16 == 0, "weight_images: bad argument");
+    return fx_build_weight_images(w, K, C, RS, img_fwd, img_bwd, (hipStream_t)stream);
 }
 
 // ---- profile of the conv launches made by the executor (and by p3d_conv2d_* when enabled) ---------------------------------------------------------

@@ -12,6 +12,7 @@ struct FxConvParams {
     const float* X;         // activation operand: x (FWD) or dy / the upstream gradient g (DGRAD), [N][Cred][Hi][Wi]
     const float* X2;        // PRO 2 / 3: the raw conv output c the BatchNorm backward needs beside g, same layout as X
     const float* W;         // weight operand (see fx_conv_kernel)
+    const unsigned char* Wimg;      // WMODE 2: pre-split weight image
     float* Y;               // result [N][M][YH][YW], or the split-K slabs
     const float* bias;      // [M] or null
     const float* tab;       // PRO constants per reduction channel
@@ -55,6 +56,7 @@ struct FxFuse {
     float* partial;         // FWD: partial sums of y, y^2;  DGRAD: partial sums of g, g * ep_c
     const float* ep_c;      // DGRAD epilogue: raw conv output laid out like dx
     const float* ep_tab;    // DGRAD epilogue: table of the BN ep_c went through
+    const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: split the fp32 weights on the fly
 };
 constexpr int FX_TAB = 8;   // floats per channel of a table
 
@@ -88,6 +90,8 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
                       hipStream_t st);
 // p3d_conv.hip: fold the split slabs and write (or add) the weight gradient in the weight's own [K][C][R][S] layout
 int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm, float* dw, hipStream_t st);
+size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd);
+int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st);
 int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, const FxFuse* fuse, hipStream_t st);
 
 }  // namespace p3d

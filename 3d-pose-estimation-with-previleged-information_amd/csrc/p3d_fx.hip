@@ -38,6 +38,7 @@ using f32x2 = float __attribute__((ext_vector_type(2)));
 using u32x2 = unsigned __attribute__((ext_vector_type(2)));
 using s4t = short __attribute__((ext_vector_type(4)));
 using s8v = short __attribute__((ext_vector_type(8)));
+using i32x4 = int __attribute__((ext_vector_type(4)));
 
 constexpr int FX_BM = 128, FX_BN = 128, FX_BK = 16;
 constexpr int FX_PIECE = 128 * FX_BK * 2;          // bytes of one bf16 piece of one operand tile (128 rows or columns x 16 k)
@@ -93,16 +94,34 @@ __device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int
 // ------------------------------------------------------------------------------------------------------------------------------------------
 // FWD / DGRAD
 // ------------------------------------------------------------------------------------------------------------------------------------------
-// WM = false: weight element (m, k) of tap t at W[t * w_ts + m * w_ld + k]   (forward: [K][C] or the tap-major image [tap][K][C])
-// WM = true : weight element (k, m) of tap t at W[t * w_ts + k * w_ld + m]   (dgrad:   [K][C] or [tap][K][C], m = input channel)
+// WMODE 0: weight element (m, k) of tap t at W[t * w_ts + m * w_ld + k]   (forward: [K][C] or the tap-major image [tap][K][C])
+// WMODE 1: weight element (k, m) of tap t at W[t * w_ts + k * w_ld + m]   (dgrad:   [K][C] or [tap][K][C], m = input channel)
+// WMODE 2: pre-split weight image (fx_weight_images_kernel): per (tap, channel tile, K step) the 12 KB that Cs holds for that step -- three bf16 pieces of
+//          128 rows x 16 k in the reduction-contiguous LDS layout -- so the weight operand costs three 16-B copies per thread and K step and no VALU work
 // Every BatchNorm layer owns one table of 8 floats per channel: {sc, sh, mean, invstd, A, B, K, 0} (sc = gamma * invstd, sh = beta - mean * sc: written
 // by the forward finalize; A, B, K: the backward map d c = A * g + B * c + K, written by the backward finalize).
 // PRO: 0 none; 1 relu(x * sc + sh) per reduction channel; 2 A * (mask ? g : 0) + B * c + K per reduction channel with mask = (c * sc + sh > 0)
 //      (X = g, X2 = c); 3 the same without the mask (A * g + B * c + K)
 // EPI: 0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2; 2 store + partial sums of g, g * (c2 - mean) with g = y * [c2 * sc + sh > 0]
 //      (ep_c = c2 laid out like the output, ep_tab = its BatchNorm's table); under split-K the epilogue work is done by fx_reduce_kernel instead
-template <bool WM, int PRO, int EPI>
+// Operand fetches are buffer loads against block-uniform resources: per-thread byte offsets change only when the filter tap changes (they carry the
+// out-of-range bit 0x80000000 for padding pixels / rows beyond the tensor, which the resource's range check turns into zeros), the per-K-step part of an
+// address is a wave-uniform scalar offset.  So a K step's fetch is loads only: no branches, no per-step address arithmetic.
+constexpr int FX_OOB = (int)0x80000000;
+__device__ f32x4 fx_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ i32x4 fx_buffer_load_i32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+__device__ float fx_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ __forceinline__ i32x4 fx_rsrc(const void* base, size_t bytes) {
+    const unsigned n = bytes < (size_t)0x80000000u ? (unsigned)bytes : 0x80000000u;
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    i32x4 r;
+    r[0] = (int)(unsigned)a; r[1] = (int)((a >> 32) & 0xffff); r[2] = (int)n; r[3] = 0x00020000;
+    return r;
+}
+
+template <int WMODE, int PRO, int EPI>
 __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
+    constexpr bool WM = WMODE == 1;
     __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * 3 * FX_PIECE];      // pixel (activation) operand, double buffered
     __shared__ __attribute__((aligned(16))) unsigned char Cs[2 * 3 * FX_PIECE];      // channel (weight) operand
     __shared__ float red[2][2][128];                                                   // EPI 1 / 2: [wave along pixels][sum kind][channel]
@@ -116,6 +135,7 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
     const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
     const int m0 = tile_m * FX_BM, n0 = tile_n * FX_BN;
     const int OHW = p.OH * p.OW;
+    const int HWi = p.Hi * p.Wi;
 
     // ---- staging maps ----
     const int nrow = t >> 2, nkq = t & 3;          // reduction-contiguous operand: rows nrow, nrow + 64; floats 4 nkq .. 4 nkq + 3 of the K step
@@ -123,17 +143,20 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
     // this thread's four consecutive output pixels (one output row: OW % 4 == 0)
     const int col = n0 + 4 * tp4;
     const bool col_ok = col < p.NP;
-    int pn = 0, hbase = 0, wbase = 0;
+    const int nfirst = n0 / OHW;                   // first image this block touches: base of the activation resources
+    int hbase = 0, wbase = 0, img_off = 0;
     {
         const int cc = col_ok ? col : 0;
-        pn = cc / OHW;
+        const int pn = cc / OHW;
         const int rem = cc - pn * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
         hbase = oh * p.hmul + p.hoff;
         wbase = ow * p.wmul + p.woff;
+        img_off = ((pn - nfirst) * p.Cred + trow) * HWi;
     }
-    const float* xb = p.X + (size_t)pn * p.Cred * p.Hi * p.Wi;
-    const float* x2b = (PRO >= 2) ? p.X2 + (size_t)pn * p.Cred * p.Hi * p.Wi : nullptr;
-    const int HWi = p.Hi * p.Wi;
+    const size_t act_left = (size_t)(p.N - nfirst) * p.Cred * HWi * sizeof(float);
+    const i32x4 rX = fx_rsrc(p.X + (size_t)nfirst * p.Cred * HWi, act_left);
+    const i32x4 rX2 = fx_rsrc(PRO >= 2 ? p.X2 + (size_t)nfirst * p.Cred * HWi : nullptr, PRO >= 2 ? act_left : 0);
+    const i32x4 rT = fx_rsrc(PRO >= 1 ? p.tab : nullptr, PRO >= 1 ? (size_t)p.Cred * FX_TAB * sizeof(float) : 0);
     const int csteps = p.Cred / FX_BK;
     int nk = p.ntap * csteps, kt0 = 0;
     if (p.kchunk > 0) {                            // split-K: this block reduces K steps [kt0, kt0 + nk) into slab blockIdx.y
@@ -142,71 +165,118 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
     }
     int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
 
-    f32x4 rw[2], rx[2], rx2[2];
-    f32x4 rtab[2][2];                              // PRO constants of this thread's two reduction rows
-    bool rvalid[2][4];
-    auto fetch = [&]() {
-        const int ir = f_tap / p.nS, is = f_tap - ir * p.nS;
+    // weight operand
+    i32x4 rW;
+    int w_voff[3] = {0, 0, 0};                     // WMODE 0 / 1: two rows (index 0, 1); WMODE 2: three 16-B chunks of the K step's 12 KB image tile
+    if constexpr (WMODE == 2) {
+        const size_t img_bytes = (size_t)p.R * p.S * p.tiles_m * csteps * (3 * FX_PIECE);
+        rW = fx_rsrc(p.Wimg, img_bytes);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w_voff[j] = 16 * (t + 256 * j);
+    } else if constexpr (WMODE == 1) {
+        rW = fx_rsrc(p.W, ((size_t)p.R * p.S * (p.w_ts ? p.w_ts : 0) + (size_t)p.Cred * p.w_ld) * sizeof(float));
+        const int m = m0 + 4 * tp4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_voff[i] = (m < p.M) ? ((trow + 8 * i) * p.w_ld + m) * 4 : FX_OOB;
+    } else {
+        rW = fx_rsrc(p.W, ((size_t)p.R * p.S * (p.w_ts ? p.w_ts : 0) + (size_t)p.M * p.w_ld) * sizeof(float));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int m = m0 + nrow + 64 * i; w_voff[i] = (m < p.M) ? (m * p.w_ld + 4 * nkq) * 4 : FX_OOB; }
+    }
+
+    // per-tap state of the activation gather (recomputed only when the tap changes)
+    int x_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};     // byte offsets of this thread's four pixels in reduction row `trow` of chunk 0 (| out-of-range bit)
+    bool x_vec = false;
+    int w_tapoff = 0;                                      // scalar byte offset of the tap inside the weight operand
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        cur_tap = tap;
+        const int ir = tap / p.nS, is = tap - ir * p.nS;
         const int wtap = (p.r0 + p.rstep * ir) * p.S + p.s0 + p.sstep * is;
-        const float* wt = p.W + (size_t)wtap * p.w_ts;
+        if constexpr (WMODE == 2) w_tapoff = (wtap * p.tiles_m + tile_m) * csteps * (3 * FX_PIECE);
+        else w_tapoff = (int)(wtap * p.w_ts * sizeof(float));
         const int hi = hbase + ir * p.hstep, wshift = is * p.wstep, wi0 = wbase + wshift;
         const bool row_ok = col_ok && (unsigned)hi < (unsigned)p.Hi;
-        const bool vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;       // wave-uniform: the four pixels are one aligned 16-B group, in or out together
+        x_vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;        // wave-uniform: the four pixels are one aligned 16-B group, in or out together
+        const int base = (img_off + hi * p.Wi + wi0) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
+            x_voff[e] = ok ? base + e * p.wmul * 4 : FX_OOB;
+        }
+    };
+
+    f32x4 rw[2], rx[2], rx2[2];
+    i32x4 rwi[3];                                  // WMODE 2: this thread's three 16-B chunks of the K step's weight image
+    f32x4 rtab[2][2];                              // PRO constants of this thread's two reduction rows
+    int rvoff[4];                                  // validity of the fetched pixels (the offsets they were fetched with): staged as zeros after a PRO map
+    auto fetch = [&]() {
+        if (f_tap != cur_tap) { asm volatile("" ::: "memory"); set_tap(f_tap); }       // (a real, wave-uniform branch: taken once per tap, not if-converted into every K step)
+        if constexpr (WMODE == 2) {
+            const int so = w_tapoff + (f_k >> 4) * (3 * FX_PIECE);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], so, 0);
+        } else if constexpr (WMODE == 1) {
+            const int so = w_tapoff + f_k * p.w_ld * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], so, 0);
+        } else {
+            const int so = w_tapoff + f_k * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], so, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (WM) {
-                const int m = m0 + 4 * tp4;
-                rw[i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(wt + (size_t)(f_k + trow + 8 * i) * p.w_ld + m) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                const int m = m0 + nrow + 64 * i;
-                rw[i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(wt + (size_t)m * p.w_ld + f_k + 4 * nkq) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            const int krow = f_k + trow + 8 * i;
-            const int off = krow * HWi + hi * p.Wi + wi0;
-            if (vec) {
-                const bool ok = row_ok && (unsigned)wi0 < (unsigned)p.Wi;
-                rx[i] = ok ? *reinterpret_cast<const f32x4*>(xb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (PRO >= 2) rx2[i] = ok ? *reinterpret_cast<const f32x4*>(x2b + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rvalid[i][e] = ok;
+            const int so = (f_k + 8 * i) * HWi * 4;                 // wave-uniform: reduction chunk + this pass's 8-row step
+            if (x_vec) {
+                rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], so, 0);
+                if constexpr (PRO >= 2) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], so, 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
-                    rx[i][e] = ok ? xb[off + e * p.wmul] : 0.f;
-                    if constexpr (PRO >= 2) rx2[i][e] = ok ? x2b[off + e * p.wmul] : 0.f;
-                    rvalid[i][e] = ok;
+                    rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], so, 0);
+                    if constexpr (PRO >= 2) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], so, 0);
                 }
             }
-            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = *reinterpret_cast<const f32x4*>(p.tab + 8 * krow);           // {sc, sh, mean, invstd}
-            if constexpr (PRO >= 2) rtab[i][0] = *reinterpret_cast<const f32x4*>(p.tab + 8 * krow + 4);                  // {A, B, K, 0}
+            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = fx_buffer_load_f32x4(rT, trow * 32, (f_k + 8 * i) * 32, 0);           // {sc, sh, mean, invstd}
+            if constexpr (PRO >= 2) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, (f_k + 8 * i) * 32, 0);                // {A, B, K, 0}
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rvoff[e] = x_vec ? x_voff[0] : x_voff[e];
         f_k += FX_BK;
         if (f_k == p.Cred) { f_k = 0; ++f_tap; }
     };
+    // LDS addresses of this thread's staging stores and of this lane's fragment reads, relative to a buffer's first piece
+    const int st_p[2] = {fx_tr_off(trow, tp4 >> 1) + 8 * (tp4 & 1), fx_tr_off(trow + 8, tp4 >> 1) + 8 * (tp4 & 1)};
+    const int st_c[2] = {WM ? st_p[0] : fx_rc_off(nrow, nkq >> 1) + 8 * (nkq & 1), WM ? st_p[1] : fx_rc_off(nrow + 64, nkq >> 1) + 8 * (nkq & 1)};
     auto stage = [&](int buf) {
+        unsigned char* pb = Ps + buf * 3 * FX_PIECE;
+        unsigned char* cb = Cs + buf * 3 * FX_PIECE;
+        if constexpr (WMODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4*>(cb + 16 * (t + 256 * j)) = rwi[j];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (WM) fx_split_store(Cs + buf * 3 * FX_PIECE + fx_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), rw[i]);
-            else fx_split_store(Cs + buf * 3 * FX_PIECE + fx_rc_off(nrow + 64 * i, nkq >> 1) + 8 * (nkq & 1), rw[i]);
+            if constexpr (WMODE != 2) fx_split_store(cb + st_c[i], rw[i]);
             f32x4 v = rx[i];
             if constexpr (PRO == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rvalid[i][e] ? fmaxf(fmaf(rx[i][e], rtab[i][1][0], rtab[i][1][1]), 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = rvoff[e] >= 0 ? fmaxf(fmaf(rx[i][e], rtab[i][1][0], rtab[i][1][1]), 0.f) : 0.f;
             }
             if constexpr (PRO == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float c = rx2[i][e];
                     const float g = fmaf(c, rtab[i][1][0], rtab[i][1][1]) > 0.f ? rx[i][e] : 0.f;
-                    v[e] = rvalid[i][e] ? fmaf(rtab[i][0][0], g, fmaf(rtab[i][0][1], c, rtab[i][0][2])) : 0.f;
+                    v[e] = rvoff[e] >= 0 ? fmaf(rtab[i][0][0], g, fmaf(rtab[i][0][1], c, rtab[i][0][2])) : 0.f;
                 }
             }
             if constexpr (PRO == 3) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rvalid[i][e] ? fmaf(rtab[i][0][0], rx[i][e], fmaf(rtab[i][0][1], rx2[i][e], rtab[i][0][2])) : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = rvoff[e] >= 0 ? fmaf(rtab[i][0][0], rx[i][e], fmaf(rtab[i][0][1], rx2[i][e], rtab[i][0][2])) : 0.f;
             }
-            fx_split_store(Ps + buf * 3 * FX_PIECE + fx_tr_off(trow + 8 * i, tp4 >> 1) + 8 * (tp4 & 1), v);
+            fx_split_store(pb + st_p[i], v);
         }
     };
 
@@ -218,6 +288,29 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
+    // fragment read offsets (see fx_tr_frag): two transposing 8-B reads per pixel fragment, one 16-B read per reduction-contiguous weight fragment
+    int rd_p[2][2], rd_c[2][2];
+    {
+        const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = 8 * (g >> 1) + 4 * half + q;
+                rd_p[a][half] = fx_tr_off(row, ((wn * 64 + a * 32 + 16 * (g & 1)) >> 3) + (pq >> 1)) + 8 * (pq & 1);
+                rd_c[a][half] = WM ? fx_tr_off(row, ((wm * 64 + a * 32 + 16 * (g & 1)) >> 3) + (pq >> 1)) + 8 * (pq & 1) : fx_rc_off(wm * 64 + a * 32 + fr, fh);
+            }
+    }
+    auto tr_read = [&](const unsigned char* base, const int (&off)[2]) {
+        s8v v;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)(base + off[half]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
+        }
+        return __builtin_bit_cast(bf8, v);
+    };
     if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -228,9 +321,9 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                pf[pc][a] = fx_tr_frag(Ps + (buf * 3 + pc) * FX_PIECE, wn * 64 + a * 32, lane);
-                if (WM) cf[pc][a] = fx_tr_frag(Cs + (buf * 3 + pc) * FX_PIECE, wm * 64 + a * 32, lane);
-                else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wm * 64 + a * 32 + fr, fh));
+                pf[pc][a] = tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
+                if (WM) cf[pc][a] = tr_read(Cs + (buf * 3 + pc) * FX_PIECE, rd_c[a]);
+                else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a][0]);
             }
         P3D_FX_PRODUCTS(acc, pf, cf)
         if (kt + 1 < nk) stage(buf ^ 1);
@@ -397,34 +490,55 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
             if (b_ok[i]) btab[i] = *reinterpret_cast<const f32x4*>(p.btab + 8 * (n0 + row + 64 * i));
         }
     }
+    // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
+    // pixel position of the K step in a wave-uniform scalar offset.  (fx_common bounds every tensor below 2^31 elements; the resources are cut to 2 GiB.)
+    const i32x4 rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
+    const i32x4 rA2 = fx_rsrc(PA >= 2 ? p.DY2 : nullptr, PA >= 2 ? (size_t)p.N * p.K * OHW * sizeof(float) : 0);
+    const i32x4 rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_voff[i] = a_ok[i] ? ((m0 + row + 64 * i) * OHW + 4 * kq) * 4 : FX_OOB;
+    const bool simple = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the input pixel IS the output pixel
     const bool vec = p.stride == 1 && (dw & 3) == 0;        // uniform: the four input pixels are one aligned 16-B group, in or out together
+    const int b_row = (n0 + row) * HWi;
     f32x4 ra[2], ra2[2], rb[2];
-    bool bvalid[4];
+    int b_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};
     int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
     auto fetch = [&]() {
-        const int pp = f_p + 4 * kq;
-        const size_t aoff = ((size_t)f_img * p.K + m0 + row) * OHW + pp;
-        const int oh = pp / p.OW, ow = pp - oh * p.OW;
-        const int hi = oh * p.stride + dh, wi0 = ow * p.stride + dw;
-        const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
-        const size_t boff = ((size_t)f_img * p.C + n0 + row) * HWi + hi * p.Wi + wi0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bvalid[e] = row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi;
+        const int a_so = (f_img * p.K * OHW + f_p) * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.DY + aoff + (size_t)i * 64 * OHW) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (PA >= 2) ra2[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p.DY2 + aoff + (size_t)i * 64 * OHW) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* src = p.X + boff + (size_t)i * 64 * HWi;
-            if (vec) {
-                rb[i] = (b_ok[i] && bvalid[0]) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
+            ra[i] = fx_buffer_load_f32x4(rA, a_voff[i], a_so, 0);
+            if constexpr (PA >= 2) ra2[i] = fx_buffer_load_f32x4(rA2, a_voff[i], a_so, 0);
+        }
+        int b_so = f_img * p.C * HWi * 4;
+        if (simple) {
+            b_so += f_p * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = (b_ok[i] && bvalid[e]) ? src[e * p.stride] : 0.f;
+            for (int e = 0; e < 4; ++e) b_voff[e] = (b_row + 4 * kq + e) * 4;
+        } else {
+            const int pp = f_p + 4 * kq;
+            const int oh = pp / p.OW, ow = pp - oh * p.OW;
+            const int hi = oh * p.stride + dh, wi0 = ow * p.stride + dw;
+            const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
+            const int base = (b_row + hi * p.Wi + wi0) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b_voff[e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int so = b_so + i * 64 * HWi * 4;
+            const int rowbad = b_ok[i] ? 0 : FX_OOB;
+            if (vec) rb[i] = fx_buffer_load_f32x4(rB, b_voff[0] | rowbad, so, 0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = fx_buffer_load_f32(rB, b_voff[e] | rowbad, so, 0);
             }
         }
         f_p += FX_BK;
         if (f_p == OHW) { f_p = 0; ++f_img; }
     };
+    const int st_off[2] = {fx_rc_off(row, kq >> 1) + 8 * (kq & 1), fx_rc_off(row + 64, kq >> 1) + 8 * (kq & 1)};
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -443,10 +557,10 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
             }
             if constexpr (PB == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && bvalid[e]) ? fmaxf(fmaf(rb[i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && (vec ? b_voff[0] : b_voff[e]) >= 0) ? fmaxf(fmaf(rb[i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
             }
-            fx_split_store(As + buf * 3 * FX_PIECE + fx_rc_off(row + 64 * i, kq >> 1) + 8 * (kq & 1), va);
-            fx_split_store(Bs + buf * 3 * FX_PIECE + fx_rc_off(row + 64 * i, kq >> 1) + 8 * (kq & 1), vb);
+            fx_split_store(As + buf * 3 * FX_PIECE + st_off[i], va);
+            fx_split_store(Bs + buf * 3 * FX_PIECE + st_off[i], vb);
         }
     };
     f32x16 acc[2][2];
@@ -457,6 +571,7 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
+    const int rd_a[2] = {fx_rc_off(wm * 64 + fr, fh), fx_rc_off(wm * 64 + 32 + fr, fh)}, rd_b[2] = {fx_rc_off(wn * 64 + fr, fh), fx_rc_off(wn * 64 + 32 + fr, fh)};
     if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -467,8 +582,8 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wm * 64 + a * 32 + fr, fh));
-                bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + fx_rc_off(wn * 64 + a * 32 + fr, fh));
+                af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a]);
+                bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a]);
             }
         P3D_FX_PRODUCTS(acc, af, bf)
         if (kt + 1 < nk) stage(buf ^ 1);
@@ -533,6 +648,7 @@ bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m) {
     return d->H % 2 == 0 && d->W % 8 == 0 && d->pad == d->dil * (d->R - 1) / 2 && (d->R == 1 || d->dil == 1);      // stride 2: classes of equal size
 }
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
+    if ((int64_t)d->N * d->C * d->H * d->W >= (1ll << 29) || (int64_t)d->N * d->K * d->Ho * d->Wo >= (1ll << 29)) return false;      // 32-bit byte offsets into whole tensors
     return fx_common(d) && d->K >= fx_min_m(min_m) && d->C >= fx_min_m(min_m) && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
 }
 
@@ -583,11 +699,60 @@ __global__ __launch_bounds__(256) void fx_weight_tapmajor_kernel(const float* __
         for (int tap = 0; tap < RS; ++tap) wT[(size_t)tap * KC + i] = w[i * RS + tap];
 }
 
-template <bool WM>
+// Pre-split weight images of one conv weight w [K][C][R*S] (fp32): blockIdx.y = 0 the forward image (rows = output channels, reduction = input channels),
+// 1 the data-gradient image (rows = input channels, reduction = output channels).  One thread per 16-B chunk position (tap, row tile, K step, row, half):
+// eight fp32 weights -> three bf16 pieces, written where fx_conv_kernel<2, ..>'s linear 12 KB copy wants them.
+__global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __restrict__ w, unsigned char* __restrict__ img_fwd, unsigned char* __restrict__ img_bwd, int K,
+                                                               int C, int RS) {
+    const bool bwd = blockIdx.y == 1;
+    const int rows = bwd ? C : K, red = bwd ? K : C;
+    const int tiles = (rows + 127) / 128, ksteps = red / FX_BK;
+    const size_t total = (size_t)RS * tiles * ksteps * 256;
+    unsigned char* img = bwd ? img_bwd : img_fwd;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int half = (int)(i & 1), row = (int)((i >> 1) & 127);
+        size_t j = i >> 8;
+        const int ks = (int)(j % ksteps); j /= ksteps;
+        const int tm = (int)(j % tiles);
+        const int tap = (int)(j / tiles);
+        const int m = tm * 128 + row, k0 = ks * FX_BK + half * 8;
+        unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = 0.f;
+            if (m < rows) x = bwd ? w[((size_t)(k0 + e) * C + m) * RS + tap] : w[((size_t)m * C + k0 + e) * RS + tap];
+            const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+            const float r1 = x - __builtin_bit_cast(float, hb);
+            const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, mb);
+            hi[e] = hb; mid[e] = mb; lo[e] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+        }
+        unsigned char* dst = img + (((size_t)tap * tiles + tm) * ksteps + ks) * (3 * FX_PIECE) + fx_rc_off(row, half);
+        *reinterpret_cast<i32x4*>(dst) = i32x4{(int)((hi[0] >> 16) | hi[1]), (int)((hi[2] >> 16) | hi[3]), (int)((hi[4] >> 16) | hi[5]), (int)((hi[6] >> 16) | hi[7])};
+        *reinterpret_cast<i32x4*>(dst + FX_PIECE) = i32x4{(int)((mid[0] >> 16) | mid[1]), (int)((mid[2] >> 16) | mid[3]), (int)((mid[4] >> 16) | mid[5]), (int)((mid[6] >> 16) | mid[7])};
+        *reinterpret_cast<i32x4*>(dst + 2 * FX_PIECE) = i32x4{(int)((lo[0] >> 16) | lo[1]), (int)((lo[2] >> 16) | lo[3]), (int)((lo[4] >> 16) | lo[5]), (int)((lo[6] >> 16) | lo[7])};
+    }
+}
+
+size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd) {
+    const int rows = bwd ? C : K, red = bwd ? K : C;
+    return (size_t)RS * ((rows + 127) / 128) * (red / FX_BK) * (3 * FX_PIECE);
+}
+
+int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st) {
+    const size_t a = fx_weight_image_bytes(K, C, RS, false) / 48, b = fx_weight_image_bytes(K, C, RS, true) / 48;        // chunk positions (3 chunks each)
+    const size_t total = a > b ? a : b;
+    const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 4096 ? ceil_div((int64_t)total, 256) : 4096);
+    hipLaunchKernelGGL(fx_weight_images_kernel, dim3(blocks, 2), dim3(256), 0, st, w, (unsigned char*)img_fwd, (unsigned char*)img_bwd, K, C, RS);
+    return check_launch("fx_build_weight_images");
+}
+
+template <int WMODE>
 static void fx_launch_conv(const FxConvParams& p, int pro, int epi, dim3 grid, hipStream_t st) {
-#define P3D_FX_CASE(PRO, EPI) if (pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<WM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
-    if constexpr (!WM) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) }
-    else { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
+#define P3D_FX_CASE(PRO, EPI) if (pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<WMODE, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
+    if constexpr (WMODE == 0) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) }
+    else if constexpr (WMODE == 1) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
+    else { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(0, 2) }       // image mode: the block executor's default (BatchNorm apply as passes of its own)
 #undef P3D_FX_CASE
 }
 
@@ -601,6 +766,7 @@ static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* sl
 // y = conv(pro(x), w) (+ bias); fuse may be null (plain convolution)
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st) {
+    const void* wimg = (fuse && !fuse->pro_tab) ? fuse->wimg : nullptr;
     const size_t need = fx_fwd_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
@@ -612,7 +778,8 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     p.accumulate = d->accumulate;
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
-    if (RS > 1) {
+    if (wimg) { p.Wimg = (const unsigned char*)wimg; if (RS > 1) ws += fx_image_bytes(d); }
+    else if (RS > 1) {
         const int64_t kc = (int64_t)d->K * d->C;
         hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
         p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
@@ -628,11 +795,14 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     const FxSplit sp = fx_fwd_split(d);
     if (sp.splits > 1) {
         p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
-        fx_launch_conv<false>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        if (wimg) fx_launch_conv<2>(p, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        else fx_launch_conv<0>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
         fx_launch_reduce(epi, dim3((unsigned)d->K, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, y, bias, sp.splits, p.slab_stride, d->N, d->K,
                          d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial);
+    } else if (wimg) {
+        fx_launch_conv<2>(p, 0, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     } else {
-        fx_launch_conv<false>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+        fx_launch_conv<0>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     }
     return check_launch("fx_conv_fwd");
 }
@@ -640,6 +810,7 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
 // dx (=|+=) dgrad(pro(dy), w); strided: one launch per parity class of the input, written straight into dx
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,
                       hipStream_t st) {
+    const void* wimg = (fuse && !fuse->pro_tab) ? fuse->wimg : nullptr;
     const size_t need = fx_dgrad_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
@@ -650,7 +821,8 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     p.accumulate = d->accumulate;
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
-    if (RS > 1) {
+    if (wimg) { p.Wimg = (const unsigned char*)wimg; if (RS > 1) ws += fx_image_bytes(d); }
+    else if (RS > 1) {
         const int64_t kc = (int64_t)d->K * d->C;
         hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
         p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
@@ -670,11 +842,14 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         const FxSplit sp = fx_dgrad_split(d);
         if (sp.splits > 1) {
             p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
-            fx_launch_conv<true>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            if (wimg) fx_launch_conv<2>(p, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            else fx_launch_conv<1>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
             fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
                              d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
+        } else if (wimg) {
+            fx_launch_conv<2>(p, 0, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         } else {
-            fx_launch_conv<true>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+            fx_launch_conv<1>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         }
         return check_launch("fx_conv_dgrad");
     }
@@ -697,7 +872,8 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
             c.hoff = th >= 0 ? th / st2 : -((-th) / st2); c.hstep = -(c.rstep * d->dil) / st2;
             c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
             c.oy0 = ph; c.ox0 = pw;
-            fx_launch_conv<true>(c, pro, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            if (wimg) fx_launch_conv<2>(c, 0, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            else fx_launch_conv<1>(c, pro, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
         }
     (void)any_dead;      // classes no tap reaches keep what dx held: the caller zero-fills dx first unless it accumulates (p3d_conv2d_dgrad does)
     return check_launch("fx_conv_dgrad");

@@ -776,6 +776,7 @@ def set_x3(on):
 
 
 X3_EPOCH = 0
+WEIGHT_EPOCH = 0          # bumped by FlatAdam after every optimizer step: cached per-weight derivatives (ops_block.weight_images) are stale
 
 
 def profile_convs(on):

@@ -32,7 +32,7 @@ class BlockDesc(ctypes.Structure):
 
 class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
-    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
+    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcl', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
                 ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
 
@@ -82,6 +82,30 @@ class _Plan:
         self.table_rows = sum(ks)
 
 
+def weight_images(conv):
+    """(forward image, data-gradient image) of conv.weight as device byte tensors (p3d_fx_weight_images), rebuilt when the weight has changed:
+    in-place edits through torch bump weight._version; the optimizer kernels write through raw pointers, so FlatAdam bumps ops.WEIGHT_EPOCH."""
+    w = conv.weight
+    key = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+    cached = conv.__dict__.get('_fx_images')
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    k, c, r, s_ = w.shape
+    if cached is None:
+        fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().p3d_fx_weight_image_bytes(k, c, r * s_, ctypes.byref(fb), ctypes.byref(bb)), 'p3d_fx_weight_image_bytes')
+        fwd = torch.empty(fb.value, dtype=torch.uint8, device=w.device)
+        bwd = torch.empty(bb.value, dtype=torch.uint8, device=w.device)
+    else:
+        fwd, bwd = cached[1], cached[2]
+    check(lib().p3d_fx_weight_images(ops._p(w.detach()), k, c, r * s_, ops._p(fwd), ops._p(bwd), ops._stream()), 'p3d_fx_weight_images')
+    conv.__dict__['_fx_images'] = (key, fwd, bwd)
+    return fwd, bwd
+
+
+USE_WEIGHT_IMAGES = os.environ.get('P3D_WEIGHT_IMAGES', '1') != '0'
+
+
 def plan_for(block, x):
     cache = block.__dict__.setdefault('_blk_plans', {})
     key = (tuple(x.shape), ops.X3_EPOCH)
@@ -119,6 +143,8 @@ class ResidualBlockFn(torch.autograd.Function):
             c = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
             cs[slot] = c
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), c.data_ptr()
+            if USE_WEIGHT_IMAGES:
+                io.wimg[slot] = weight_images(conv)[0].data_ptr()
             if slot < plan.desc.nconv - 1:
                 acts[slot] = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
                 io.a[slot] = acts[slot].data_ptr()
@@ -159,6 +185,8 @@ class ResidualBlockFn(torch.autograd.Function):
         row = 0
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
+            if USE_WEIGHT_IMAGES:
+                io.wimgT[slot] = weight_images(conv)[1].data_ptr()
             if slot in acts:
                 io.a[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32

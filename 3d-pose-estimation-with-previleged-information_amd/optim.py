@@ -94,6 +94,7 @@ class FlatAdam:
         if skip_nonfinite and not math.isfinite(float(self.norm_sq.item())):
             return False
         self.step_count += 1
+        ops.WEIGHT_EPOCH += 1
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, max_norm or 0.0,
                       self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
@@ -107,6 +108,7 @@ class FlatAdam:
             self._dev_scratch = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
         self._check_all_touched()
         self.norm_sq.zero_()
+        ops.WEIGHT_EPOCH += 1
         ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
         ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0], self.betas[1],
                           self.eps, self.weight_decay, self.dev_state, max_norm or 0.0, self.norm_sq, grad_scale, skip_nonfinite, self._dev_scratch)

@@ -133,6 +133,8 @@ typedef struct p3d_block_io {
     const float* x;             /* block input  [N, C_in, H, W] */
     float* out;                 /* block output [N, K_last, Ho, Wo] */
     const float* w[4];
+    const void* wimg[4];        /* pre-split weight images (p3d_fx_weight_images) of w[i] for the forward pass / the data gradient, or NULL: the kernels split */
+    const void* wimgT[4];       /*   the fp32 weights on the fly.  The caller rebuilds an image whenever its weight changes. */
     float* c[4];
     float* a[4];                /* a[i] = relu(bn_i(c[i])), i < nconv-1: written by forward, read by backward (the x operand of conv i+1's weight gradient) */
     float* table[4];
@@ -158,6 +160,11 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 /* side_stream: NULL, or a second stream for the weight-gradient kernels (ordered by events inside the call; the caller joins the streams before it reads dw) */
 int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
                       void* stream, void* side_stream);
+
+/* Pre-split weight images for p3d_block_io.wimg / wimgT: every fp32 weight as three bf16 pieces (hi + mid + lo = w exactly), laid out as the 12 KB LDS tile
+ * each (filter tap, 128-channel tile, 16-deep K step) of the conv kernels consumes, so the weight operand costs the kernels no arithmetic.  w [K][C][R*S]. */
+int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_bytes, size_t* bwd_bytes);
+int32_t p3d_fx_weight_images(const float* w, int32_t K, int32_t C, int32_t RS, void* img_fwd, void* img_bwd, void* stream);
 
 /* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */

@@ -17,9 +17,9 @@ for i in (1,2,3):
     if not f: print('pass',i,'missing'); continue
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if 'igemm' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        if ('igemm' in r['Kernel_Name'] or 'fx_conv' in r['Kernel_Name'] or 'fx_wgrad' in r['Kernel_Name']): agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items(): print('%-28s %.4g'%(k,sum(v)/len(v)))
     tr=glob.glob('gpurun_out/pmcx_%d/*/*_kernel_trace.csv'%i)[0]
-    d=[(float(r['End_Timestamp'])-float(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(tr)) if 'igemm' in r['Kernel_Name']]
+    d=[(float(r['End_Timestamp'])-float(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(tr)) if ('igemm' in r['Kernel_Name'] or 'fx_conv' in r['Kernel_Name'] or 'fx_wgrad' in r['Kernel_Name'])]
     print('  us/launch %.1f (n=%d)'%(sum(d)/len(d),len(d)))
 PY
