@@ -884,8 +884,10 @@ bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 &&
 int fx_wgrad_splits(const p3d_conv_desc* d) {
     const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
-    int64_t splits = ceil_div(1024, tiles);
-    if (splits > total / 32) splits = total / 32;           // at least 32 K steps per block
+    static const int target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();      // tuning aid
+    static const int minsteps = [] { const char* e = getenv("P3D_FX_WGRAD_MINSTEPS"); return e ? atoi(e) : 32; }();
+    int64_t splits = ceil_div(target, tiles);
+    if (splits > total / minsteps) splits = total / minsteps;           // at least 32 K steps per block
     if (splits < 1) splits = 1;
     const int64_t spb = ceil_div(total, splits);
     return (int)ceil_div(total, spb);

@@ -15,12 +15,11 @@ from ._lib import ConvDesc, P3DError, check, lib
 
 _vp = ctypes.c_void_p
 
-# P3D_BLOCK_SIDE=1: weight-gradient kernels of the block executor on the second HIP stream (p3d_block_bwd orders them with events).  OFF by default:
-# with it on, the training step was no longer bitwise reproducible run to run -- isolated 32-B sectors of a data gradient differed when a conv's
-# dgrad ran beside the weight-gradient kernels of the same block, although the two streams share read-only operands only; workspaces, event flags,
-# launch order and the runtime's fence options were ruled out (tools/debug_det.py).  Until the cause is known the block path
-# keeps every kernel on the launch stream, where the step is bitwise reproducible; the per-layer path (ops.py) keeps its second stream.
-BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '0') == '1'
+# P3D_BLOCK_SIDE=0: keep the weight-gradient kernels of the block executor on the launch stream.  By default they run on the second HIP stream
+# (p3d_block_bwd orders them with events), as in the per-layer path.  History: with the BatchNorm folded into the operand fetch (P3D_BLOCK_FUSE=1) the
+# two-stream step was not bitwise reproducible run to run, so that mode is single-stream inside the library; the default mode is reproducible
+# (tests/test_step_gpu.py::test_training_is_bitwise_reproducible, tools/debug_det.py on ResNet-18 / -50 at batch 4 .. 64).
+BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '1') != '0'
 
 
 class BlockDesc(ctypes.Structure):

@@ -97,10 +97,11 @@ def test_legacy_resnet_forward(pkg):
     assert np.abs(z_mat[1, :, 7, 2] - g['z_mat_slice']).max() < 1e-3 * np.abs(g['z_mat_slice']).max()
 
 
-def test_training_is_bitwise_reproducible(pkg):
+@pytest.mark.parametrize('case', ['depth_r18_b2', 'depth_r50_b2'])
+def test_training_is_bitwise_reproducible(case, pkg):
     """Two runs of the same two steps give bit-identical parameters, BatchNorm statistics and loss: split-K slabs, BN partial sums and the
     gradient norm are combined in a fixed order (no floating-point atomics), and the second HIP stream only changes WHEN kernels run."""
-    g = np.load(golden_path('step_depth_r18_b2.npz'))
+    g = np.load(golden_path('step_%s.npz' % case))
     meta = json.loads(str(g['meta']))
     outs = []
     for run in range(2):
