@@ -43,8 +43,16 @@ using i32x4 = int __attribute__((ext_vector_type(4)));
 constexpr int FX_BM = 128, FX_BN = 128, FX_BK = 16;
 constexpr int FX_PIECE = 128 * FX_BK * 2;          // bytes of one bf16 piece of one operand tile (128 rows or columns x 16 k)
 
-// fp32 x4 -> three bf16 x4 pieces (hi, mid, lo) by mantissa truncation, written as 8-B chunks FX_PIECE apart
+// fp32 x4 -> three bf16 x4 pieces (hi, mid, lo), written as 8-B chunks FX_PIECE apart.  Each piece is the round-to-nearest-even bf16 of what is left
+// (v_cvt_pk_bf16_f32 converts and packs two values per instruction): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  Both subtractions are
+// exact in fp32 and the last remainder has at most 8 significant bits, so hi + mid + lo == x exactly, as with the truncating split (P3D_FX_TRUNC_SPLIT).
+using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned fx_pack2(float a, float b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
 __device__ __forceinline__ void fx_split_store(unsigned char* base, const f32x4 v) {
+#ifdef P3D_FX_TRUNC_SPLIT
     unsigned hi[4], mid[4], lo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -58,6 +66,21 @@ __device__ __forceinline__ void fx_split_store(unsigned char* base, const f32x4 
     *reinterpret_cast<u32x2*>(base) = u32x2{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
     *reinterpret_cast<u32x2*>(base + FX_PIECE) = u32x2{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
     *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
+#else
+    unsigned hp[2], mp[2], lp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = v[2 * q], x1 = v[2 * q + 1];
+        hp[q] = fx_pack2(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, hp[q] << 16), r1 = x1 - __builtin_bit_cast(float, hp[q] & 0xFFFF0000u);
+        mp[q] = fx_pack2(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, mp[q] << 16), s1 = r1 - __builtin_bit_cast(float, mp[q] & 0xFFFF0000u);
+        lp[q] = fx_pack2(s0, s1);
+    }
+    *reinterpret_cast<u32x2*>(base) = u32x2{hp[0], hp[1]};
+    *reinterpret_cast<u32x2*>(base + FX_PIECE) = u32x2{mp[0], mp[1]};
+    *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = u32x2{lp[0], lp[1]};
+#endif
 }
 
 // LDS images of one piece of one operand tile:

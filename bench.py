@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--augment', action='store_true', help='BASELINE config 5: colour + eraser augmentation and normalisation of a raw RGB batch on the GPU, inside the timed step')
     ap.add_argument('--half', action='store_true', help='informational: the -half_acc (fp16 NHWC) path; the contract line is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lean', action='store_true', help='profiling aid: only the warm-up and the timed steps (no fwd+bwd-only pass, no kernel pass, no fp32-MFMA pass); prints a reduced line')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-batch', type=int, default=64, help='batch of the CPU baseline sample (the bench config; 8 = the survey container\'s sample)')
     opt = ap.parse_args()
@@ -172,6 +173,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(loss)
+
+    if opt.lean:
+        if rank == 0:
+            print(json.dumps({'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU', 'value': round(opt.batch * world * opt.steps / elapsed, 2), 'unit': 'crops/s',
+                              'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # fwd + bwd only (the literal wording of BASELINE.json's metric; SURVEY 8(d) "also report fwd+bwd only"): the same steps with the
     # clip + Adam launches left out (the gradient all-reduce stays: it is part of a data-parallel backward).  Never `value`.
