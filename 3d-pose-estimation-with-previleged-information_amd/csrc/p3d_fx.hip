@@ -1,8 +1,8 @@
 // Convolution forward / data gradient / weight gradient as exact-fp32 implicit GEMMs on the bf16 matrix pipe of gfx950, with the
 // BatchNorm of the residual blocks folded into them (depthnet.py:40-56,96-116 and the twins in resnet.py / fusionnet.py).
 //
-// Arithmetic ("x3"): every fp32 operand value is cut, on its way into LDS, into three bf16 pieces by mantissa truncation (x = hi + mid + lo
-// exactly, 8 + 8 + 8 bits).  Per K = 16 step the six piece products that can exceed 2^-24 |a b| (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
+// Arithmetic ("x3"): every fp32 operand value is cut, on its way into LDS, into three bf16 pieces, each the round-to-nearest bf16 of what the previous ones
+// leave (x = hi + mid + lo exactly).  Per K = 16 step the six piece products that can exceed 2^-24 |a b| (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
 // are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first: fp32-grade results (measured error <= the fp32-MFMA kernel's)
 // at 192 matrix-pipe cycles per 32x32x16 block instead of the 512 of v_mfma_f32_32x32x2_f32.
 //
@@ -26,6 +26,7 @@
 //     dbeta and the table {A, B, K} of   d c = A * g + B * c + K   (the BatchNorm backward as an affine map per channel), which the producer's
 //     DGRAD and WGRAD apply when they stage their dy operand (PRO_BNBWD).
 // Only the block-closing BN (add + ReLU, its output is the next block's input) is a pass over HBM of its own (p3d_block.hip).
+#include <type_traits>
 #include "p3d_common.h"
 #include "p3d_fx.h"
 
@@ -52,7 +53,12 @@ __device__ __forceinline__ unsigned fx_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 __device__ __forceinline__ void fx_split_store(unsigned char* base, const f32x4 v) {
-#ifdef P3D_FX_TRUNC_SPLIT
+#if defined(P3D_FX_ABL_NOSPLIT)
+    const u32x2 raw = u32x2{__builtin_bit_cast(unsigned, (float)v[0]), __builtin_bit_cast(unsigned, (float)v[2])};
+    *reinterpret_cast<u32x2*>(base) = raw;
+    *reinterpret_cast<u32x2*>(base + FX_PIECE) = raw;
+    *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = raw;
+#elif defined(P3D_FX_TRUNC_SPLIT)
     unsigned hi[4], mid[4], lo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -107,12 +113,20 @@ __device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int
     return __builtin_bit_cast(bf8, v);
 }
 
-#define P3D_FX_PRODUCTS(ACC, PIX, CH)                                                                                   \
+// NA x NB of the wave's 2 x 2 sub-tiles (32 x 32 each) are computed: a wave whose rows reach beyond the tensor (272 = 2 x 128 + 16 regressor channels,
+// 64-channel layers in a 128-row tile) issues no MFMAs for the sub-tiles that hold nothing
+#define P3D_FX_PRODUCTS_AB(ACC, PIX, CH, NA, NB)                                                                        \
     _Pragma("unroll") for (int pa = 0; pa < 6; ++pa) {                                                                 \
         constexpr int PP[6] = {2, 0, 1, 1, 0, 0}, PC[6] = {0, 2, 1, 0, 1, 0};                                           \
-        _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                     \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                   \
             ACC[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIX[PP[pa]][a], CH[PC[pa]][b], ACC[a][b], 0, 0, 0);    \
     }
+#define P3D_FX_PRODUCTS(ACC, PIX, CH) P3D_FX_PRODUCTS_AB(ACC, PIX, CH, 2, 2)
+// wave-uniform count (0, 1, 2) of 32-row sub-tiles of the wave's 64 rows starting at `first` that begin below `limit`
+__device__ __forceinline__ int fx_live_subtiles(int first, int limit) {
+    const int n = (limit - first + 31) >> 5;
+    return __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > 2 ? 2 : n));
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
 // FWD / DGRAD
@@ -131,6 +145,13 @@ __device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int
 // out-of-range bit 0x80000000 for padding pixels / rows beyond the tensor, which the resource's range check turns into zeros), the per-K-step part of an
 // address is a wave-uniform scalar offset.  So a K step's fetch is loads only: no branches, no per-step address arithmetic.
 constexpr int FX_OOB = (int)0x80000000;
+// tuning ablations (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands),
+// P3D_FX_ABL_NOSPLIT stores the raw bits instead of the three pieces (no split arithmetic)
+#ifdef P3D_FX_ABL_NOLOAD
+#define FX_SO(x) 0
+#else
+#define FX_SO(x) (x)
+#endif
 __device__ f32x4 fx_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ i32x4 fx_buffer_load_i32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 __device__ float fx_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
@@ -143,7 +164,7 @@ __device__ __forceinline__ i32x4 fx_rsrc(const void* base, size_t bytes) {
 }
 
 template <int WMODE, int PRO, int EPI>
-__global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
+__global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     constexpr bool WM = WMODE == 1;
     __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * 3 * FX_PIECE];      // pixel (activation) operand, double buffered
     __shared__ __attribute__((aligned(16))) unsigned char Cs[2 * 3 * FX_PIECE];      // channel (weight) operand
@@ -238,31 +259,31 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
         if constexpr (WMODE == 2) {
             const int so = w_tapoff + (f_k >> 4) * (3 * FX_PIECE);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], so, 0);
+            for (int j = 0; j < 3; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], FX_SO(so), 0);
         } else if constexpr (WMODE == 1) {
             const int so = w_tapoff + f_k * p.w_ld * 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], so, 0);
+            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], FX_SO(so), 0);
         } else {
             const int so = w_tapoff + f_k * 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], so, 0);
+            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], FX_SO(so), 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int so = (f_k + 8 * i) * HWi * 4;                 // wave-uniform: reduction chunk + this pass's 8-row step
             if (x_vec) {
-                rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], so, 0);
-                if constexpr (PRO >= 2) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], so, 0);
+                rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], FX_SO(so), 0);
+                if constexpr (PRO >= 2) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], FX_SO(so), 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], so, 0);
-                    if constexpr (PRO >= 2) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], so, 0);
+                    rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], FX_SO(so), 0);
+                    if constexpr (PRO >= 2) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], FX_SO(so), 0);
                 }
             }
-            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = fx_buffer_load_f32x4(rT, trow * 32, (f_k + 8 * i) * 32, 0);           // {sc, sh, mean, invstd}
-            if constexpr (PRO >= 2) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, (f_k + 8 * i) * 32, 0);                // {A, B, K, 0}
+            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = fx_buffer_load_f32x4(rT, trow * 32, FX_SO((f_k + 8 * i) * 32), 0);           // {sc, sh, mean, invstd}
+            if constexpr (PRO >= 2) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, FX_SO((f_k + 8 * i) * 32), 0);                // {A, B, K, 0}
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) rvoff[e] = x_vec ? x_voff[0] : x_voff[e];
@@ -334,24 +355,36 @@ __global__ __launch_bounds__(256) void fx_conv_kernel(const FxConvParams p) {
         }
         return __builtin_bit_cast(bf8, v);
     };
+    const int live_b = fx_live_subtiles(m0 + wm * 64, p.M);       // channel sub-tiles of this wave that hold output channels
     if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch();
-        bf8 pf[3][2], cf[3][2];
+    // the K loop, once per count of live channel sub-tiles (a wave-uniform choice made outside the loop, so that each copy is the straight-line loop)
+    auto kloop = [&](auto nbt) {
+        constexpr int NB = decltype(nbt)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch();
+            if constexpr (NB > 0) {
+                bf8 pf[3][2], cf[3][2];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                pf[pc][a] = tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
-                if (WM) cf[pc][a] = tr_read(Cs + (buf * 3 + pc) * FX_PIECE, rd_c[a]);
-                else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a][0]);
+                    for (int a = 0; a < 2; ++a) {
+                        pf[pc][a] = tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
+                        if (a < NB) {
+                            if (WM) cf[pc][a] = tr_read(Cs + (buf * 3 + pc) * FX_PIECE, rd_c[a]);
+                            else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a][0]);
+                        }
+                    }
+                P3D_FX_PRODUCTS_AB(acc, pf, cf, 2, NB)
             }
-        P3D_FX_PRODUCTS(acc, pf, cf)
-        if (kt + 1 < nk) stage(buf ^ 1);
-        __syncthreads();
-    }
+            if (kt + 1 < nk) stage(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    if (live_b == 2) kloop(std::integral_constant<int, 2>{});
+    else if (live_b == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
 
     // ---- epilogue: lane = output channel (m), registers = pixels; acc[a][b][4 g + e] is pixel 32 a + 8 g + 4 fh + e of the wave's 64 ----
     const bool split = p.kchunk > 0;
@@ -484,7 +517,7 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // PA: 0 none; 2 / 3 the BatchNorm-backward map of fx_conv_kernel on dy (per row k: constants live in registers; DY2 = the raw conv output c)
 // PB: 0 none; 1 relu(x * sc + sh) per row c
 template <int PA, int PB>
-__global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
+__global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -527,18 +560,31 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
     f32x4 ra[2], ra2[2], rb[2];
     int b_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};
     int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
+    const bool rowwise = (p.OW & (FX_BK - 1)) == 0;        // uniform: a K step never straddles two output rows
+    int f_oh = f_p / p.OW, f_ow = f_p - f_oh * p.OW;       // rowwise: the step's output row and first column (scalars)
+    const int tw = 4 * kq * p.stride + dw;
     auto fetch = [&]() {
         const int a_so = (f_img * p.K * OHW + f_p) * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            ra[i] = fx_buffer_load_f32x4(rA, a_voff[i], a_so, 0);
-            if constexpr (PA >= 2) ra2[i] = fx_buffer_load_f32x4(rA2, a_voff[i], a_so, 0);
+            ra[i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
+            if constexpr (PA >= 2) ra2[i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
         }
         int b_so = f_img * p.C * HWi * 4;
         if (simple) {
             b_so += f_p * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) b_voff[e] = (b_row + 4 * kq + e) * 4;
+        } else if (rowwise) {
+            // the K step's 16 pixels lie in output row f_oh (a scalar, like everything that depends on the step): per thread, one add and one range check per pixel
+            const int hi = f_oh * p.stride + dh;
+            const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
+            const int wi0 = f_ow * p.stride + tw;
+            const int base = (b_row + hi * p.Wi + wi0) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b_voff[e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+            f_ow += FX_BK;
+            if (f_ow == p.OW) { f_ow = 0; ++f_oh; if (f_oh == p.OH) f_oh = 0; }
         } else {
             const int pp = f_p + 4 * kq;
             const int oh = pp / p.OW, ow = pp - oh * p.OW;
@@ -552,10 +598,10 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
         for (int i = 0; i < 2; ++i) {
             const int so = b_so + i * 64 * HWi * 4;
             const int rowbad = b_ok[i] ? 0 : FX_OOB;
-            if (vec) rb[i] = fx_buffer_load_f32x4(rB, b_voff[0] | rowbad, so, 0);
+            if (vec) rb[i] = fx_buffer_load_f32x4(rB, b_voff[0] | rowbad, FX_SO(so), 0);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = fx_buffer_load_f32(rB, b_voff[e] | rowbad, so, 0);
+                for (int e = 0; e < 4; ++e) rb[i][e] = fx_buffer_load_f32(rB, b_voff[e] | rowbad, FX_SO(so), 0);
             }
         }
         f_p += FX_BK;
@@ -595,23 +641,32 @@ __global__ __launch_bounds__(256) void fx_wgrad_kernel(const FxWgradParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
     const int rd_a[2] = {fx_rc_off(wm * 64 + fr, fh), fx_rc_off(wm * 64 + 32 + fr, fh)}, rd_b[2] = {fx_rc_off(wn * 64 + fr, fh), fx_rc_off(wn * 64 + 32 + fr, fh)};
+    const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
     if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch();
-        bf8 af[3][2], bf[3][2];
+    auto kloop = [&](auto nat) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles along k
+        constexpr int NA = decltype(nat)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch();
+            if constexpr (NA > 0) {
+                bf8 af[3][2], bf[3][2];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a]);
-                bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a]);
+                    for (int a = 0; a < 2; ++a) {
+                        if (a < NA) af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a]);
+                        bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a]);
+                    }
+                P3D_FX_PRODUCTS_AB(acc, af, bf, NA, 2)
             }
-        P3D_FX_PRODUCTS(acc, af, bf)
-        if (kt + 1 < nk) stage(buf ^ 1);
-        __syncthreads();
-    }
+            if (kt + 1 < nk) stage(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    if (live_a == 0 || live_b == 0) kloop(std::integral_constant<int, 0>{});
+    else if (live_a == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 2>{});
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
     const int RS = p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;

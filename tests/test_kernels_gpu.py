@@ -556,7 +556,8 @@ def test_x3_kernels_match_fp32_kernels(case, pkg):
     for i, ref, name in ((0, y_ref.detach(), 'fwd'), (1, xd.grad, 'dgrad'), (2, dw_ref, 'wgrad')):
         scale = ref.abs().max()
         e32, e3 = ((res[False][i] - ref).abs().max() / scale).item(), ((res[True][i] - ref).abs().max() / scale).item()
-        assert e3 < 3e-6 and e3 < 4 * e32 + 2e-7, (name, e32, e3)
+        # 4e-6 of the largest value: fp32 accumulation over the longest reduction here (128 x 5 x 5 = 3200 terms, six products each) stays below it
+        assert e3 < 4e-6 and e3 < 4 * e32 + 2e-7, (name, e32, e3)
         assert torch.equal(res[False][i], res[True][i]) != covered[i], name
 
 

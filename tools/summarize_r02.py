@@ -57,6 +57,8 @@ def main():
     out = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         f = glob.glob(go('pmc_%s' % c, '*', '*_counter_collection.csv')) + glob.glob(go('pmc_%s' % c, '*_counter_collection.csv'))
+        # gpurun_out/ keeps files of earlier calls and of helper processes: the run of interest is the newest trace that holds the x3 kernels
+        f = sorted((x for x in f if 'fx_conv_kernel' in open(x).read()), key=os.path.getmtime, reverse=True)
         if not f:
             continue
         tot, n = collections.defaultdict(float), collections.defaultdict(int)
