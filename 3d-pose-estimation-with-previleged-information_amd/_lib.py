@@ -75,6 +75,7 @@ SIGNATURES = {
     'p3d_augment_occlude': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_x3_enable': (_i32, [_i32]),
+    'p3d_fx_tune': (None, [_i32, _i32]),
     'p3d_conv_path_stats': (None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), _i32]),
     'p3d_reproject_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_enhance_depth': (_i32, [_ptr, _ptr, _i64, _f32, _i32, _ptr]),

@@ -19,7 +19,14 @@ constexpr int CLOSE_MAX_SPLIT = 64;
 constexpr int FIN_CH = 16, FIN_LANES = 16;      // finalize kernels: a 256-thread block sums 16 channels with 16 row lanes each
 // channel counts below 96 leave the 128-row tile of the x3 kernels too empty (64-channel layers measured 72-82 TF there against 88-99 TF on the fp32-MFMA
 // kernel, weight gradient 37 against 80): blocks with such layers (ResNet layer1) stay on the per-layer path
-constexpr int BLOCK_MIN_M = 96;
+constexpr int BLOCK_MIN_M = 96;        // a weight gradient takes the x3 kernel from 96 channels on both sides; below that (64-channel layer1) the fp32-MFMA one (p3d_conv2d_wgrad)
+constexpr int BLOCK_MIN_M_CONV = 64;   // forward / data gradient: half-filled 128-row tiles issue no MFMAs for their dead half (fx_live_subtiles)
+static int fuse_mode();
+// which convolutions the executor takes: mode 1 (BatchNorm inside the operand fetch) needs the x3 kernels everywhere
+static bool block_conv_ok(const p3d_conv_desc* d) {
+    if (fuse_mode() == 1) return fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M);
+    return fx_fwd_applies(d, BLOCK_MIN_M_CONV) && fx_dgrad_applies(d, BLOCK_MIN_M_CONV) && (d->Ho * d->Wo) % 4 == 0;
+}
 
 __device__ __forceinline__ void blk_sum3(double& a, double& b, double& c, double* red /*[12]*/) {
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
@@ -297,7 +304,7 @@ static int32_t check_block(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        P3D_REQUIRE(fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M),
+        P3D_REQUIRE(block_conv_ok(d),
                     "block: convolution %d (C=%d K=%d %dx%d stride %d, %dx%d input) is outside the fused path", i, d->C, d->K, d->R, d->S, d->stride, d->H, d->W);
         P3D_REQUIRE((d->Ho * d->Wo) % 4 == 0, "block: conv %d output rows are not 16-B groups", i);
     }
@@ -315,7 +322,7 @@ int32_t p3d_block_supported(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        if (!(fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M))) return 0;
+        if (!block_conv_ok(d)) return 0;
     }
     return 1;
 }
@@ -336,7 +343,7 @@ int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, s
         const size_t open = (size_t)d->K * CLOSE_MAX_SPLIT * 3 * sizeof(double), open2 = (size_t)d->C * CLOSE_MAX_SPLIT * 3 * sizeof(double);
         if (open > part) part = open;
         if (open2 > part) part = open2;
-        const size_t slabs = (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
+        const size_t slabs = fx_wgrad_applies(d, BLOCK_MIN_M) ? (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float) : p3d_conv2d_wgrad_workspace_bytes(d);
         if (slabs > sw) sw = slabs;
     }
     if (main_bytes) *main_bytes = align256(mw) + align256(part);
@@ -456,6 +463,11 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     auto launch_wgrad = [&](int slot, const float* dy, const float* xin, const FxFuse* fw, bool tapm) -> int32_t {
         const p3d_conv_desc* d = &b->conv[slot];
         if (two) { if (!order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; } side_used = true; }
+        if (!fx_wgrad_applies(d, BLOCK_MIN_M)) {        // (mode 0 only, see block_conv_ok: the operands are plain tensors here)
+            p3d_conv_desc dw_desc = *d;
+            dw_desc.accumulate = acc;
+            return p3d_conv2d_wgrad(&dw_desc, dy, xin, nullptr, nullptr, io->dw[slot], side_workspace, side_bytes, ss);
+        }
         ProfScope ps(2, d, ss);
         fx_count(2, d);
         const int splits = fx_wgrad_splits(d);

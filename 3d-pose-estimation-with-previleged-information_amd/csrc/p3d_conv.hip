@@ -1369,6 +1369,7 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
 }
 
 int32_t p3d_x3_enable(int32_t on) { return fx_set_enabled(on); }
+void p3d_fx_tune(int32_t what, int32_t value) { fx_tune(what, value); }
 
 void p3d_conv_path_stats(uint64_t* counts, double* flops, int32_t reset) {
     unsigned long long c[6];

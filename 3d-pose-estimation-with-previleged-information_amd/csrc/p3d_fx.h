@@ -71,6 +71,7 @@ struct ProfScope {
 };
 
 bool fx_enabled();
+void fx_tune(int what, int value);
 int fx_set_enabled(int on);
 void fx_count(int kind, const p3d_conv_desc* d);
 void fx_stats(unsigned long long* counts, double* flops, int reset);

@@ -730,14 +730,22 @@ bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
     return fx_common(d) && d->K >= fx_min_m(min_m) && d->C >= fx_min_m(min_m) && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
 }
 
+// tuning aid (p3d_fx_tune): forced split counts, 0 = the built-in plan
+static int g_force_conv_splits = 0, g_force_wgrad_splits = 0;
+void fx_tune(int what, int value) { (what == 0 ? g_force_wgrad_splits : g_force_conv_splits) = value; }
+
 struct FxSplit { int splits, kchunk; };
 static FxSplit fx_plan_split(int64_t tiles, int nk) {
     FxSplit s{1, 0};
     static const bool nosplit = getenv("P3D_FX_NOSPLIT") != nullptr;      // debugging aid
-    if (nosplit || tiles > 400 || nk < 64) return s;
-    int64_t want = ceil_div(768, tiles);
-    if (want > nk / 32) want = nk / 32;
-    if (want > 8) want = 8;
+    int64_t want;
+    if (g_force_conv_splits > 0) want = g_force_conv_splits < nk ? g_force_conv_splits : nk;
+    else {
+        if (nosplit || tiles > 400 || nk < 64) return s;
+        want = ceil_div(768, tiles);
+        if (want > nk / 32) want = nk / 32;
+        if (want > 8) want = 8;
+    }
     if (want < 2) return s;
     s.kchunk = (int)ceil_div(nk, want);
     s.splits = (int)ceil_div(nk, s.kchunk);
@@ -966,6 +974,7 @@ int fx_wgrad_splits(const p3d_conv_desc* d) {
     static const int minsteps = [] { const char* e = getenv("P3D_FX_WGRAD_MINSTEPS"); return e ? atoi(e) : 32; }();
     int64_t splits = ceil_div(target, tiles);
     if (splits > total / minsteps) splits = total / minsteps;           // at least 32 K steps per block
+    if (g_force_wgrad_splits > 0) splits = g_force_wgrad_splits < total ? g_force_wgrad_splits : total;
     if (splits < 1) splits = 1;
     const int64_t spb = ceil_div(total, splits);
     return (int)ceil_div(total, spb);

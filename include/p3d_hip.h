@@ -89,6 +89,8 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
  * (three-piece operand split, six piece products, fp32 accumulation; csrc/p3d_fx.hip): fp32-grade results, measured error <= the
  * fp32-MFMA kernel's.  p3d_x3_enable(0) (or P3D_X3=0 in the environment) keeps every layer on the v_mfma_f32_32x32x2_f32 kernels.  Returns the previous setting. */
 int32_t p3d_x3_enable(int32_t on);
+/* Tuning aid of tools/split_sweep.py: force the split count of the x3 weight-gradient (what = 0) or forward / data-gradient (what = 1) launches; value 0 restores the built-in plan. */
+void p3d_fx_tune(int32_t what, int32_t value);
 /* How many conv launches took which path since the last reset: counts / flops [0..2] = forward, data gradient, weight gradient on the bf16-pipe kernels,
  * [3..5] = the same three on the fp32-MFMA kernels (algorithmic flops 2*N*K*Ho*Wo*C*R*S).  Host-side bookkeeping only. */
 void p3d_conv_path_stats(uint64_t* counts, double* flops, int32_t reset);

@@ -15,6 +15,9 @@ CASES = [('bottleneck', 512, 128, 1, 1, 4, 16, False),       # identity shortcut
          ('basic', 128, 128, 1, 1, 4, 16, False),
          ('basic', 128, 256, 2, 1, 4, 32, True),
          ('basic', 128, 256, 1, 4, 2, 32, True),             # -stride 8 geometry: dilation 4
+         ('bottleneck', 256, 64, 1, 1, 4, 32, False),        # layer1.1+: 64-channel convs in half-dead 128-row tiles, their weight gradients on the fp32-MFMA kernel
+         ('bottleneck', 64, 64, 1, 1, 2, 32, True),          # layer1.0
+         ('basic', 64, 64, 1, 1, 4, 32, False),              # ResNet-18 layer1
          ('bottleneck', 1024, 256, 1, 1, 64, 16, False)]      # a BASELINE-size layer3 block at batch 64 (split-K forward / dgrad of the 3x3)
 
 
@@ -124,9 +127,12 @@ def test_fused_block_matches_per_layer_path_and_float64(case, pkg):
     assert rel(fused['y'], plain['y']) < 1e-5 and err(fused['dx'], plain['dx']) < tol
 
 
-def test_blocks_with_64_channel_layers_stay_on_the_per_layer_path(pkg):
-    block = build(pkg, 'bottleneck', 256, 64, 1, 1, False, seed=1)
-    assert not pkg.ops_block.usable(block, torch.zeros(2, 256, 16, 16, device='cuda'))
+def test_blocks_outside_the_executor_stay_on_the_per_layer_path(pkg):
+    """Channel counts the x3 kernels do not take (a reduction that is not a multiple of 16) keep the block on the per-layer path."""
+    block = build(pkg, 'bottleneck', 160, 40, 1, 1, False, seed=1)
+    x = torch.randn(2, 160, 16, 16, device='cuda')
+    assert not pkg.ops_block.usable(block, x)
+    assert torch.isfinite(block(x)).all()
 
 
 def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
