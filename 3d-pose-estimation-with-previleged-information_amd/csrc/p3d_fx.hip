@@ -145,6 +145,13 @@ __device__ __forceinline__ int fx_live_subtiles(int first, int limit) {
 // out-of-range bit 0x80000000 for padding pixels / rows beyond the tensor, which the resource's range check turns into zeros), the per-K-step part of an
 // address is a wave-uniform scalar offset.  So a K step's fetch is loads only: no branches, no per-step address arithmetic.
 constexpr int FX_OOB = (int)0x80000000;
+#ifndef P3D_FX_WGRAD_PIPE
+#define P3D_FX_WGRAD_PIPE 0
+#endif
+#ifndef P3D_FX_WGRAD_SCHED
+#define P3D_FX_WGRAD_SCHED 1
+#endif
+constexpr bool FX_WGRAD_PIPE = P3D_FX_WGRAD_PIPE != 0, FX_WGRAD_SCHED = P3D_FX_WGRAD_SCHED != 0;
 // tuning ablations (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands),
 // P3D_FX_ABL_NOSPLIT stores the raw bits instead of the three pieces (no split arithmetic)
 #ifdef P3D_FX_ABL_NOLOAD
@@ -557,24 +564,27 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const bool simple = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the input pixel IS the output pixel
     const bool vec = p.stride == 1 && (dw & 3) == 0;        // uniform: the four input pixels are one aligned 16-B group, in or out together
     const int b_row = (n0 + row) * HWi;
-    f32x4 ra[2], ra2[2], rb[2];
-    int b_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};
+    // Two register sets for fetched tiles: the plain variant (PA == 0 && PB == 0, what the residual-block executor launches by default) keeps the loads of
+    // TWO K steps in flight and splits step kt + 1 while the matrix pipe works on step kt; the others use set 0 only, one step ahead.
+    f32x4 ra[2][2], ra2[2][2], rb[2][2];
+    int b_voff[2][4] = {{FX_OOB, FX_OOB, FX_OOB, FX_OOB}, {FX_OOB, FX_OOB, FX_OOB, FX_OOB}};
     int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
     const bool rowwise = (p.OW & (FX_BK - 1)) == 0;        // uniform: a K step never straddles two output rows
     int f_oh = f_p / p.OW, f_ow = f_p - f_oh * p.OW;       // rowwise: the step's output row and first column (scalars)
     const int tw = 4 * kq * p.stride + dw;
-    auto fetch = [&]() {
+    auto fetch = [&](auto sel) {
+        constexpr int Q = decltype(sel)::value;
         const int a_so = (f_img * p.K * OHW + f_p) * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            ra[i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
-            if constexpr (PA >= 2) ra2[i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
+            ra[Q][i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
+            if constexpr (PA >= 2) ra2[Q][i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
         }
         int b_so = f_img * p.C * HWi * 4;
         if (simple) {
             b_so += f_p * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[e] = (b_row + 4 * kq + e) * 4;
+            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (b_row + 4 * kq + e) * 4;
         } else if (rowwise) {
             // the K step's 16 pixels lie in output row f_oh (a scalar, like everything that depends on the step): per thread, one add and one range check per pixel
             const int hi = f_oh * p.stride + dh;
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
             const int wi0 = f_ow * p.stride + tw;
             const int base = (b_row + hi * p.Wi + wi0) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
             f_ow += FX_BK;
             if (f_ow == p.OW) { f_ow = 0; ++f_oh; if (f_oh == p.OH) f_oh = 0; }
         } else {
@@ -592,41 +602,42 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
             const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
             const int base = (b_row + hi * p.Wi + wi0) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int so = b_so + i * 64 * HWi * 4;
             const int rowbad = b_ok[i] ? 0 : FX_OOB;
-            if (vec) rb[i] = fx_buffer_load_f32x4(rB, b_voff[0] | rowbad, FX_SO(so), 0);
+            if (vec) rb[Q][i] = fx_buffer_load_f32x4(rB, b_voff[Q][0] | rowbad, FX_SO(so), 0);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[i][e] = fx_buffer_load_f32(rB, b_voff[e] | rowbad, FX_SO(so), 0);
+                for (int e = 0; e < 4; ++e) rb[Q][i][e] = fx_buffer_load_f32(rB, b_voff[Q][e] | rowbad, FX_SO(so), 0);
             }
         }
         f_p += FX_BK;
         if (f_p == OHW) { f_p = 0; ++f_img; }
     };
     const int st_off[2] = {fx_rc_off(row, kq >> 1) + 8 * (kq & 1), fx_rc_off(row + 64, kq >> 1) + 8 * (kq & 1)};
-    auto stage = [&](int buf) {
+    auto stage = [&](auto sel, int buf) {
+        constexpr int Q = decltype(sel)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f32x4 va = ra[i], vb = rb[i];
+            f32x4 va = ra[Q][i], vb = rb[Q][i];
             if constexpr (PA == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float c = ra2[i][e];
-                    const float g = fmaf(c, atab[i][1][0], atab[i][1][1]) > 0.f ? ra[i][e] : 0.f;
+                    const float c = ra2[Q][i][e];
+                    const float g = fmaf(c, atab[i][1][0], atab[i][1][1]) > 0.f ? ra[Q][i][e] : 0.f;
                     va[e] = fmaf(atab[i][0][0], g, fmaf(atab[i][0][1], c, atab[i][0][2]));      // (rows k >= K have all-zero constants)
                 }
             }
             if constexpr (PA == 3) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) va[e] = fmaf(atab[i][0][0], ra[i][e], fmaf(atab[i][0][1], ra2[i][e], atab[i][0][2]));
+                for (int e = 0; e < 4; ++e) va[e] = fmaf(atab[i][0][0], ra[Q][i][e], fmaf(atab[i][0][1], ra2[Q][i][e], atab[i][0][2]));
             }
             if constexpr (PB == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && (vec ? b_voff[0] : b_voff[e]) >= 0) ? fmaxf(fmaf(rb[i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && (vec ? b_voff[Q][0] : b_voff[Q][e]) >= 0) ? fmaxf(fmaf(rb[Q][i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
             }
             fx_split_store(As + buf * 3 * FX_PIECE + st_off[i], va);
             fx_split_store(Bs + buf * 3 * FX_PIECE + st_off[i], vb);
@@ -642,13 +653,15 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const int fr = lane & 31, fh = lane >> 5;
     const int rd_a[2] = {fx_rc_off(wm * 64 + fr, fh), fx_rc_off(wm * 64 + 32 + fr, fh)}, rd_b[2] = {fx_rc_off(wn * 64 + fr, fh), fx_rc_off(wn * 64 + 32 + fr, fh)};
     const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
-    if (nk > 0) { fetch(); stage(0); }
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    constexpr bool PIPE = PA == 0 && PB == 0 && FX_WGRAD_PIPE;
+    if (nk > 0) { fetch(Q0{}); stage(Q0{}, 0); }
+    if (PIPE && nk > 1) fetch(Q1{});
     __syncthreads();
     auto kloop = [&](auto nat) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles along k
         constexpr int NA = decltype(nat)::value;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) fetch();
+        auto compute = [&](int buf) {
             if constexpr (NA > 0) {
                 bf8 af[3][2], bf[3][2];
 #pragma unroll
@@ -660,8 +673,40 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
                     }
                 P3D_FX_PRODUCTS_AB(acc, af, bf, NA, 2)
             }
-            if (kt + 1 < nk) stage(buf ^ 1);
-            __syncthreads();
+        };
+        if constexpr (PIPE) {
+            // step kt: tile kt is in LDS buffer kt & 1, tile kt + 1 in register set (kt + 1) & 1 (fetched a whole step ago), tile kt + 2 goes into set kt & 1
+            // (the last step splits a stale register set into the LDS buffer nobody reads any more: the split stays unconditional, in the MFMAs' basic block)
+            auto step = [&](auto par, int kt) {
+                constexpr int P = decltype(par)::value;
+                if (kt + 2 < nk) fetch(std::integral_constant<int, P>{});
+                compute(P);
+                stage(std::integral_constant<int, P ^ 1>{}, P ^ 1);
+                if constexpr (NA == 2 && FX_WGRAD_SCHED) {
+                    // one basic block: 12 fragment reads, 24 MFMAs, ~90 VALU of the split and its 8 LDS stores -- spread the split into the MFMAs' shadow
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                __syncthreads();
+            };
+            for (int kt = 0; kt < nk; kt += 2) {
+                step(Q0{}, kt);
+                if (kt + 1 < nk) step(Q1{}, kt + 1);
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                if (kt + 1 < nk) fetch(Q0{});
+                compute(buf);
+                if (kt + 1 < nk) stage(Q0{}, buf ^ 1);
+                __syncthreads();
+            }
         }
     };
     if (live_a == 0 || live_b == 0) kloop(std::integral_constant<int, 0>{});
@@ -731,8 +776,8 @@ bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
 }
 
 // tuning aid (p3d_fx_tune): forced split counts, 0 = the built-in plan
-static int g_force_conv_splits = 0, g_force_wgrad_splits = 0;
-void fx_tune(int what, int value) { (what == 0 ? g_force_wgrad_splits : g_force_conv_splits) = value; }
+static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0;
+void fx_tune(int what, int value) { (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value; }
 
 struct FxSplit { int splits, kchunk; };
 static FxSplit fx_plan_split(int64_t tiles, int nk) {
@@ -967,12 +1012,24 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
 
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 && d->R == 1; }
 
+// How many slabs (splits of the pixel reduction) a weight gradient is cut into.  Measured on MI355X over the ResNet layer classes at batch 64
+// (tools/split_sweep.py, profiles/r02_summary.md): one resident round of blocks -- two or three per CU, 512 to 768 in all -- beats the 1024+ blocks
+// the first plan asked for by 5-25 % per layer; grids that are an exact multiple of the 256 CUs do best, so tile counts that divide 256 aim at
+// 512 (mid-sized) or 768 blocks, the 3x3 grids (9, 36, 144 tiles) at 576, and a grid that cannot fit one round (the 272-channel regressor: a third of
+// its blocks are nearly empty) goes the other way, to many short blocks that balance themselves.
 int fx_wgrad_splits(const p3d_conv_desc* d) {
     const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
-    static const int target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();      // tuning aid
+    static const int env_target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning aids
     static const int minsteps = [] { const char* e = getenv("P3D_FX_WGRAD_MINSTEPS"); return e ? atoi(e) : 32; }();
-    int64_t splits = ceil_div(target, tiles);
+    int64_t target;
+    if (g_wgrad_target > 0) target = g_wgrad_target;
+    else if (env_target > 0) target = env_target;
+    else if (tiles >= 256) target = 3072;
+    else if ((tiles & (tiles - 1)) == 0) target = (tiles <= 8 || tiles >= 128) ? 768 : 512;
+    else if (d->stride > 1) target = tiles < 16 ? 768 : 512;
+    else target = 576;
+    int64_t splits = (2 * target + tiles) / (2 * tiles);                 // nearest
     if (splits > total / minsteps) splits = total / minsteps;           // at least 32 K steps per block
     if (g_force_wgrad_splits > 0) splits = g_force_wgrad_splits < total ? g_force_wgrad_splits : total;
     if (splits < 1) splits = 1;
