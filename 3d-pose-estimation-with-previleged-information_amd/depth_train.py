@@ -144,9 +144,10 @@ class Trainer:
     # ---- process-group ordering ----------------------------------------------------------------
     def warm_memory(self, color_image, depth_image, true_cam, true_val):
         """One forward + backward WITHOUT an optimizer step and with the BatchNorm buffers restored afterwards: it only makes the
-        caching allocator own every activation / workspace / gradient block the step needs.  Device memory that is first allocated
-        after an RCCL communicator exists is measurably slower for the kernels (+4 % step time on MI355X / ROCm 7.2), so a launcher
-        calls this BEFORE dist.init_from_env() and attach_reducer() after it (bench.py, depth_main.main)."""
+        caching allocator own every activation / workspace / gradient block the step needs and creates the weight-gradient stream, so that
+        nothing is allocated or created inside the timed steps.  A launcher calls this before dist.init_from_env() and attach_reducer() after
+        it (bench.py, depth_main.main); the order no longer matters for speed (the +4 % of round 1 was a hardware-queue
+        collision of the weight-gradient stream, now excluded by a probe)."""
         saved = {k: v.clone() for k, v in self.model.state_dict().items() if 'running_' in k or 'num_batches_tracked' in k}
         opt = self.optimizer
         keep = (opt.clip_and_step, opt.clip_and_step_dev)

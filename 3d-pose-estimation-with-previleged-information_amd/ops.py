@@ -90,10 +90,29 @@ def _second_workspace(device, nbytes):
     return ws
 
 
+SIDE_STREAM_KIND = os.environ.get('P3D_SIDE_STREAM', 'probe')       # probe | torch (a stream from PyTorch's pool) | low | normal | high (a fixed priority class)
+SIDE_STREAM_OVERLAPS = {}                                              # device -> what the probe found (None: not probed)
+
+
 def _side_stream(device):
+    """The weight-gradient stream.  HIP multiplexes the streams of one priority onto four hardware queues: a stream taken from PyTorch's pool landed on
+    the launch stream's own queue whenever an RCCL communicator had been created first (rocprofv3: every kernel of the step on one queue), which costs
+    the overlap plus a queue barrier per cross-stream event, +2.3 ms per step.  So the stream is chosen by measurement:
+    p3d_stream_create_beside creates candidates until two spin kernels, one per stream, demonstrably run side by side."""
     st = _side_streams.get(device)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        if SIDE_STREAM_KIND == 'torch':
+            st = torch.cuda.Stream(device=device)
+            SIDE_STREAM_OVERLAPS[device] = None
+        else:
+            handle, found = ctypes.c_void_p(), ctypes.c_int32(-1)
+            with torch.cuda.device(device):
+                if SIDE_STREAM_KIND == 'probe':
+                    check(lib().p3d_stream_create_beside(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream), ctypes.byref(handle), ctypes.byref(found)), 'stream_create_beside')
+                else:
+                    check(lib().p3d_stream_create({'low': 1, 'normal': 0, 'high': -1}[SIDE_STREAM_KIND], ctypes.byref(handle)), 'stream_create')
+            st = torch.cuda.ExternalStream(handle.value, device=device)
+            SIDE_STREAM_OVERLAPS[device] = None if found.value < 0 else bool(found.value)
         _side_streams[device] = st
     return st
 

@@ -107,8 +107,9 @@ def main():
     import torch.distributed as dist
     pkg = importlib.import_module(PKG_NAME)
     ops = pkg.ops
-    # The process group is joined only AFTER the model, the optimizer buffers and one step's worth of activations have been allocated
-    # (Trainer.warm_memory): memory first allocated once an RCCL communicator exists is slower for the kernels.
+    # The process group is joined after the model, the optimizer buffers and one step's worth of activations exist (Trainer.warm_memory): round 1
+    # measured +4 % when the group came first.  Round 2 found the cause (the weight-gradient stream shared the launch stream's
+    # hardware queue then) and removed it (ops._side_stream picks its stream by a concurrency probe); the order is kept because it costs nothing.
     world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('P3D_BENCH_SHARE_GPU'):      # rehearsal of the N > 1 flow on a one-GPU box (with P3D_DIST_BACKEND=gloo): all ranks on cuda:0
         local_rank = 0
@@ -116,6 +117,9 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (a launcher set a different world size)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    join_first = bool(os.environ.get('P3D_BENCH_JOIN_FIRST')) and (world > 1 or pkg.dist.FORCE_GROUP)       # experiment (tools/rccl_order.sh): the other order
+    if join_first:
+        pkg.dist.init_from_env()
 
     extra = {'depthnet': [], 'fusionnet': ['-do_fusion'], 'partial_depthnet': ['-depth_only', '-partial_conv'],
              'partial_fusionnet': ['-do_fusion', '-partial_conv']}[opt.family]
@@ -148,8 +152,9 @@ def main():
         trainer.train_step = step_with_augmentation
 
     if world > 1 or pkg.dist.FORCE_GROUP:
-        trainer.warm_memory(*batches[0])
-        pkg.dist.init_from_env()
+        if not join_first:
+            trainer.warm_memory(*batches[0])
+            pkg.dist.init_from_env()
         trainer.attach_reducer()
 
     def sync():
@@ -287,7 +292,8 @@ def main():
             'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32 (3xbf16 split, 6 products, f32 accumulate)', 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
-                       'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4)},
+                       'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4),
+                       'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank)))},
             'roofline': {'bound': 'mfma',
                          'kernel': 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)' if opt.half else
                                    'p3d::fx_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16)',

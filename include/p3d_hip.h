@@ -34,6 +34,13 @@ extern "C" {
 
 int32_t p3d_version(void);
 const char* p3d_last_error(void);
+/* A HIP stream of a priority class (-1 high, 0 normal, 1 low) on the current device; the weight-gradient stream of the host mirror is a LOW one (its own
+ * hardware-queue pool: see csrc/p3d_api.hip).  No reference counterpart: the reference leaves streams to PyTorch. */
+int32_t p3d_stream_create(int32_t priority_class, void** stream);
+/* A second stream that is PROVEN to run beside `main_stream` (two 200-us spin kernels, one per stream, must take ~200 us, not ~400): see csrc/p3d_api.hip.
+ * *overlaps = 1 if a candidate passed the probe, 0 if the returned stream shares the main stream's hardware queue after all. */
+int32_t p3d_stream_create_beside(void* main_stream, void** stream, int32_t* overlaps);
+int32_t p3d_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution: nn.Conv2d forward / input gradient / weight gradient
