@@ -111,8 +111,9 @@ def main():
     # measured +4 % when the group came first.  Round 2 found the cause (the weight-gradient stream shared the launch stream's
     # hardware queue then) and removed it (ops._side_stream picks its stream by a concurrency probe); the order is kept because it costs nothing.
     world, rank, local_rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('P3D_BENCH_SHARE_GPU'):      # rehearsal of the N > 1 flow on a one-GPU box (with P3D_DIST_BACKEND=gloo): all ranks on cuda:0
+    if os.environ.get('P3D_BENCH_SHARE_GPU'):      # rehearsal of the N > 1 flow on a one-GPU box: all ranks on cuda:0, gradients exchanged through gloo
         local_rank = 0
+        os.environ.setdefault('P3D_DIST_BACKEND', 'gloo')
     if world != opt.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (a launcher set a different world size)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
