@@ -16,7 +16,8 @@ namespace p3d {
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int CLOSE_MAX_SPLIT = 64;
-constexpr int FIN_CH = 16, FIN_LANES = 16;      // finalize kernels: a 256-thread block sums 16 channels with 16 row lanes each
+constexpr int FIN_CH = 16, FIN_MAX_LANES = 64;  // finalize kernels: a block sums 16 channels with blockDim / 16 row lanes each (16 lanes, or 64 when there are many rows)
+static inline unsigned fin_threads(int rows) { return rows > 64 ? 1024u : 256u; }
 // channel counts below 96 leave the 128-row tile of the x3 kernels too empty (64-channel layers measured 72-82 TF there against 88-99 TF on the fp32-MFMA
 // kernel, weight gradient 37 against 80): blocks with such layers (ResNet layer1) stay on the per-layer path
 constexpr int BLOCK_MIN_M = 96;        // a weight gradient takes the x3 kernel from 96 channels on both sides; below that (64-channel layer1) the fp32-MFMA one (p3d_conv2d_wgrad)
@@ -42,23 +43,22 @@ __device__ __forceinline__ void blk_sum3(double& a, double& b, double& c, double
 // Forward finalize of one BatchNorm layer from the conv epilogue's partial sums: partial [rows][C][2] = (sum y, sum y^2) per pixel tile.
 // One block per 64 channels, 4 row lanes per channel; fp64 combine.  Writes the table entries {sc, sh, mean, invstd} and updates the running statistics
 // (momentum, unbiased variance) exactly as p3d_bn_train_fwd does.
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ partial, int rows, int C, double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __restrict__ partial, int rows, int C, double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
                                                               float* __restrict__ table) {
-    const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl;
+    const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl, FIN_LANES = blockDim.x / FIN_CH;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
         for (int r = rl; r < rows; r += FIN_LANES) {
             const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
             s1 += v.x; s2 += v.y;
         }
-    __shared__ double red[2][FIN_LANES][FIN_CH];
+    __shared__ double red[2][FIN_MAX_LANES][FIN_CH];
     red[0][rl][cl] = s1; red[1][rl][cl] = s2;
     __syncthreads();
     if (rl != 0 || c >= C) return;
     s1 = s2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < FIN_LANES; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }       // fixed order: bitwise reproducible
+    for (int i = 0; i < FIN_LANES; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }       // fixed order (the lane count follows from `rows` alone): bitwise reproducible
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 // the second sum) = (sum g, sum g * (c - mean)).  dbeta = sum g, dgamma = invstd * sum g (c - mean); table {A, B, K}:  d c = A g + B c + K  with
 // A = gamma invstd, B = -A invstd m2, K = A (mean invstd m2 - m1), m1 = dbeta / count, m2 = dgamma / count.
 template <bool F64>
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const void* __restrict__ partial_, int rows, int C, double count, int which, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const void* __restrict__ partial_, int rows, int C, double count, int which, const float* __restrict__ gamma,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ table) {
-    const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl;
+    const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl, FIN_LANES = blockDim.x / FIN_CH;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         if constexpr (F64) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const void* __rest
             }
         }
     }
-    __shared__ double red[2][FIN_LANES][FIN_CH];
+    __shared__ double red[2][FIN_MAX_LANES][FIN_CH];
     red[0][rl][cl] = s1; red[1][rl][cl] = s2;
     __syncthreads();
     if (rl != 0 || c >= C) return;
@@ -383,7 +383,7 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             fx_count(0, d);
             if (int32_t e = fx_conv_fwd(d, ds ? io->x : in, io->w[i], nullptr, io->c[i], workspace, conv_ws, &f, st)) return e;
         }
-        hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(256), 0, st, (const float*)partial, fx_partial_rows_fwd(d), d->K,
+        hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(fin_threads(fx_partial_rows_fwd(d))), 0, st, (const float*)partial, fx_partial_rows_fwd(d), d->K,
                            (double)d->N * d->Ho * d->Wo, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
         if (!ds) {
             in = io->c[i];
@@ -441,10 +441,10 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                        (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
                        b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->gbuf, (double*)partial, dl->N, dl->K, dl->Ho * dl->Wo, b->relu_out);
     const double cnt_last = (double)dl->N * dl->Ho * dl->Wo;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(256), 0, st, (const void*)partial, split, dl->K, cnt_last, 0, io->gamma[last],
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(fin_threads(split)), 0, st, (const void*)partial, split, dl->K, cnt_last, 0, io->gamma[last],
                        io->dgamma[last], io->dbeta[last], acc, io->table[last]);
     if (b->has_downsample)
-        hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(256), 0, st, (const void*)partial, split, dl->K, cnt_last, 1, io->gamma[3],
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(fin_threads(split)), 0, st, (const void*)partial, split, dl->K, cnt_last, 1, io->gamma[3],
                            io->dgamma[3], io->dbeta[3], acc, io->table[3]);
     if (int32_t e = check_launch("block_bwd open")) return e;
 
@@ -510,13 +510,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             }
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
             if (epi) {
-                hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(256), 0, st, (const void*)partial, fx_partial_rows_dgrad(d), dp->K,
+                hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(fin_threads(fx_partial_rows_dgrad(d))), 0, st, (const void*)partial, fx_partial_rows_dgrad(d), dp->K,
                                    cnt, 0, io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
             } else {
                 const int sp = close_split(dp->N, dp->K);
                 hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dp->K, sp), dim3(256), 0, st, (const float*)io->da[i - 1], (const float*)io->c[i - 1],
                                    (const float*)io->table[i - 1], (double*)partial, dp->N, dp->K, dp->Ho * dp->Wo);
-                hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(256), 0, st, (const void*)partial, sp, dp->K, cnt, 0,
+                hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(fin_threads(sp)), 0, st, (const void*)partial, sp, dp->K, cnt, 0,
                                    io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
             }
             gi = io->da[i - 1];
