@@ -269,21 +269,15 @@ static size_t g_event_next = 0;
 static hipEvent_t next_event() {
     if (g_events.size() < 128) {
         hipEvent_t e;
-        static const int evt = [] { const char* v = getenv("P3D_BLK_EVT"); return v ? atoi(v) : 0; }();
-        const unsigned flags = evt == 1 ? hipEventDefault : (evt == 2 ? (hipEventDisableTiming | hipEventReleaseToSystem) : hipEventDisableTiming);
-        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
         g_events.push_back(e);
         return e;
     }
     return g_events[g_event_next++ % g_events.size()];          // a recorded event may be re-recorded once the wait on it has been enqueued
 }
-__global__ void blk_noop_kernel() {}
 static bool order_after(hipStream_t waiter, hipStream_t signaller) {
     hipEvent_t e = next_event();
-    const bool ok = e && hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
-    static const int dummy = [] { const char* v = getenv("P3D_BLK_DUMMY"); return v ? atoi(v) : 0; }();       // experiment: an empty kernel behind the event record
-    if (dummy) hipLaunchKernelGGL(blk_noop_kernel, dim3(1), dim3(64), 0, signaller);
-    return ok;
+    return e && hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
 }
 
 // ---- conv launch profile (bench.py's roofline brackets): HIP events around every conv call of the executor, on the stream it runs on ----------
