@@ -152,6 +152,10 @@ constexpr int FX_OOB = (int)0x80000000;
 #define P3D_FX_WGRAD_SCHED 1
 #endif
 constexpr bool FX_WGRAD_PIPE = P3D_FX_WGRAD_PIPE != 0, FX_WGRAD_SCHED = P3D_FX_WGRAD_SCHED != 0;
+#ifndef P3D_FX_WGRAD_MFMA16
+#define P3D_FX_WGRAD_MFMA16 0
+#endif
+constexpr bool FX_WGRAD_MFMA16 = P3D_FX_WGRAD_MFMA16 != 0;
 // tuning ablations (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands),
 // P3D_FX_ABL_NOSPLIT stores the raw bits instead of the three pieces (no split arithmetic)
 #ifdef P3D_FX_ABL_NOLOAD
@@ -652,6 +656,25 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
     const int rd_a[2] = {fx_rc_off(wm * 64 + fr, fh), fx_rc_off(wm * 64 + 32 + fr, fh)}, rd_b[2] = {fx_rc_off(wn * 64 + fr, fh), fx_rc_off(wn * 64 + 32 + fr, fh)};
+    // FX_WGRAD_MFMA16: the same six products on v_mfma_f32_16x16x32_bf16.  Its 32-deep reduction is used as TWO piece products over the step's 16 k: lanes
+    // 0-31 feed one (A piece, B piece) pair, lanes 32-63 another, so three instructions per 16 x 16 tile give lo*hi + hi*lo, mid*hi + mid*mid, hi*hi + hi*mid.
+    // Lane l holds row (l & 15), k half (l >> 4) & 1 of the piece its half-wave reads; sub-tiles are 16 rows apart (512 B in the 32-B-row image).
+    f32x4 acc16[4][4];
+    const int r16 = lane & 15, kh16 = (lane >> 4) & 1, ps16 = lane >> 5;
+    int rd16_a[3], rd16_b[2];
+    {
+        const int pa[3][2] = {{2, 0}, {1, 1}, {0, 0}}, pb[2][2] = {{0, 2}, {0, 1}};      // [pair][half-wave] piece: pairs run smallest first; B of pairs 1 and 2 is the same
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rd16_a[q] = pa[q][ps16] * FX_PIECE + fx_rc_off(wm * 64 + r16, kh16);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rd16_b[q] = pb[q][ps16] * FX_PIECE + fx_rc_off(wn * 64 + r16, kh16);
+    }
+    if constexpr (FX_WGRAD_MFMA16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
@@ -662,7 +685,25 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     auto kloop = [&](auto nat) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles along k
         constexpr int NA = decltype(nat)::value;
         auto compute = [&](int buf) {
-            if constexpr (NA > 0) {
+            if constexpr (NA > 0 && FX_WGRAD_MFMA16) {
+                const unsigned char* ab = As + buf * 3 * FX_PIECE;
+                const unsigned char* bb = Bs + buf * 3 * FX_PIECE;
+                bf8 bq[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[q][j] = *reinterpret_cast<const bf8*>(bb + rd16_b[q] + 512 * j);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    bf8 aq[2 * NA];
+#pragma unroll
+                    for (int i = 0; i < 2 * NA; ++i) aq[i] = *reinterpret_cast<const bf8*>(ab + rd16_a[q] + 512 * i);
+#pragma unroll
+                    for (int i = 0; i < 2 * NA; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[q == 0 ? 0 : 1][j], acc16[i][j], 0, 0, 0);
+                }
+            } else if constexpr (NA > 0) {
                 bf8 af[3][2], bf[3][2];
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
@@ -715,6 +756,22 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
     const int RS = p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;
+    if constexpr (FX_WGRAD_MFMA16) {
+        // 16 x 16 C/D layout: col = lane & 15 (input channel c), row = 4 (lane >> 4) + reg (output channel k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = n0 + wn * 64 + 16 * j + r16;
+                if (c >= p.C) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = m0 + wm * 64 + 16 * i + 4 * (lane >> 4) + r;
+                    if (k < p.K) out[((size_t)k * RS + tap) * p.C + c] = acc16[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
