@@ -508,6 +508,8 @@ X3_CASES = [
     (4, 512, 512, 16, 3, 1, 2, False), (3, 2048, 272, 16, 3, 1, 1, True), (64, 128, 128, 32, 5, 1, 1, True),
     (8, 128, 128, 64, 3, 2, 1, False), (4, 256, 512, 64, 1, 2, 1, False), (6, 256, 256, 32, 3, 2, 1, False), (2, 128, 256, 32, 3, 1, 4, False),
     (3, 256, 128, 8, 3, 1, 1, False), (64, 256, 256, 16, 3, 1, 1, False),
+    # 64 channels on one side: forward / dgrad in half-dead 128-row tiles, the weight gradient on the fp32-MFMA kernel (a 64 x 64-tile x3 kernel measured slower: 60 vs 80 TF)
+    (4, 64, 128, 32, 3, 2, 1, False), (3, 64, 64, 8, 3, 1, 1, False), (5, 192, 64, 8, 1, 1, 1, False), (2, 64, 64, 32, 3, 1, 2, False), (64, 64, 64, 64, 3, 1, 1, False),
 ]
 
 
