@@ -283,23 +283,25 @@ def main():
         gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if is_contract else conv_flops / 1e9 / (opt.batch * ksteps)
         achieved = gflop_crop * opt.batch * ksteps / conv_total_ms             # GFLOP/ms == TFLOP/s
         step_tflops = value / world * gflop_crop / 1e3                          # crops/s x GFLOP/crop, whole step, per GPU
-        peak = BF16_MFMA_PEAK_TFLOPS if opt.half else X3_PEAK_TFLOPS
+        x3_on = coverage['x3_launches_per_step'] > 0            # P3D_X3=0: every conv on the fp32-MFMA instruction -> its own dtype string and peak
+        peak = BF16_MFMA_PEAK_TFLOPS if opt.half else (X3_PEAK_TFLOPS if x3_on else FP32_MFMA_PEAK_TFLOPS)
         out = {
             'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU',
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'fwd_bwd_crops_per_s': round(opt.batch * world * fsteps / fb_elapsed, 2), 'fwd_bwd_ms_per_step': round(fb_elapsed / fsteps * 1e3, 3),
             'vs_baseline': None,
-            'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else 'f32 (3xbf16 split, 6 products, f32 accumulate)', 'data': 'synthetic',
+            'dtype': 'f16 (fp32 accumulate, fp32 masters)' if opt.half else ('f32 (3xbf16 split, 6 products, f32 accumulate)' if x3_on else 'f32'), 'data': 'synthetic',
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4),
                        'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank)))},
             'roofline': {'bound': 'mfma',
                          'kernel': 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)' if opt.half else
-                                   'p3d::fx_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16)',
+                                   ('p3d::fx_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16)' if x3_on else
+                                    'p3d::igemm_kernel (conv fwd/dgrad/wgrad on v_mfma_f32_32x32x2_f32)'),
                          'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'peak_note': 'dense f16 MFMA peak' if opt.half else 'fp32-equivalent ceiling of the pipe the kernel runs on: 2500 TFLOP/s dense bf16 / 6 piece products',
+                         'peak_note': 'dense f16 MFMA peak' if opt.half else ('fp32-equivalent ceiling of the pipe the kernel runs on: 2500 TFLOP/s dense bf16 / 6 piece products' if x3_on else 'dense fp32 MFMA peak'),
                          'frac_of_fp32_mfma_peak': None if opt.half else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'fp32_mfma_peak': FP32_MFMA_PEAK_TFLOPS,
                          'traffic': traffic, 'launches_per_step': launches,
                          'avg_launch_ms': round(conv_total_ms / max(nlaunch, 1), 4),

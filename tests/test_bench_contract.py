@@ -23,15 +23,19 @@ def test_bench_line_schema():
         assert isinstance(line[key], kind), key
     assert 'vs_baseline' in line and line['vs_baseline'] is None          # BASELINE.md publishes no number for this metric
     assert line['unit'] == 'crops/s' and line['n_gpus'] == 1 and line['steps'] == 3 and line['warmup'] == 1
-    assert line['scaling'] == 'weak' and line['dtype'].startswith('f32 (3xbf16 split') and line['data'] == 'synthetic' and line['higher_is_better'] is True
+    x3 = os.environ.get('P3D_X3', '1') != '0'                       # (the suite also runs with the x3 kernels switched off)
+    assert line['scaling'] == 'weak' and (line['dtype'].startswith('f32 (3xbf16 split') if x3 else line['dtype'] == 'f32') and line['data'] == 'synthetic' and line['higher_is_better'] is True
     assert line['fwd_bwd_crops_per_s'] >= line['value'] * 0.98          # forward + backward alone is never slower than the full step
     assert 'workload' in line['config'] and 'model' not in line['config']
     assert line['value'] == pytest.approx(64 * 3 / (line['ms_per_step'] * 3 / 1e3), rel=1e-3)
     r = line['roofline']
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == pytest.approx(2500.0 / 6, abs=0.1) and r['fp32_mfma_peak'] == 157.3
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == pytest.approx(2500.0 / 6 if x3 else 157.3, abs=0.1) and r['fp32_mfma_peak'] == 157.3
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], abs=1e-3) and 0.1 < r['frac'] < 1.0
     assert r['frac_of_fp32_mfma_peak'] == pytest.approx(r['achieved'] / 157.3, abs=1e-3)
-    assert r['conv_paths']['x3_flop_fraction'] > 0.9 and r['conv_paths']['fp32_mfma_launches_per_step'] >= 2         # the 3-channel stem stays on the fp32-MFMA kernel, and is counted
+    if x3:
+        assert r['conv_paths']['x3_flop_fraction'] > 0.9 and r['conv_paths']['fp32_mfma_launches_per_step'] >= 2     # the 3-channel stem stays on the fp32-MFMA kernel, and is counted
+    else:
+        assert r['conv_paths']['x3_launches_per_step'] == 0
     assert r['traffic'] is None or r['traffic'] > 0
     side = line['fp32_mfma_only']                                   # informational side measurement, never `value`
     assert side['unit'] == 'crops/s' and side['value'] > 0 and 'NOT the contract' in side['note']

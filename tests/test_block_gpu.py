@@ -1,11 +1,13 @@
 """The fused residual-block executor (p3d_block_fwd / p3d_block_bwd: one C call per block and direction, BatchNorm inside the convolution kernels)
 against the per-layer path (one autograd node per conv / BN, stand-alone BatchNorm passes) on the same module and data, and against float64 PyTorch:
 block output, input gradient, every parameter gradient and the BatchNorm running statistics (depthnet.py:40-56,96-116)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get('P3D_X3', '1') == '0', reason='the block executor needs the x3 kernels (P3D_X3=0 runs every layer on the fp32-MFMA path)')]
 
 #        kind          inplanes planes stride dil  N  H   downsample
 CASES = [('bottleneck', 512, 128, 1, 1, 4, 16, False),       # identity shortcut (layerN.1+)
@@ -38,6 +40,7 @@ def build(pkg, kind, inplanes, planes, stride, dil, with_ds, seed):
 
 
 def run(pkg, block, x0, dy, fused):
+    before = pkg._trunk.FUSED_BLOCKS
     pkg._trunk.FUSED_BLOCKS = fused
     try:
         state = {k: v.clone() for k, v in block.state_dict().items()}
@@ -51,7 +54,7 @@ def run(pkg, block, x0, dy, fused):
         block.load_state_dict(state)
         return res
     finally:
-        pkg._trunk.FUSED_BLOCKS = True
+        pkg._trunk.FUSED_BLOCKS = before
 
 
 def reference(block, x0, dy, with_ds):
@@ -140,6 +143,7 @@ def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
     block, x0, dy, (ref, xr, yr, closest) = make_case(pkg, 'bottleneck', 512, 128, 1, 1, 4, 16, False, want_clean=True)
     opt = pkg.optim.FlatAdam(list(block.named_parameters()), lr=1e-3)
     res = []
+    default = pkg._trunk.FUSED_BLOCKS
     for fused in (False, True):
         pkg._trunk.FUSED_BLOCKS = fused
         try:
@@ -151,7 +155,7 @@ def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
                 torch.cuda.synchronize()
             res.append((opt.flat_g.clone(), x.grad.clone()))
         finally:
-            pkg._trunk.FUSED_BLOCKS = True
+            pkg._trunk.FUSED_BLOCKS = default
     want = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in ref.parameters()])
     for flat, dx in res:
         assert rel(flat, want) < 1e-4 and rel(dx, xr.grad) < 2e-5

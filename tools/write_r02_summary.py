@@ -135,6 +135,8 @@ Other settings measured on the way (each line one box): `GPU_MAX_HW_QUEUES=8`: g
 
 `python -m pytest tests -m gpu -q` on MI355X: **239 passed**; `python -m pytest tests -m "not gpu" -q` in the build container: 63 passed;
 `__graft_entry__.smoke()`: loss rel 8e-8, spec_cam rel 5e-7 against the oracle.
+The same suite with the switches of INTEGRATION.md: `P3D_BLOCKS=0` (x3 kernels, one autograd node per layer) 239 passed; `P3D_X3=0` (every conv on the
+fp32-MFMA kernels) 226 passed, 13 skipped (the block-executor tests need the x3 kernels; the bench line then says dtype "f32", peak 157.3).
 ''' % dict(bench=bench, value=b['value'], ms=b['ms_per_step'], f32ms=b['fp32_mfma_only']['ms_per_step'], other=rd('r02_other_configs.txt'), tables=rd('r02_tables.md'),
            fetch=tr['FETCH_SIZE']['x3']['kb_per_launch'] * 1024 * MB, write=tr['WRITE_SIZE']['x3']['kb_per_launch'] * 1024 * MB, raw=tr['raw_bytes_per_launch'] * MB,
            corr=tr['bytes_per_launch'] * MB, conv=rd('r02_conv_bench.txt'), pmc1=rd('r02_pmc_fwd_c1024_k2048.txt'), pmc2=rd('r02_pmc_wgrad_c512_3x3.txt'),
