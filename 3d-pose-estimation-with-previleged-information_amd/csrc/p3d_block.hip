@@ -516,12 +516,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             gi = io->da[i - 1];
         } else if (b->need_dx) {
             // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
-            // the downsample conv's dgrad adds to it below.  With a second stream the launch stream waits for it here in BOTH cases.  Identity: the
-            // weight-gradient kernels that read g must be done before g's buffer becomes dx.  Downsample: no buffer is shared, yet without the wait the
-            // input gradient showed run-to-run differences; the two-stream mode is off by default for that reason.
+            // the downsample conv's dgrad adds to it below.  The launch stream does NOT wait for the weight-gradient stream here: in the only mode that
+            // runs two streams (mode 0) no weight-gradient kernel reads g -- they read dcl / da[i] and the activations -- so nothing they touch is
+            // written by this launch.  (Round 2 first had a wait here, 69 x ~14 us of idle launch stream per step in the kernel trace.)
             dd = *d;
             float* dx;
-            if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
+            static const bool wait_side = getenv("P3D_BLOCK_WAIT_SIDE") != nullptr;      // the earlier behaviour, for A/B
+            if (wait_side && two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");
