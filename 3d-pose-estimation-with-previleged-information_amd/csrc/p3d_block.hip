@@ -541,9 +541,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         const float* dy = g;
         if (fused) { f.pro_tab = io->table[3]; f.pro_c = io->c[3]; f.pro_masked = 0; }
         else {
-            if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }      // (dcl is still read by the closing conv's wgrad)
-            bwd_apply(g, 3, io->dcl, 0);
-            dy = io->dcl;
+            float* dst = io->dcl_ds;
+            if (!dst) {          // no buffer of its own: dcl is re-used, and it is still read by the closing conv's weight gradient on the other stream
+                if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
+                dst = io->dcl;
+            }
+            bwd_apply(g, 3, dst, 0);
+            dy = dst;
         }
         if (int32_t e = launch_wgrad(3, dy, io->x, &f, false)) return e;
         if (b->need_dx) {

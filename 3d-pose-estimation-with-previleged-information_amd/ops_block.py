@@ -33,7 +33,7 @@ class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
     _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcl', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
-                ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
+                ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('dcl_ds', _vp)]
 
 
 def _one(v):
@@ -197,6 +197,10 @@ class ResidualBlockFn(torch.autograd.Function):
         gbuf = torch.empty_like(out)
         dcl = torch.empty_like(out)
         io.gbuf, io.dcl = gbuf.data_ptr(), dcl.data_ptr()
+        if d.has_downsample:                                # its BatchNorm's input gradient gets a buffer of its own: no wait for the weight-gradient stream
+            dcl_ds = torch.empty_like(out)
+            keep.append(dcl_ds)
+            io.dcl_ds = dcl_ds.data_ptr()
         for slot, _, _ in layers:
             if slot < d.nconv - 1:
                 da = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)

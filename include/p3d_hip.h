@@ -160,6 +160,7 @@ typedef struct p3d_block_io {
     float* dw[4];
     float* dgamma[4];
     float* dbeta[4];
+    float* dcl_ds;              /* like dcl, for the downsample BatchNorm's input gradient; may be NULL (dcl is re-used then, after a wait for the weight-gradient stream) */
 } p3d_block_io;
 
 /* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 96, four-pixel-aligned rows, stride <= 2) */
