@@ -14,8 +14,8 @@ queues = '\n'.join(l for l in rd('r02_rccl_queues.txt').split('\n') if 'queue' i
 MB = 1.0 / 1e6
 s = '''# Round 2 — measurements (MI355X, ROCm 7.2, one GPU per box)
 
-All numbers below were taken through `gpurun`; every block names the command.  Boxes of the pool differ (the final binaries: 1857, 1920, 1934, 1973
-crops/s on four boxes; earlier commits of the round 1804–1918), so A/B comparisons are only made inside one call.
+All numbers below were taken through `gpurun`; every block names the command.  Boxes of the pool differ by +-3 % on the same binary, so A/B comparisons
+are only made inside one call.
 
 ## 1. Contract line (`python bench.py`, defaults: N = 1, 50 timed steps after 10 warm-up steps)
 
@@ -28,8 +28,8 @@ on `v_mfma_f32_32x32x2_f32`, BatchNorm as stand-alone passes) measured in the sa
 
 History of the round on the contract step (each on its own box, so +- 3 %%): 43.7 ms (r01) -> 38.3 (r01 opt-in x3 for the 1x1 layers) -> 36.9 (new x3
 kernels for every dense layer >= 96 channels, per-layer BatchNorm) -> 35.4 (residual-block executor: statistics / sums in the conv epilogues, one call per
-block, RNE split, no SLP packing) -> 33.4 (partial tiles without dead MFMAs, layer1 in the executor, measured weight-gradient slab plan) -> 33.3 / 32.4
-by box (wider finalize kernels, probe-selected weight-gradient stream).
+block, RNE split, no SLP packing) -> 33.4 (partial tiles without dead MFMAs, layer1 in the executor, measured weight-gradient slab plan) -> 33.3 (wider finalize kernels, probe-selected weight-gradient stream) -> 32.3 (no wait of the launch stream for the weight-gradient stream inside a
+block: found in the kernel trace as 69 idle gaps per step, `tools/trace_step.sh`).
 
 Informational lines of the other BASELINE configurations (`bash tools/other_lines.sh`, `r02_other_configs.txt`):
 
@@ -41,7 +41,7 @@ Informational lines of the other BASELINE configurations (`bash tools/other_line
 
 %(tables)s
 
-Reading (serialised table): the x3 conv kernels are 23.4 of the 34.3 kernel-ms of a step (68 %%), the fp32-MFMA kernel 2.1 ms (stem 0.83 + ten 64-channel
+Reading (serialised table): the x3 conv kernels are 23.4 of the 34.4 kernel-ms of a step (68 %%), the fp32-MFMA kernel 2.1 ms (stem 0.83 + ten 64-channel
 weight gradients), everything BatchNorm / ReLU / shortcut 6.5 ms (`bn_bwd_apply` 2.14, `block_open_bwd` 1.70, `block_close_fwd` 1.21, the two finalize
 kernels 0.72, `bn_apply_relu` 0.42, the stem's four stand-alone passes 0.34), split-K / slab reductions 1.2 ms, weight-image rebuild 0.33 ms.
 rocprofv3's per-kernel averages agree with the in-library HIP-event brackets of the bench line (x3 + fp32 conv kernels: 25.5 ms per step here; 26.9 ms in
