@@ -14,7 +14,7 @@ queues = '\n'.join(l for l in rd('r02_rccl_queues.txt').split('\n') if 'queue' i
 MB = 1.0 / 1e6
 s = '''# Round 2 — measurements (MI355X, ROCm 7.2, one GPU per box)
 
-All numbers below were taken through `gpurun`; every block names the command.  Boxes of the pool differ by +-3 % on the same binary, so A/B comparisons
+All numbers below were taken through `gpurun`; every block names the command.  Boxes of the pool differ by +-3 %% on the same binary, so A/B comparisons
 are only made inside one call.
 
 ## 1. Contract line (`python bench.py`, defaults: N = 1, 50 timed steps after 10 warm-up steps)
