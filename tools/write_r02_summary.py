@@ -98,7 +98,10 @@ Tried on top and NOT kept as default (all parity-green, all measured inside one 
   plain loop at three waves (512-channel 3x3 / 1024->2048 1x1 / 256-channel 3x3); forced to three waves it spills (0.838 ms);
 * the weight gradient on `v_mfma_f32_16x16x32_bf16` (two piece products per instruction, `-DP3D_FX_WGRAD_MFMA16=1`): -4 ... +7 %% by layer, +-0 over a step;
 * a 64 x 64-tile x3 weight-gradient kernel for the 64-channel layers: 60-80 TF against the fp32-MFMA kernel's 80-90 TF;
-* operand-fetch BatchNorm fusion (`P3D_BLOCK_FUSE=1`): 49.4 ms against 35.4 ms per step when introduced.
+* operand-fetch BatchNorm fusion (`P3D_BLOCK_FUSE=1`): 49.4 ms against 35.4 ms per step when introduced;
+* handing a block's opening pass to the data-gradient epilogue of the block behind it: +0.35 ms per step (33.98 vs 33.63 ms);
+* rebuilding the weight images on the second stream right after the optimizer step instead of lazily on the forward path: -0.14 ms (32.12 vs 32.26 ms),
+  not worth what it complicates (the join falls outside a captured step).
 
 Weight-gradient slab plan (`python tools/split_sweep.py`, `r02_wgrad_split_sweep.txt`): per layer class, the time at target block counts 256 ... 4096;
 sum over a step: first plan (1024 blocks) 9.05 ms, rule now in `fx_wgrad_splits` 8.0 ms, per-shape optimum 7.8 ms.
