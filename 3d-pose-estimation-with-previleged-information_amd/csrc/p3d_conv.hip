@@ -1119,7 +1119,7 @@ size_t p3d_conv2d_fwd_workspace_bytes(const p3d_conv_desc* d) {
     if (validate(d)) return 0;
     const FwdPlan pl = plan_fwd(d, false, true);
     const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
-    const size_t fx = fx_fwd_applies(d) ? fx_fwd_workspace(d) : 0;
+    const size_t fx = (fx_fwd_applies(d) || fx_fwd_masked_applies(d)) ? fx_fwd_workspace(d) : 0;
     return base > fx ? base : fx;
 }
 
@@ -1132,6 +1132,14 @@ static int32_t conv2d_fwd_impl(const p3d_conv_desc* d, const float* x, const flo
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0) {
         fx_count(0, d);          // exact fp32 on the bf16 matrix pipe (p3d_fx.hip), the default path of the dense layers
         return fx_conv_fwd(d, x, w, bias, y, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+    }
+    if (mask_in && mult && !bias && !ep_scale && !ep_res && !ep_relu && fx_enabled() && fx_fwd_masked_applies(d) && workspace_bytes >= fx_fwd_workspace(d) &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace) |
+          reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mult)) & 15) == 0) {
+        fx_count(0, d);          // partial convolution on the same kernels: x * mask_in in the operand fetch, * mult in the epilogue
+        FxFuse f{};
+        f.pmask = mask_in; f.emask = mult;
+        return fx_conv_fwd(d, x, w, nullptr, y, workspace, workspace_bytes, &f, (hipStream_t)stream);
     }
     fx_count(3, d);
     IgemmParams p = base_params(d);
@@ -1232,12 +1240,12 @@ size_t p3d_conv2d_dgrad_workspace_bytes(const p3d_conv_desc* d) {
     if (d->stride == 1) {
         const FwdPlan pl = plan_dgrad1(d, false);
         const size_t base = weight_image_bytes(d) + (pl.splits > 1 ? (size_t)pl.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
-        const size_t fx = fx_dgrad_applies(d) ? fx_dgrad_workspace(d) : 0;
+        const size_t fx = (fx_dgrad_applies(d) || fx_dgrad_masked_applies(d)) ? fx_dgrad_workspace(d) : 0;
         return base > fx ? base : fx;
     }
     const size_t hc = (size_t)ceil_div(d->H, d->stride), wc = (size_t)ceil_div(d->W, d->stride);
     const size_t staged = (size_t)d->stride * d->stride * d->N * d->C * hc * wc * sizeof(float);
-    const size_t fx = fx_dgrad_applies(d) ? fx_dgrad_workspace(d) : 0;
+    const size_t fx = (fx_dgrad_applies(d) || fx_dgrad_masked_applies(d)) ? fx_dgrad_workspace(d) : 0;
     return staged > fx ? staged : fx;
 }
 
@@ -1252,6 +1260,16 @@ int32_t p3d_conv2d_dgrad(const p3d_conv_desc* d, const float* dy, const float* w
         if (fx_dgrad_has_dead_classes(d) && !d->accumulate)          // input pixels no tap reaches (1x1, stride 2) must read zero
             (void)hipMemsetAsync(dx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), (hipStream_t)stream);
         return fx_conv_dgrad(d, dy, w, dx, workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+    }
+    if (mask_in && mult && fx_enabled() && fx_dgrad_masked_applies(d) && workspace_bytes >= fx_dgrad_workspace(d) &&
+        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace) |
+          reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mult)) & 15) == 0) {
+        fx_count(1, d);          // partial convolution: dy * mult in the operand fetch, * mask_in in the epilogue
+        if (fx_dgrad_has_dead_classes(d) && !d->accumulate)
+            (void)hipMemsetAsync(dx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), (hipStream_t)stream);
+        FxFuse f{};
+        f.pmask = mult; f.emask = mask_in;
+        return fx_conv_dgrad(d, dy, w, dx, workspace, workspace_bytes, &f, (hipStream_t)stream);
     }
     fx_count(4, d);
     IgemmParams p = base_params(d);
@@ -1337,7 +1355,9 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
     ProfScope ps(2, d, (hipStream_t)stream);
     const bool masked = mask_in || mult;
     WgradPlan pl = plan_wgrad(d, masked);
-    const bool fx = !masked && fx_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    const bool fxm = mask_in && mult && fx_enabled() && fx_wgrad_masked_applies(d) &&
+                     ((reinterpret_cast<uintptr_t>(mask_in) | reinterpret_cast<uintptr_t>(mult)) & 15) == 0;          // partial convolution: dy * mult, x * mask_in in the fetch
+    const bool fx = (!masked || fxm) && fx_wgrad_applies(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
     if (fx) { pl.splits = fx_wgrad_splits(d); pl.tapm = d->R * d->S > 1; }      // slabs [split][k][tap][c]: the tap-major columns of wgrad_reduce_tapm_kernel
     fx_count(fx ? 2 : 5, d);
     const size_t need = (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
@@ -1362,7 +1382,11 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
         if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && al16(x) && al16(mask_in)) wv = 2;
     }
     { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
-    if (fx) { if (int32_t e = fx_conv_wgrad_slabs(d, dy, x, (float*)workspace, pl.splits, nullptr, (hipStream_t)stream)) return e; }
+    if (fx) {
+        FxFuse f{};
+        f.pmask = mult; f.emask = mask_in;
+        if (int32_t e = fx_conv_wgrad_slabs(d, dy, x, (float*)workspace, pl.splits, masked ? &f : nullptr, (hipStream_t)stream)) return e;
+    }
     else launch_igemm<MODE_WGRAD>(pl.cfg, pl.tapm, masked, p, pl.splits, (hipStream_t)stream, wv);
     if (int32_t e = check_launch("conv2d_wgrad")) return e;
     return wgrad_finish(d, (float*)workspace, pl.splits, pl.tapm, dw, (hipStream_t)stream);

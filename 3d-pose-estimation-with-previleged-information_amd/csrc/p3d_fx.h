@@ -19,6 +19,8 @@ struct FxConvParams {
     const float* ep_c;      // EPI 2: raw conv output laid out like the result
     const float* ep_tab;    // EPI 2: {sc, sh} per result channel
     float* partial;         // EPI 1 / 2: [rows][M][2] partial sums
+    const float* pmask;     // PRO 4 (partial convolution): per-pixel factor of the activation operand, [N][1][Hi][Wi]
+    const float* emask;     // EPI 4: per-pixel factor of the result, [N][1][YH][YW]
     size_t w_ts;            // elements between two taps of the weight image
     size_t slab_stride;     // elements between two split-K slabs
     int w_ld;
@@ -36,6 +38,8 @@ struct FxConvParams {
 };
 
 struct FxWgradParams {
+    const float* amask;     // PA 4: per-output-pixel factor of dy, [N][1][OH][OW]
+    const float* bmask;     // PB 2: per-input-pixel factor of x, [N][1][Hi][Wi]
     const float* DY;        // [N][K][OH][OW]
     const float* DY2;       // PA 2 / 3: the raw conv output beside DY
     const float* X;         // [N][C][Hi][Wi]
@@ -56,6 +60,8 @@ struct FxFuse {
     float* partial;         // FWD: partial sums of y, y^2;  DGRAD: partial sums of g, g * ep_c
     const float* ep_c;      // DGRAD epilogue: raw conv output laid out like dx
     const float* ep_tab;    // DGRAD epilogue: table of the BN ep_c went through
+    const float* pmask;     // partial convolution (partial_conv.py:32-57): factor of the activation operand per pixel (FWD: mask_in, DGRAD: mult; WGRAD: mult for dy)
+    const float* emask;     //   and of the result per pixel (FWD: mult, DGRAD: mask_in; WGRAD: mask_in for x).  Both or neither.
     const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: split the fp32 weights on the fly
 };
 constexpr int FX_TAB = 8;   // floats per channel of a table
@@ -79,6 +85,9 @@ bool fx_fwd_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d);
+bool fx_fwd_masked_applies(const p3d_conv_desc* d);          // partial convolutions: the masked instances exist for unsplit launches without bias
+bool fx_dgrad_masked_applies(const p3d_conv_desc* d);
+bool fx_wgrad_masked_applies(const p3d_conv_desc* d);
 size_t fx_image_bytes(const p3d_conv_desc* d);
 size_t fx_fwd_workspace(const p3d_conv_desc* d);
 size_t fx_dgrad_workspace(const p3d_conv_desc* d);

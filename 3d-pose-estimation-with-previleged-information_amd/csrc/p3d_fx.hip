@@ -138,8 +138,9 @@ __device__ __forceinline__ int fx_live_subtiles(int first, int limit) {
 // Every BatchNorm layer owns one table of 8 floats per channel: {sc, sh, mean, invstd, A, B, K, 0} (sc = gamma * invstd, sh = beta - mean * sc: written
 // by the forward finalize; A, B, K: the backward map d c = A * g + B * c + K, written by the backward finalize).
 // PRO: 0 none; 1 relu(x * sc + sh) per reduction channel; 2 A * (mask ? g : 0) + B * c + K per reduction channel with mask = (c * sc + sh > 0)
-//      (X = g, X2 = c); 3 the same without the mask (A * g + B * c + K)
-// EPI: 0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2; 2 store + partial sums of g, g * (c2 - mean) with g = y * [c2 * sc + sh > 0]
+//      (X = g, X2 = c); 3 the same without the mask (A * g + B * c + K); 4 x * pmask[pixel] (partial convolution: one factor per pixel, all channels)
+// EPI: 4 store y * emask[pixel] (partial convolution);
+//      0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2; 2 store + partial sums of g, g * (c2 - mean) with g = y * [c2 * sc + sh > 0]
 //      (ep_c = c2 laid out like the output, ep_tab = its BatchNorm's table); under split-K the epilogue work is done by fx_reduce_kernel instead
 // Operand fetches are buffer loads against block-uniform resources: per-thread byte offsets change only when the filter tap changes (they carry the
 // out-of-range bit 0x80000000 for padding pixels / rows beyond the tensor, which the resource's range check turns into zeros), the per-K-step part of an
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     const int col = n0 + 4 * tp4;
     const bool col_ok = col < p.NP;
     const int nfirst = n0 / OHW;                   // first image this block touches: base of the activation resources
-    int hbase = 0, wbase = 0, img_off = 0;
+    int hbase = 0, wbase = 0, img_off = 0, mimg_off = 0;
     {
         const int cc = col_ok ? col : 0;
         const int pn = cc / OHW;
@@ -207,11 +208,13 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
         hbase = oh * p.hmul + p.hoff;
         wbase = ow * p.wmul + p.woff;
         img_off = ((pn - nfirst) * p.Cred + trow) * HWi;
+        mimg_off = (pn - nfirst) * HWi;                 // PRO 4: the per-pixel factor has one plane per image
     }
     const size_t act_left = (size_t)(p.N - nfirst) * p.Cred * HWi * sizeof(float);
     const i32x4 rX = fx_rsrc(p.X + (size_t)nfirst * p.Cred * HWi, act_left);
-    const i32x4 rX2 = fx_rsrc(PRO >= 2 ? p.X2 + (size_t)nfirst * p.Cred * HWi : nullptr, PRO >= 2 ? act_left : 0);
-    const i32x4 rT = fx_rsrc(PRO >= 1 ? p.tab : nullptr, PRO >= 1 ? (size_t)p.Cred * FX_TAB * sizeof(float) : 0);
+    const i32x4 rX2 = fx_rsrc((PRO == 2 || PRO == 3) ? p.X2 + (size_t)nfirst * p.Cred * HWi : nullptr, (PRO == 2 || PRO == 3) ? act_left : 0);
+    const i32x4 rT = fx_rsrc((PRO >= 1 && PRO <= 3) ? p.tab : nullptr, (PRO >= 1 && PRO <= 3) ? (size_t)p.Cred * FX_TAB * sizeof(float) : 0);
+    const i32x4 rPM = fx_rsrc(PRO == 4 ? p.pmask + (size_t)nfirst * HWi : nullptr, PRO == 4 ? (size_t)(p.N - nfirst) * HWi * sizeof(float) : 0);
     const int csteps = p.Cred / FX_BK;
     int nk = p.ntap * csteps, kt0 = 0;
     if (p.kchunk > 0) {                            // split-K: this block reduces K steps [kt0, kt0 + nk) into slab blockIdx.y
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     bool x_vec = false;
     int w_tapoff = 0;                                      // scalar byte offset of the tap inside the weight operand
     int cur_tap = -1;
+    f32x4 tmask = {1.f, 1.f, 1.f, 1.f};                    // PRO 4: the factor of this thread's four pixels at the current tap (the same for every K step of the tap)
     auto set_tap = [&](int tap) {
         cur_tap = tap;
         const int ir = tap / p.nS, is = tap - ir * p.nS;
@@ -259,11 +263,20 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
             x_voff[e] = ok ? base + e * p.wmul * 4 : FX_OOB;
         }
+        if constexpr (PRO == 4) {
+            const int mbase = (mimg_off + hi * p.Wi + wi0) * 4;
+            if (x_vec) tmask = fx_buffer_load_f32x4(rPM, x_voff[0] >= 0 ? mbase : FX_OOB, 0, 0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tmask[e] = fx_buffer_load_f32(rPM, x_voff[e] >= 0 ? mbase + e * p.wmul * 4 : FX_OOB, 0, 0);
+            }
+        }
     };
 
     f32x4 rw[2], rx[2], rx2[2];
     i32x4 rwi[3];                                  // WMODE 2: this thread's three 16-B chunks of the K step's weight image
     f32x4 rtab[2][2];                              // PRO constants of this thread's two reduction rows
+    f32x4 smask = {1.f, 1.f, 1.f, 1.f};            // PRO 4: per-pixel factor of the fetched K step
     int rvoff[4];                                  // validity of the fetched pixels (the offsets they were fetched with): staged as zeros after a PRO map
     auto fetch = [&]() {
         if (f_tap != cur_tap) { asm volatile("" ::: "memory"); set_tap(f_tap); }       // (a real, wave-uniform branch: taken once per tap, not if-converted into every K step)
@@ -285,19 +298,20 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             const int so = (f_k + 8 * i) * HWi * 4;                 // wave-uniform: reduction chunk + this pass's 8-row step
             if (x_vec) {
                 rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], FX_SO(so), 0);
-                if constexpr (PRO >= 2) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], FX_SO(so), 0);
+                if constexpr (PRO == 2 || PRO == 3) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], FX_SO(so), 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], FX_SO(so), 0);
-                    if constexpr (PRO >= 2) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], FX_SO(so), 0);
+                    if constexpr (PRO == 2 || PRO == 3) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], FX_SO(so), 0);
                 }
             }
             if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = fx_buffer_load_f32x4(rT, trow * 32, FX_SO((f_k + 8 * i) * 32), 0);           // {sc, sh, mean, invstd}
-            if constexpr (PRO >= 2) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, FX_SO((f_k + 8 * i) * 32), 0);                // {A, B, K, 0}
+            if constexpr (PRO == 2 || PRO == 3) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, FX_SO((f_k + 8 * i) * 32), 0);                // {A, B, K, 0}
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) rvoff[e] = x_vec ? x_voff[0] : x_voff[e];
+        if constexpr (PRO == 4) smask = tmask;            // (the factor of the tap these loads belong to: the next fetch may already be at another tap)
         f_k += FX_BK;
         if (f_k == p.Cred) { f_k = 0; ++f_tap; }
     };
@@ -330,6 +344,10 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             if constexpr (PRO == 3) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rvoff[e] >= 0 ? fmaf(rtab[i][0][0], rx[i][e], fmaf(rtab[i][0][1], rx2[i][e], rtab[i][0][2])) : 0.f;
+            }
+            if constexpr (PRO == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= smask[e];
             }
             fx_split_store(pb + st_p[i], v);
         }
@@ -428,10 +446,19 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                     const size_t o = split ? ((size_t)n * p.M + m) * OHW + rem
                                            : (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow;
                     f32x4* dst = reinterpret_cast<f32x4*>(yout + o);
+                    if constexpr (EPI == 4) {           // partial convolution: the result times the per-pixel factor (before it joins an existing gradient)
+                        const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow);
+                        v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
+                    }
                     if (!split && p.accumulate) { const f32x4 o4 = *dst; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
                     *dst = v;
                 } else {
                     float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+                    if constexpr (EPI == 4) {
+                        const float* em = p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= em[e * p.oxs];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dst[e * p.oxs] = p.accumulate ? dst[e * p.oxs] + v[e] : v[e];
                 }
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 }
             }
         }
-    if constexpr (EPI != 0) {
+    if constexpr (EPI >= 1 && EPI <= 3) {
         if (!split) {
             // the two half-waves hold different pixels of the same channels; then the two waves along the pixel axis
 #pragma unroll
@@ -525,6 +552,7 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // Both operands are contiguous along the reduction (pixel) index; a K step is 16 consecutive output pixels of one image (OHW % 16 == 0), a thread fetches
 // 4 of them for two rows of each operand.  grid (C tiles, K tiles, taps * splits); slabs [split][k][tap][c] ("tap-major columns", what
 // wgrad_reduce_tapm_kernel of p3d_conv.hip sums and transposes) or, for 1x1, [split][k][c].
+// PA: 4 dy * amask[output pixel], PB: 2 x * bmask[input pixel] (partial convolution);
 // PA: 0 none; 2 / 3 the BatchNorm-backward map of fx_conv_kernel on dy (per row k: constants live in registers; DY2 = the raw conv output c)
 // PB: 0 none; 1 relu(x * sc + sh) per row c
 template <int PA, int PB>
@@ -547,7 +575,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         atab[i][0] = atab[i][1] = btab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (PA >= 2) {
+        if constexpr (PA == 2 || PA == 3) {
             if (a_ok[i]) {
                 atab[i][0] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i) + 4);      // {A, B, K, 0}
                 atab[i][1] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i));          // {sc, sh, mean, invstd}
@@ -560,7 +588,9 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
     // pixel position of the K step in a wave-uniform scalar offset.  (fx_common bounds every tensor below 2^31 elements; the resources are cut to 2 GiB.)
     const i32x4 rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
-    const i32x4 rA2 = fx_rsrc(PA >= 2 ? p.DY2 : nullptr, PA >= 2 ? (size_t)p.N * p.K * OHW * sizeof(float) : 0);
+    const i32x4 rA2 = fx_rsrc((PA == 2 || PA == 3) ? p.DY2 : nullptr, (PA == 2 || PA == 3) ? (size_t)p.N * p.K * OHW * sizeof(float) : 0);
+    const i32x4 rAM = fx_rsrc(PA == 4 ? p.amask : nullptr, PA == 4 ? (size_t)p.N * OHW * sizeof(float) : 0);
+    const i32x4 rBM = fx_rsrc(PB == 2 ? p.bmask : nullptr, PB == 2 ? (size_t)p.N * HWi * sizeof(float) : 0);
     const i32x4 rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
     int a_voff[2];
 #pragma unroll
@@ -571,6 +601,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // Two register sets for fetched tiles: the plain variant (PA == 0 && PB == 0, what the residual-block executor launches by default) keeps the loads of
     // TWO K steps in flight and splits step kt + 1 while the matrix pipe works on step kt; the others use set 0 only, one step ahead.
     f32x4 ra[2][2], ra2[2][2], rb[2][2];
+    f32x4 ram[2], rbm[2];        // PA 4 / PB 2: the per-pixel factors of the fetched K step (one value per pixel, whatever the row)
     int b_voff[2][4] = {{FX_OOB, FX_OOB, FX_OOB, FX_OOB}, {FX_OOB, FX_OOB, FX_OOB, FX_OOB}};
     int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
     const bool rowwise = (p.OW & (FX_BK - 1)) == 0;        // uniform: a K step never straddles two output rows
@@ -582,8 +613,9 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             ra[Q][i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
-            if constexpr (PA >= 2) ra2[Q][i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
+            if constexpr (PA == 2 || PA == 3) ra2[Q][i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
         }
+        if constexpr (PA == 4) ram[Q] = fx_buffer_load_f32x4(rAM, 16 * kq, (f_img * OHW + f_p) * 4, 0);
         int b_so = f_img * p.C * HWi * 4;
         if (simple) {
             b_so += f_p * 4;
@@ -618,6 +650,14 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
                 for (int e = 0; e < 4; ++e) rb[Q][i][e] = fx_buffer_load_f32(rB, b_voff[Q][e] | rowbad, FX_SO(so), 0);
             }
         }
+        if constexpr (PB == 2) {        // the factor at the four input pixels: the x offsets without the channel row
+            const int mso = b_so - f_img * (p.C - 1) * HWi * 4;
+            if (vec) rbm[Q] = fx_buffer_load_f32x4(rBM, b_voff[Q][0] >= 0 ? b_voff[Q][0] - b_row * 4 : FX_OOB, mso, 0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rbm[Q][e] = fx_buffer_load_f32(rBM, b_voff[Q][e] >= 0 ? b_voff[Q][e] - b_row * 4 : FX_OOB, mso, 0);
+            }
+        }
         f_p += FX_BK;
         if (f_p == OHW) { f_p = 0; ++f_img; }
     };
@@ -642,6 +682,14 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
             if constexpr (PB == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && (vec ? b_voff[Q][0] : b_voff[Q][e]) >= 0) ? fmaxf(fmaf(rb[Q][i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
+            }
+            if constexpr (PA == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) va[e] *= ram[Q][e];
+            }
+            if constexpr (PB == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vb[e] *= rbm[Q][e];
             }
             fx_split_store(As + buf * 3 * FX_PIECE + st_off[i], va);
             fx_split_store(Bs + buf * 3 * FX_PIECE + st_off[i], vb);
@@ -678,7 +726,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
-    constexpr bool PIPE = PA == 0 && PB == 0 && FX_WGRAD_PIPE;
+    constexpr bool PIPE = PA == 0 && PB == 0 && FX_WGRAD_PIPE;        // (the masked and the fused variants use set 0 only)
     if (nk > 0) { fetch(Q0{}); stage(Q0{}, 0); }
     if (PIPE && nk > 1) fetch(Q1{});
     __syncthreads();
@@ -864,6 +912,11 @@ static FxSplit fx_dgrad_split(const p3d_conv_desc* d) {
     if (d->stride != 1) return FxSplit{1, 0};
     return fx_plan_split(ceil_div(d->C, FX_BM) * ceil_div((int64_t)d->N * d->H * d->W, FX_BN), d->R * d->S * (d->K / FX_BK));
 }
+// partial convolutions (PRO 4 / EPI 4 instances): 64-channel layers included (half-dead tiles), unsplit launches only
+static bool fx_masked_on() { static const bool on = [] { const char* e = getenv("P3D_FX_MASKED"); return !(e && atoi(e) == 0); }(); return on; }      // A/B switch
+bool fx_fwd_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_fwd_applies(d, 64) && fx_fwd_split(d).splits == 1; }
+bool fx_dgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_dgrad_applies(d, 64) && (d->stride != 1 || fx_dgrad_split(d).splits == 1); }
+bool fx_wgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_wgrad_applies(d, 96); }
 size_t fx_fwd_workspace(const p3d_conv_desc* d) {
     const FxSplit s = fx_fwd_split(d);
     return fx_image_bytes(d) + (s.splits > 1 ? (size_t)s.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
@@ -938,8 +991,8 @@ int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_f
 template <int WMODE>
 static void fx_launch_conv(const FxConvParams& p, int pro, int epi, dim3 grid, hipStream_t st) {
 #define P3D_FX_CASE(PRO, EPI) if (pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<WMODE, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
-    if constexpr (WMODE == 0) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) }
-    else if constexpr (WMODE == 1) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
+    if constexpr (WMODE == 0) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) P3D_FX_CASE(4, 4) }
+    else if constexpr (WMODE == 1) { P3D_FX_CASE(4, 4) P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
     else { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(0, 2) }       // image mode: the block executor's default (BatchNorm apply as passes of its own)
 #undef P3D_FX_CASE
 }
@@ -954,7 +1007,11 @@ static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* sl
 // y = conv(pro(x), w) (+ bias); fuse may be null (plain convolution)
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st) {
-    const void* wimg = (fuse && !fuse->pro_tab) ? fuse->wimg : nullptr;
+    const bool masked = fuse && fuse->pmask;
+    const void* wimg = (fuse && !fuse->pro_tab && !masked) ? fuse->wimg : nullptr;
+    if (masked && (!fuse->emask || bias || fuse->pro_tab || fuse->partial || fx_fwd_split(d).splits > 1)) {
+        set_error("fx_conv_fwd: the partial-convolution instance takes both factors, no bias and an unsplit launch"); return P3D_EINVAL;
+    }
     const size_t need = fx_fwd_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
@@ -977,6 +1034,7 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     if (fuse) {
         if (fuse->pro_tab) { pro = 1; p.tab = fuse->pro_tab; }
         if (fuse->partial) { epi = 1; p.partial = fuse->partial; }
+        if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     p.tiles_m = (int)ceil_div(d->K, FX_BM);
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
@@ -998,7 +1056,11 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
 // dx (=|+=) dgrad(pro(dy), w); strided: one launch per parity class of the input, written straight into dx
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,
                       hipStream_t st) {
-    const void* wimg = (fuse && !fuse->pro_tab) ? fuse->wimg : nullptr;
+    const bool masked = fuse && fuse->pmask;
+    const void* wimg = (fuse && !fuse->pro_tab && !masked) ? fuse->wimg : nullptr;
+    if (masked && (!fuse->emask || fuse->pro_tab || fuse->partial || (d->stride == 1 && fx_dgrad_split(d).splits > 1))) {
+        set_error("fx_conv_dgrad: the partial-convolution instance takes both factors and an unsplit launch"); return P3D_EINVAL;
+    }
     const size_t need = fx_dgrad_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
@@ -1020,6 +1082,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     if (fuse) {
         if (fuse->pro_tab) { pro = fuse->pro_masked ? 2 : 3; p.tab = fuse->pro_tab; p.X2 = fuse->pro_c; }
         if (fuse->partial) { epi = 2; p.partial = fuse->partial; p.ep_c = fuse->ep_c; p.ep_tab = fuse->ep_tab; }
+        if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     p.tiles_m = (int)ceil_div(d->C, FX_BM);
     if (d->stride == 1) {
@@ -1042,7 +1105,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         return check_launch("fx_conv_dgrad");
     }
     // stride 2: input pixel (ph + 2 i, pw + 2 j) of class (ph, pw) gathers dy at (i + off0 - ir * offstep, ...) over the taps r = r0 + rstep * ir that reach it
-    if (epi != 0) { set_error("fx_conv_dgrad: the BatchNorm-backward epilogue is not available for strided data gradients"); return P3D_EINVAL; }
+    if (epi != 0 && epi != 4) { set_error("fx_conv_dgrad: the BatchNorm-backward epilogue is not available for strided data gradients"); return P3D_EINVAL; }
     const int st2 = d->stride;
     p.OH = d->H / st2; p.OW = d->W / st2; p.NP = d->N * p.OH * p.OW; p.oys = st2; p.oxs = st2;
     p.hmul = 1; p.wmul = 1;
@@ -1061,7 +1124,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
             c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
             c.oy0 = ph; c.ox0 = pw;
             if (wimg) fx_launch_conv<2>(c, 0, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
-            else fx_launch_conv<1>(c, pro, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            else fx_launch_conv<1>(c, pro, epi, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
         }
     (void)any_dead;      // classes no tap reaches keep what dx held: the caller zero-fills dx first unless it accumulates (p3d_conv2d_dgrad does)
     return check_launch("fx_conv_dgrad");
@@ -1106,10 +1169,14 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     if (fuse) {
         if (fuse->pro_tab) { pa = fuse->pro_masked ? 2 : 3; p.atab = fuse->pro_tab; p.DY2 = fuse->pro_c; }
         if (fuse->x_tab) { pb = 1; p.btab = fuse->x_tab; }
+        if (fuse->pmask) {
+            if (pa != 0 || pb != 0 || !fuse->emask) { set_error("fx_conv_wgrad: the partial-convolution instance takes both factors and plain operands"); return P3D_EINVAL; }
+            pa = 4; pb = 2; p.amask = fuse->pmask; p.bmask = fuse->emask;
+        }
     }
     const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
 #define P3D_FX_WCASE(PA, PB) if (pa == PA && pb == PB) hipLaunchKernelGGL((fx_wgrad_kernel<PA, PB>), grid, dim3(256), 0, st, p);
-    P3D_FX_WCASE(0, 0) P3D_FX_WCASE(0, 1) P3D_FX_WCASE(2, 0) P3D_FX_WCASE(2, 1) P3D_FX_WCASE(3, 0) P3D_FX_WCASE(3, 1)
+    P3D_FX_WCASE(0, 0) P3D_FX_WCASE(4, 2) P3D_FX_WCASE(0, 1) P3D_FX_WCASE(2, 0) P3D_FX_WCASE(2, 1) P3D_FX_WCASE(3, 0) P3D_FX_WCASE(3, 1)
 #undef P3D_FX_WCASE
     return check_launch("fx_conv_wgrad");
 }
