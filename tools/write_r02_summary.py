@@ -37,6 +37,9 @@ Informational lines of the other BASELINE configurations (`bash tools/other_line
 %(other)s
 ```
 
+Partial convolutions on the x3 kernels (same box, `P3D_FX_MASKED=0` = the fp32-MFMA `MASKED` kernels; lean bench, 20 timed steps), measured after the
+table above: partial_depthnet R50 bs 64 1835 vs 1770 crops/s (34.87 vs 36.17 ms), partial_fusionnet R50 bs 32 1140 vs 1120 crops/s (28.07 vs 28.58 ms).
+
 ## 2. Kernel tables (`bash tools/profile_r02.sh`: rocprofv3 --kernel-trace --stats, csv; raw files `r02_serial_kernel_stats.csv`, `r02_overlap_kernel_stats.csv`)
 
 %(tables)s
