@@ -1,12 +1,17 @@
 // One residual block (BasicBlock / Bottleneck: depthnet.py:10-56,59-116 and the twins in resnet.py / fusionnet.py) per C-ABI call, training mode:
 // forward and backward of   conv -> BN -> ReLU -> conv -> BN -> ReLU [-> conv -> BN] -> (+ identity | downsample conv -> BN) -> [ReLU]
-// with the BatchNorm layers between two convolutions folded into those convolutions (p3d_fx.hip) and everything that used to be host work of the
-// Python autograd wrappers (workspace carving, the second stream of the weight gradients and its events, the gradient join at the block input)
-// done here: one call instead of ~12 per direction.
+// with the statistics / backward sums of the BatchNorm layers produced in the convolutions' epilogues (p3d_fx.hip) and everything that used to be host
+// work of the Python autograd wrappers (workspace carving, the second stream of the weight gradients and its events, the gradient join at the block
+// input) done here: one call instead of ~12 per direction.
 //
-// HBM passes that remain BatchNorm's own, per block: forward, one pass that closes the block (out = act(bn(c_last) + shortcut): reads c_last and the
-// shortcut, writes out); backward, one pass that opens it (g = dout * [out > 0] plus the channel sums of the closing BN and of the downsample BN).
-// Everything else rides in a convolution's operand fetch or epilogue.
+// Tensors produced inside the block and consumed only by convolutions -- a_i = relu(bn_i(c_i)) and d c_i = the BatchNorm-backward map of the incoming
+// gradient -- exist only as pre-split activation images (fx_act_image: three bf16 planes, hi + mid + lo == the fp32 value): the pass that applies the
+// BatchNorm map writes them once (6 B per element instead of 4), and the two or three kernels that read them stage them into LDS with 16-B copies
+// instead of splitting every value again per channel tile and filter tap.  The block input x and the gradients that leave a data gradient stay fp32.
+//
+// HBM passes that are BatchNorm's own, per block: forward, per inner layer the image pass (reads c_i, writes the image of a_i) and one pass that closes
+// the block (out = act(bn(c_last) + shortcut)); backward, one pass that opens it (g = dout * [out > 0] plus the channel sums of the closing BN and of
+// the downsample BN) and per layer the image pass of d c_i (reads g and c_i).
 #include "p3d_common.h"
 #include "p3d_fx.h"
 #include <vector>
@@ -18,15 +23,16 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 constexpr int CLOSE_MAX_SPLIT = 64;
 constexpr int FIN_CH = 16, FIN_MAX_LANES = 64;  // finalize kernels: a block sums 16 channels with blockDim / 16 row lanes each (16 lanes, or 64 when there are many rows)
 static inline unsigned fin_threads(int rows) { return rows > 64 ? 1024u : 256u; }
-// channel counts below 96 leave the 128-row tile of the x3 kernels too empty (64-channel layers measured 72-82 TF there against 88-99 TF on the fp32-MFMA
-// kernel, weight gradient 37 against 80): blocks with such layers (ResNet layer1) stay on the per-layer path
-constexpr int BLOCK_MIN_M = 96;        // a weight gradient takes the x3 kernel from 96 channels on both sides; below that (64-channel layer1) the fp32-MFMA one (p3d_conv2d_wgrad)
-constexpr int BLOCK_MIN_M_CONV = 64;   // forward / data gradient: half-filled 128-row tiles issue no MFMAs for their dead half (fx_live_subtiles)
-static int fuse_mode();
-// which convolutions the executor takes: mode 1 (BatchNorm inside the operand fetch) needs the x3 kernels everywhere
-static bool block_conv_ok(const p3d_conv_desc* d) {
-    if (fuse_mode() == 1) return fx_fwd_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M);
-    return fx_fwd_applies(d, BLOCK_MIN_M_CONV) && fx_dgrad_applies(d, BLOCK_MIN_M_CONV) && (d->Ho * d->Wo) % 4 == 0;
+// forward / data gradient / weight gradient from 64 channels up: half-filled 128-row tiles issue no MFMAs for their dead half (fx_live_subtiles), and
+// image-fed kernels spend nothing on staging them
+constexpr int BLOCK_MIN_M = 64;
+// which convolutions the executor takes.  Every operand that is produced inside the block travels as a pre-split activation image, so all three passes of
+// every convolution must be on the x3 kernels (there is no fp32 copy of a_i / d c_i for another kernel to read).  A main-chain convolution whose strided
+// data gradient leaves input pixels untouched (1x1, stride 2: fx_dgrad_has_dead_classes) is refused: its gradient buffer is not zero-filled here (the
+// reference's blocks put the stride on the 3x3; the strided 1x1 of a downsample branch ADDS onto a gradient that is already complete).
+static bool block_conv_ok(const p3d_conv_desc* d, bool main_chain) {
+    return fx_fwd_applies(d, BLOCK_MIN_M) && fx_dgrad_applies(d, BLOCK_MIN_M) && fx_wgrad_applies(d, BLOCK_MIN_M) && (d->Ho * d->Wo) % 4 == 0 &&
+           (d->H * d->W) % 4 == 0 && d->C % 16 == 0 && d->K % 16 == 0 && !(main_chain && fx_dgrad_has_dead_classes(d));
 }
 
 __device__ __forceinline__ void blk_sum3(double& a, double& b, double& c, double* red /*[12]*/) {
@@ -206,56 +212,6 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
     }
 }
 
-// a = relu(c * sc + sh): the BatchNorm + ReLU between two convolutions as a pass of its own (p3d_block mode 0; the statistics still come from the
-// producing conv's epilogue).  Same grid as the closing pass.
-__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ c, const float* __restrict__ tab, float* __restrict__ a, int N, int C, int HW) {
-    const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
-    const float sc = tab[ch * FX_TAB], sh = tab[ch * FX_TAB + 1];
-    for (int n = s; n < N; n += split) {
-        const size_t off = ((size_t)n * C + ch) * HW;
-        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
-        f32x4* av = reinterpret_cast<f32x4*>(a + off);
-        for (int i = threadIdx.x; i < HW / 4; i += 256) {
-            f32x4 q = cv[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = fmaxf(fmaf(q[e], sc, sh), 0.f);
-            av[i] = q;
-        }
-    }
-}
-
-// d c = A * (masked ? g * [c * sc + sh > 0] : g) + B * c + K: the BatchNorm backward as a pass of its own (p3d_block mode 0; its channel sums still come
-// from the consuming conv's dgrad epilogue / the block-opening pass).  dc may alias g.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* g, const float* __restrict__ c, const float* __restrict__ tab, float* dc, int N, int C,
-                                                           int HW, int masked) {
-    const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
-    const float sc = tab[ch * FX_TAB], sh = tab[ch * FX_TAB + 1], A = tab[ch * FX_TAB + 4], B = tab[ch * FX_TAB + 5], K = tab[ch * FX_TAB + 6];
-    for (int n = s; n < N; n += split) {
-        const size_t off = ((size_t)n * C + ch) * HW;
-        const f32x4* gv = reinterpret_cast<const f32x4*>(g + off);
-        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
-        f32x4* dv = reinterpret_cast<f32x4*>(dc + off);
-        for (int i = threadIdx.x; i < HW / 4; i += 256) {
-            f32x4 q = gv[i];
-            const f32x4 x = cv[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gg = (!masked || fmaf(x[e], sc, sh) > 0.f) ? q[e] : 0.f;
-                q[e] = fmaf(A, gg, fmaf(B, x[e], K));
-            }
-            dv[i] = q;
-        }
-    }
-}
-
-// 0 (default): BatchNorm apply / backward-apply as passes of their own, statistics and sums in the conv epilogues; 1: everything in the conv operand
-// fetch (PRO variants of p3d_fx.hip).  The x3 kernels are bound by their staging VALU work, not by the matrix pipe, so the fetch-side arithmetic of mode 1
-// costs more conv time than the passes it removes (measured: DESIGN.md section 3); it is kept for when the kernels have VALU slack.
-static int fuse_mode() {
-    static const int m = [] { const char* e = getenv("P3D_BLOCK_FUSE"); return e ? atoi(e) : 0; }();
-    return m;
-}
-
 static int close_split(int N, int C) {
     int split = (int)ceil_div(2048, C);
     if (split > N) split = N;
@@ -298,9 +254,8 @@ static int32_t check_block(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        P3D_REQUIRE(block_conv_ok(d),
+        P3D_REQUIRE(block_conv_ok(d, i < 3),
                     "block: convolution %d (C=%d K=%d %dx%d stride %d, %dx%d input) is outside the fused path", i, d->C, d->K, d->R, d->S, d->stride, d->H, d->W);
-        P3D_REQUIRE((d->Ho * d->Wo) % 4 == 0, "block: conv %d output rows are not 16-B groups", i);
     }
     return P3D_OK;
 }
@@ -316,7 +271,7 @@ int32_t p3d_block_supported(const p3d_block_desc* b) {
     for (int i = 0; i < 4; ++i) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
-        if (!block_conv_ok(d)) return 0;
+        if (!block_conv_ok(d, i < 3)) return 0;
     }
     return 1;
 }
@@ -337,7 +292,7 @@ int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, s
         const size_t open = (size_t)d->K * CLOSE_MAX_SPLIT * 3 * sizeof(double), open2 = (size_t)d->C * CLOSE_MAX_SPLIT * 3 * sizeof(double);
         if (open > part) part = open;
         if (open2 > part) part = open2;
-        const size_t slabs = fx_wgrad_applies(d, BLOCK_MIN_M) ? (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float) : p3d_conv2d_wgrad_workspace_bytes(d);
+        const size_t slabs = (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
         if (slabs > sw) sw = slabs;
     }
     if (main_bytes) *main_bytes = align256(mw) + align256(part);
@@ -361,32 +316,28 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     }
     conv_ws = align256(conv_ws);
     float* partial = (float*)((char*)workspace + conv_ws);
-    const float* in = io->x;
-    const bool fused = fuse_mode() == 1;
     for (int i = 0; i < 4; ++i) {
         const bool ds = i == 3;
         if (i >= b->nconv && !(ds && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
         P3D_REQUIRE(io->w[i] && io->c[i] && io->table[i] && io->gamma[i] && io->beta[i], "block_fwd: null tensor of conv %d", i);
+        const bool from_x = ds || i == 0;          // the block input arrives as fp32 (split in the kernel); everything produced inside the block as an image
+        if (!from_x) P3D_REQUIRE(io->aimg[i - 1], "block_fwd: null activation image %d", i - 1);
         FxFuse f{};
-        f.pro_tab = (fused && !ds && i > 0) ? io->table[i - 1] : nullptr;
+        f.act_img = from_x ? nullptr : io->aimg[i - 1];
         f.partial = partial;
         f.wimg = io->wimg[i];
         {
             ProfScope ps(0, d, st);
             fx_count(0, d);
-            if (int32_t e = fx_conv_fwd(d, ds ? io->x : in, io->w[i], nullptr, io->c[i], workspace, conv_ws, &f, st)) return e;
+            if (int32_t e = fx_conv_fwd(d, from_x ? io->x : nullptr, io->w[i], nullptr, io->c[i], workspace, conv_ws, &f, st)) return e;
         }
         hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(fin_threads(fx_partial_rows_fwd(d))), 0, st, (const float*)partial, fx_partial_rows_fwd(d), d->K,
                            (double)d->N * d->Ho * d->Wo, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
-        if (!ds) {
-            in = io->c[i];
-            if (!fused && i < b->nconv - 1) {
-                P3D_REQUIRE(io->a[i], "block_fwd: null activation buffer %d", i);
-                hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(d->K, close_split(d->N, d->K)), dim3(256), 0, st, (const float*)io->c[i], (const float*)io->table[i], io->a[i],
-                                   d->N, d->K, d->Ho * d->Wo);
-                in = io->a[i];
-            }
+        if (!ds && i < b->nconv - 1) {
+            // a_i = relu(bn_i(c_i)), written once, as the image the next convolution (and, in backward, its weight gradient) copies into LDS
+            P3D_REQUIRE(io->aimg[i], "block_fwd: null activation image %d", i);
+            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st)) return e;
         }
     }
     const int last = b->nconv - 1;
@@ -411,9 +362,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         set_error("block_bwd: workspaces %zu / %zu B < required %zu / %zu B", workspace_bytes, side_bytes, need, need_side);
         return P3D_EWORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream, ss = (side_stream && fuse_mode() != 1) ? (hipStream_t)side_stream : st;
-    // (mode 1 keeps every kernel on the launch stream: with its operand-fetch BatchNorm the two-stream step was not bitwise reproducible run to run --
-    //  isolated 32-B sectors of a data gradient differed although the streams share read-only operands only; mode 0 is, see tools/debug_det.py)
+    hipStream_t st = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : st;
     const bool two = ss != st;
     size_t conv_ws = 0;
     for (int i = 0; i < 4; ++i) {
@@ -443,64 +392,50 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     if (int32_t e = check_launch("block_bwd open")) return e;
 
     // 2. the main chain, last conv first.  The gradient that enters conv i is the upstream gradient taken through BN i's backward map (masked by its
-    //    ReLU, except the closing BN whose ReLU went into g already); what leaves it is the gradient w.r.t. the previous ReLU's output.
-    //    mode 0: that map is applied by a pass of its own (in place on da[i]; the closing BN's into io->dcl, because g is still needed), mode 1: inside
-    //    the operand fetch of the dgrad / wgrad kernels.
-    const bool fused = fuse_mode() == 1;
+    //    ReLU, except the closing BN whose ReLU went into g already): d c_i = A g + B c_i + K, written ONCE, as the image both the weight gradient and the
+    //    data gradient of conv i copy into LDS.  What leaves the data gradient is the gradient w.r.t. the previous ReLU's output (fp32, the next g).
+    //    Streams: a weight gradient runs on the second stream behind an event of the launch stream; it reads dcimg[i] and aimg[i - 1] / x, none of which the
+    //    launch stream writes again inside this call, so the launch stream never waits for the second one here.
     const float* gi = g;
-    bool side_used = false;
-    auto bwd_apply = [&](const float* gin, int slot, float* dst, int masked) {
+    auto bwd_map = [&](const float* gin, int slot, int masked) -> int32_t {
         const p3d_conv_desc* dc = &b->conv[slot];
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dc->K, close_split(dc->N, dc->K)), dim3(256), 0, st, gin, (const float*)io->c[slot], (const float*)io->table[slot], dst,
-                           dc->N, dc->K, dc->Ho * dc->Wo, masked);
+        P3D_REQUIRE(io->dcimg[slot], "block_bwd: null gradient image %d", slot);
+        return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st);
     };
-    auto launch_wgrad = [&](int slot, const float* dy, const float* xin, const FxFuse* fw, bool tapm) -> int32_t {
+    auto launch_wgrad = [&](int slot, const float* xin, const void* ximg, bool tapm) -> int32_t {
         const p3d_conv_desc* d = &b->conv[slot];
-        if (two) { if (!order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; } side_used = true; }
-        if (!fx_wgrad_applies(d, BLOCK_MIN_M)) {        // (mode 0 only, see block_conv_ok: the operands are plain tensors here)
-            p3d_conv_desc dw_desc = *d;
-            dw_desc.accumulate = acc;
-            return p3d_conv2d_wgrad(&dw_desc, dy, xin, nullptr, nullptr, io->dw[slot], side_workspace, side_bytes, ss);
-        }
+        if (two && !order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
         ProfScope ps(2, d, ss);
         fx_count(2, d);
+        FxFuse fw{};
+        fw.dy_img = io->dcimg[slot]; fw.x_img = ximg;
         const int splits = fx_wgrad_splits(d);
-        if (int32_t e = fx_conv_wgrad_slabs(d, dy, xin, (float*)side_workspace, splits, fw, ss)) return e;
+        if (int32_t e = fx_conv_wgrad_slabs(d, nullptr, xin, (float*)side_workspace, splits, &fw, ss)) return e;
         p3d_conv_desc dw_desc = *d;
         dw_desc.accumulate = acc;
         return wgrad_finish(&dw_desc, (float*)side_workspace, splits, tapm, io->dw[slot], ss);
     };
-    if (!fused) P3D_REQUIRE(io->dcl, "block_bwd: null buffer for the closing BatchNorm's input gradient");
     for (int i = last; i >= 0; --i) {
         const p3d_conv_desc* d = &b->conv[i];
-        p3d_conv_desc dd = *d;
-        FxFuse f{};
-        const float* dy = gi;                                                 // what the conv kernels read as "dy"
-        f.wimg = io->wimgT[i];
-        if (fused) { f.pro_tab = io->table[i]; f.pro_c = io->c[i]; f.pro_masked = (i != last); }
-        else if (i == last) { bwd_apply(gi, i, io->dcl, 0); dy = io->dcl; }
-        else { bwd_apply(gi, i, io->da[i], 1); dy = io->da[i]; }              // in place: da[i] now holds d c_i
-        // weight gradient: x operand = the previous ReLU's output (mode 1: the previous conv's raw output seen through its BN + ReLU), or the block input
-        {
-            FxFuse fw = f;
-            const float* xin = io->x;
-            if (i > 0) {
-                if (fused) { xin = io->c[i - 1]; fw.x_tab = io->table[i - 1]; }
-                else { P3D_REQUIRE(io->a[i - 1], "block_bwd: null activation buffer %d", i - 1); xin = io->a[i - 1]; }
-            }
-            if (int32_t e = launch_wgrad(i, dy, xin, &fw, d->R * d->S > 1)) return e;
-        }
+        if (int32_t e = bwd_map(gi, i, i != last)) return e;
+        // weight gradient: x operand = the previous ReLU's output (an image written by forward), or the block input (fp32)
+        if (i > 0) P3D_REQUIRE(io->aimg[i - 1], "block_bwd: null activation image %d", i - 1);
+        if (int32_t e = launch_wgrad(i, i > 0 ? nullptr : io->x, i > 0 ? io->aimg[i - 1] : nullptr, d->R * d->S > 1)) return e;
         // data gradient
+        FxFuse f{};
+        f.wimg = io->wimgT[i];
+        f.act_img = io->dcimg[i];
+        p3d_conv_desc dd = *d;
         if (i > 0) {
             const p3d_conv_desc* dp = &b->conv[i - 1];                       // producer of this conv's input
             const bool epi = d->stride == 1;
             if (epi) { f.partial = (float*)partial; f.ep_c = io->c[i - 1]; f.ep_tab = io->table[i - 1]; }
-            dd = *d; dd.accumulate = 0;
+            dd.accumulate = 0;
             P3D_REQUIRE(io->da[i - 1], "block_bwd: null gradient buffer %d", i - 1);
             {
                 ProfScope ps(1, d, st);
                 fx_count(1, d);
-                if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
+                if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
             }
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
             if (epi) {
@@ -516,13 +451,8 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             gi = io->da[i - 1];
         } else if (b->need_dx) {
             // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
-            // the downsample conv's dgrad adds to it below.  The launch stream does NOT wait for the weight-gradient stream here: in the only mode that
-            // runs two streams (mode 0) no weight-gradient kernel reads g -- they read dcl / da[i] and the activations -- so nothing they touch is
-            // written by this launch.  (Round 2 first had a wait here, 69 x ~14 us of idle launch stream per step in the kernel trace.)
-            dd = *d;
+            // the downsample conv's dgrad adds to it below.  No weight-gradient kernel reads g (they read the images), so the launch stream does not wait.
             float* dx;
-            static const bool wait_side = getenv("P3D_BLOCK_WAIT_SIDE") != nullptr;      // the earlier behaviour, for A/B
-            if (wait_side && two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");
@@ -530,32 +460,23 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             }
             ProfScope ps(1, d, st);
             fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
+            if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
         }
     }
     // 3. downsample branch: its BN's backward map applied to g, weight gradient, data gradient added onto dx
     if (b->has_downsample) {
         const p3d_conv_desc* d = &b->conv[3];
-        FxFuse f{};
-        f.wimg = io->wimgT[3];
-        const float* dy = g;
-        if (fused) { f.pro_tab = io->table[3]; f.pro_c = io->c[3]; f.pro_masked = 0; }
-        else {
-            float* dst = io->dcl_ds;
-            if (!dst) {          // no buffer of its own: dcl is re-used, and it is still read by the closing conv's weight gradient on the other stream
-                if (two && side_used && !order_after(st, ss)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
-                dst = io->dcl;
-            }
-            bwd_apply(g, 3, dst, 0);
-            dy = dst;
-        }
-        if (int32_t e = launch_wgrad(3, dy, io->x, &f, false)) return e;
+        if (int32_t e = bwd_map(g, 3, 0)) return e;
+        if (int32_t e = launch_wgrad(3, io->x, nullptr, false)) return e;
         if (b->need_dx) {
+            FxFuse f{};
+            f.wimg = io->wimgT[3];
+            f.act_img = io->dcimg[3];
             p3d_conv_desc dd = *d;
             dd.accumulate = 1;
             ProfScope ps(1, d, st);
             fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, dy, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
+            if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
         }
     }
     return check_launch("block_bwd");
@@ -573,6 +494,61 @@ int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_
 int32_t p3d_fx_weight_images(const float* w, int32_t K, int32_t C, int32_t RS, void* img_fwd, void* img_bwd, void* stream) {
     P3D_REQUIRE(w && img_fwd && img_bwd && K > 0 && C > 0 && RS > 0 && C % 16 == 0 && K % 16 == 0, "weight_images: bad argument");
     return fx_build_weight_images(w, K, C, RS, img_fwd, img_bwd, (hipStream_t)stream);
+}
+
+// Pre-split activation images (csrc/p3d_fx.hip): a fp32 NCHW tensor as three bf16 planes [N][C/16][HW][16], the form in which the x3 kernels take operands
+// without splitting them.  mode 0: the tensor; 1: relu(x * sc + sh); 2: A * (masked ? g * [c * sc + sh > 0] : g) + B * c + K with x = g, x2 = c
+// (table = one BatchNorm layer's [C][8] floats {sc, sh, mean, invstd, A, B, K, 0}).
+size_t p3d_fx_act_image_bytes(int32_t N, int32_t C, int32_t HW) { return (N > 0 && C > 0 && HW > 0) ? fx_act_image_bytes(N, C, HW) : 0; }
+
+int32_t p3d_fx_act_image(int32_t mode, const float* x, const float* x2, const float* table, int32_t masked, void* img, int32_t N, int32_t C, int32_t HW, void* stream) {
+    return fx_act_image(mode, x, x2, table, masked, img, N, C, HW, (hipStream_t)stream);
+}
+
+// The three passes of a convolution with image operands (what p3d_block_* launches inside a block), for callers that hold images of their own.
+// x_img / dy_img: p3d_fx_act_image of the fp32 tensor p3d_conv2d_* would take; wimg: the matching p3d_fx_weight_images image, or NULL (built into the workspace).
+size_t p3d_fx_conv_img_workspace_bytes(const p3d_conv_desc* d, int32_t pass) {
+    if (!d) return 0;
+    if (pass == 0) return fx_fwd_workspace(d);
+    if (pass == 1) return fx_dgrad_workspace(d);
+    return (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
+}
+
+int32_t p3d_fx_conv_fwd_img(const p3d_conv_desc* d, const void* x_img, const float* w, const void* wimg, const float* bias, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(d && x_img && w && y, "fx_conv_fwd_img: null argument");
+    P3D_REQUIRE(fx_fwd_applies(d, 32) && d->C % 16 == 0 && (d->H * d->W) % 4 == 0, "fx_conv_fwd_img: shape outside the x3 kernels");
+    FxFuse f{};
+    f.act_img = x_img; f.wimg = wimg;
+    ProfScope ps(0, d, (hipStream_t)stream);
+    return fx_conv_fwd(d, nullptr, w, bias, y, workspace, workspace_bytes, &f, (hipStream_t)stream);
+}
+
+int32_t p3d_fx_conv_dgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* w, const void* wimgT, float* dx, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    P3D_REQUIRE(d && dy_img && w && dx, "fx_conv_dgrad_img: null argument");
+    P3D_REQUIRE(fx_dgrad_applies(d, 32) && d->K % 16 == 0 && (d->Ho * d->Wo) % 4 == 0, "fx_conv_dgrad_img: shape outside the x3 kernels");
+    FxFuse f{};
+    f.act_img = dy_img; f.wimg = wimgT;
+    ProfScope ps(1, d, (hipStream_t)stream);
+    if (fx_dgrad_has_dead_classes(d) && !d->accumulate)
+        if (hipMemsetAsync(dx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), (hipStream_t)stream) != hipSuccess) { set_error("fx_conv_dgrad_img: memset failed"); return P3D_ELAUNCH; }
+    return fx_conv_dgrad(d, nullptr, w, dx, workspace, workspace_bytes, &f, (hipStream_t)stream);
+}
+
+// x: the fp32 input, used when x_img is NULL (the block input of a residual block); otherwise ignored
+int32_t p3d_fx_conv_wgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* x, const void* x_img, float* dw, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    P3D_REQUIRE(d && dy_img && (x || x_img) && dw, "fx_conv_wgrad_img: null argument");
+    P3D_REQUIRE(fx_wgrad_applies(d, 32) && d->K % 16 == 0 && (!x_img || d->C % 16 == 0), "fx_conv_wgrad_img: shape outside the x3 kernels");
+    const int splits = fx_wgrad_splits(d);
+    const size_t need = (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
+    if (!workspace || workspace_bytes < need) { set_error("fx_conv_wgrad_img: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    FxFuse f{};
+    f.dy_img = dy_img; f.x_img = x_img;
+    ProfScope ps(2, d, (hipStream_t)stream);
+    if (int32_t e = fx_conv_wgrad_slabs(d, nullptr, x, (float*)workspace, splits, &f, (hipStream_t)stream)) return e;
+    return wgrad_finish(d, (float*)workspace, splits, d->R * d->S > 1, dw, (hipStream_t)stream);
 }
 
 // ---- profile of the conv launches made by the executor (and by p3d_conv2d_* when enabled) ---------------------------------------------------------

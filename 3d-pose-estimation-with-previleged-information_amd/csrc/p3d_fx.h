@@ -9,21 +9,18 @@
 namespace p3d {
 
 struct FxConvParams {
-    const float* X;         // activation operand: x (FWD) or dy / the upstream gradient g (DGRAD), [N][Cred][Hi][Wi]
-    const float* X2;        // PRO 2 / 3: the raw conv output c the BatchNorm backward needs beside g, same layout as X
-    const float* W;         // weight operand (see fx_conv_kernel)
-    const unsigned char* Wimg;      // WMODE 2: pre-split weight image
+    const float* X;         // AMODE 0: activation operand, x (FWD) or dy (DGRAD), fp32 [N][Cred][Hi][Wi]
+    const unsigned char* Ximg;      // AMODE 1: the same tensor as a pre-split activation image (fx_act_image): three bf16 planes [N][Cred/16][Hi][Wi][16]
+    size_t plane_bytes;     // AMODE 1: bytes between two planes of Ximg
+    const unsigned char* Wimg;      // pre-split weight image (fx_build_weight_images)
     float* Y;               // result [N][M][YH][YW], or the split-K slabs
     const float* bias;      // [M] or null
-    const float* tab;       // PRO constants per reduction channel
     const float* ep_c;      // EPI 2: raw conv output laid out like the result
-    const float* ep_tab;    // EPI 2: {sc, sh} per result channel
+    const float* ep_tab;    // EPI 2: {sc, sh, mean} per result channel
     float* partial;         // EPI 1 / 2: [rows][M][2] partial sums
     const float* pmask;     // PRO 4 (partial convolution): per-pixel factor of the activation operand, [N][1][Hi][Wi]
     const float* emask;     // EPI 4: per-pixel factor of the result, [N][1][YH][YW]
-    size_t w_ts;            // elements between two taps of the weight image
     size_t slab_stride;     // elements between two split-K slabs
-    int w_ld;
     int N, Cred, Hi, Wi;
     int M, OH, OW, NP;      // the GEMM's pixel grid (for strided dgrad: one parity class of the input) and its size N * OH * OW
     int YH, YW, oy0, ox0, oys, oxs;     // pixel (oh, ow) of the grid is result pixel (oy0 + oh * oys, ox0 + ow * oxs)
@@ -38,31 +35,30 @@ struct FxConvParams {
 };
 
 struct FxWgradParams {
-    const float* amask;     // PA 4: per-output-pixel factor of dy, [N][1][OH][OW]
-    const float* bmask;     // PB 2: per-input-pixel factor of x, [N][1][Hi][Wi]
-    const float* DY;        // [N][K][OH][OW]
-    const float* DY2;       // PA 2 / 3: the raw conv output beside DY
-    const float* X;         // [N][C][Hi][Wi]
+    const float* amask;     // MASKED: per-output-pixel factor of dy, [N][1][OH][OW]
+    const float* bmask;     // MASKED: per-input-pixel factor of x, [N][1][Hi][Wi]
+    const float* DY;        // fp32 [N][K][OH][OW], or
+    const unsigned char* DYimg;     //   its pre-split image [3][N][K/16][OH][OW][16] (AIMG)
+    const float* X;         // fp32 [N][C][Hi][Wi], or
+    const unsigned char* Ximg;      //   its pre-split image [3][N][C/16][Hi][Wi][16] (BIMG)
+    size_t dy_plane, x_plane;       // bytes between two planes of the images
     float* slabs;           // [split][K][taps][C]
-    const float* atab;      // PA constants per output channel k
-    const float* btab;      // PB constants {sc, sh} per input channel c
     int N, K, C, Hi, Wi, OH, OW, R, S, stride, pad, dil;
     int nsplit, spb;        // K steps (16 pixels each) per split
 };
 
-// what a fused launch adds to the plain convolution; null pointers = not used
-// a "table" is one BatchNorm layer's [C][8] floats {sc, sh, mean, invstd, A, B, K, 0} (p3d_fx.hip)
+// what a launch adds to the plain convolution; null pointers = not used
+// a "table" is one BatchNorm layer's [C][8] floats {sc, sh, mean, invstd, A, B, K, 0} (p3d_block.hip)
 struct FxFuse {
-    const float* pro_tab;   // FWD: table of the BN (+ ReLU) applied to x on the fly;  DGRAD / WGRAD: table of the BN whose backward is applied to dy
-    const float* pro_c;     // DGRAD / WGRAD: the raw conv output the BatchNorm backward is taken at
-    int pro_masked;         // DGRAD / WGRAD: 1 = g is masked by (c * sc + sh > 0) first (BN followed by ReLU), 0 = g is used as it is
-    const float* x_tab;     // WGRAD: table of the BN (+ ReLU) applied to x on the fly
-    float* partial;         // FWD: partial sums of y, y^2;  DGRAD: partial sums of g, g * ep_c
+    const void* act_img;    // FWD: pre-split image of x;  DGRAD: pre-split image of dy (fx_act_image).  The fp32 pointer of that operand is ignored then.
+    const void* dy_img;     // WGRAD: pre-split image of dy
+    const void* x_img;      // WGRAD: pre-split image of x
+    float* partial;         // FWD: partial sums of y, y^2;  DGRAD: partial sums of g, g * (ep_c - mean)
     const float* ep_c;      // DGRAD epilogue: raw conv output laid out like dx
     const float* ep_tab;    // DGRAD epilogue: table of the BN ep_c went through
     const float* pmask;     // partial convolution (partial_conv.py:32-57): factor of the activation operand per pixel (FWD: mask_in, DGRAD: mult; WGRAD: mult for dy)
     const float* emask;     //   and of the result per pixel (FWD: mult, DGRAD: mask_in; WGRAD: mask_in for x).  Both or neither.
-    const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: split the fp32 weights on the fly
+    const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: built into the workspace by the call
 };
 constexpr int FX_TAB = 8;   // floats per channel of a table
 
@@ -88,7 +84,6 @@ bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d);
 bool fx_fwd_masked_applies(const p3d_conv_desc* d);          // partial convolutions: the masked instances exist for unsplit launches without bias
 bool fx_dgrad_masked_applies(const p3d_conv_desc* d);
 bool fx_wgrad_masked_applies(const p3d_conv_desc* d);
-size_t fx_image_bytes(const p3d_conv_desc* d);
 size_t fx_fwd_workspace(const p3d_conv_desc* d);
 size_t fx_dgrad_workspace(const p3d_conv_desc* d);
 int fx_partial_rows_fwd(const p3d_conv_desc* d);
@@ -103,5 +98,10 @@ int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm,
 size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd);
 int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st);
 int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, const FxFuse* fuse, hipStream_t st);
+// Pre-split activation images: a fp32 NCHW tensor [N][C][HW] (C % 16 == 0, HW % 4 == 0) as three bf16 planes [N][C/16][HW][16] (hi + mid + lo == value exactly):
+// what the x3 kernels stage into LDS with plain 16-B copies.  mode 0: the tensor itself; 1: relu(x * sc + sh) with the table's constants per channel;
+// 2: A * (masked ? g * [c * sc + sh > 0] : g) + B * c + K (x = g, x2 = c): the BatchNorm-backward map.
+size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);
+int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st);
 
 }  // namespace p3d

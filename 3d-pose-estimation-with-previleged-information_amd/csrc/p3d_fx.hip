@@ -1,31 +1,27 @@
-// Convolution forward / data gradient / weight gradient as exact-fp32 implicit GEMMs on the bf16 matrix pipe of gfx950, with the
-// BatchNorm of the residual blocks folded into them (depthnet.py:40-56,96-116 and the twins in resnet.py / fusionnet.py).
+// Convolution forward / data gradient / weight gradient as exact-fp32 implicit GEMMs on the bf16 matrix pipe of gfx950
+// (depthnet.py:40-56,96-116 and the twins in resnet.py / fusionnet.py; partial_conv.py:32-57 for the masked instances).
 //
-// Arithmetic ("x3"): every fp32 operand value is cut, on its way into LDS, into three bf16 pieces, each the round-to-nearest bf16 of what the previous ones
-// leave (x = hi + mid + lo exactly).  Per K = 16 step the six piece products that can exceed 2^-24 |a b| (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
-// are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first: fp32-grade results (measured error <= the fp32-MFMA kernel's)
-// at 192 matrix-pipe cycles per 32x32x16 block instead of the 512 of v_mfma_f32_32x32x2_f32.
+// Arithmetic ("x3"): every fp32 operand value is cut into three bf16 pieces, each the bf16 of what the previous ones leave (x = hi + mid + lo exactly).
+// Per K = 16 step the six piece products that can exceed 2^-24 |a b| (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are issued on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first: fp32-grade results (measured error <= the fp32-MFMA kernel's) at 192 matrix-pipe
+// cycles per 32x32x16 block instead of the 512 of v_mfma_f32_32x32x2_f32.
 //
-// GEMM view, NCHW kept end to end (the pixel index is the contiguous one in HBM):
+// Where the split happens.  Weights: once per optimizer step, into "weight images" (fx_weight_images_kernel) that hold, per (filter tap, 128-row tile,
+// K step), the 12 KB the kernel's LDS buffer takes.  Activations and gradients: either in the kernel, on the way from fp32 NCHW into LDS (AMODE 0: block
+// inputs, per-layer entry points), or by the pass that PRODUCES the tensor (AMODE 1 / AIMG / BIMG: fx_act_image_kernel, run by the residual-block
+// executor where it applies BatchNorm + ReLU or the BatchNorm-backward map anyway), into an "activation image": three bf16 planes laid out
+// [n][channel / 16][h][w][16 channels], so that any (pixel, 16-channel K step) is one 32-B row per plane whatever the filter tap, stride or dilation.
+// A kernel fed by images does no arithmetic on its operands: 16-B copies into LDS, fragment reads, MFMAs.
+//
+// GEMM view (the pixel index is the contiguous one of the fp32 tensors):
 //   FWD    y [n][m][oh][ow]  = sum_tap sum_c  W[m][c][tap] * x [n][c][oh*s - pad + r*dil][ow*s - pad + q*dil]
 //   DGRAD  dx[n][m][ih][iw]  = sum_tap sum_k  W[k][m][tap] * dy[n][k][(ih + pad - r*dil)/s][(iw + pad - q*dil)/s]      (per stride^2 parity class)
 //   WGRAD  dw[k][c][tap]     = sum_n sum_p    dy[n][k][p]  * x [n][c][p at tap]                                       (split over (n, p) into slabs)
 // One block = 256 threads = 4 waves computes a 128 (channels) x 128 (pixels) tile; a wave owns 64 x 64 as 2 x 2 MFMA tiles.  The MFMA is
 // issued with the PIXEL operand in the A slot and the CHANNEL operand in the B slot, so in the accumulator a lane is an output channel and
 // its registers are pixels: four consecutive registers are four consecutive pixels (one 16-B store), and everything that is per output
-// channel -- bias, the BatchNorm batch statistics of the result, the sums of the BatchNorm backward -- is per lane, i.e. plain register
+// channel -- bias, the BatchNorm batch statistics of the result (EPI 1), the sums of the BatchNorm backward (EPI 2) -- is per lane, i.e. plain register
 // adds followed by one cross-lane step, not a 32-lane reduction per row.
-//
-// Fused BatchNorm (training mode).  A residual block is conv -> BN -> ReLU -> conv -> BN -> ReLU -> conv -> BN -> (+ shortcut) -> ReLU.
-// The BN + ReLU between two convolutions never exists in HBM:
-//   * the producing conv's epilogue leaves per-(pixel tile, channel) partial sums of y and y^2 (EPI_STATS); a few-block finalize kernel turns
-//     them into mean / invstd, updates the running statistics and writes the per-channel table {scale, shift} (scale = gamma*invstd);
-//   * the consuming conv applies relu(x*scale + shift) when it stages its activation operand (PRO_BNRELU), forward and weight gradient alike;
-//   * backward: the consumer's DGRAD epilogue accumulates, per channel of ITS result, sum(g) and sum(g * c) with g = dgrad * [bn(c) > 0]
-//     (EPI_BNRED: c is the producing conv's raw output, read once, tile-aligned with the stores); a finalize kernel turns the sums into dgamma /
-//     dbeta and the table {A, B, K} of   d c = A * g + B * c + K   (the BatchNorm backward as an affine map per channel), which the producer's
-//     DGRAD and WGRAD apply when they stage their dy operand (PRO_BNBWD).
-// Only the block-closing BN (add + ReLU, its output is the next block's input) is a pass over HBM of its own (p3d_block.hip).
 #include <type_traits>
 #include "p3d_common.h"
 #include "p3d_fx.h"
@@ -44,74 +40,39 @@ using i32x4 = int __attribute__((ext_vector_type(4)));
 constexpr int FX_BM = 128, FX_BN = 128, FX_BK = 16;
 constexpr int FX_PIECE = 128 * FX_BK * 2;          // bytes of one bf16 piece of one operand tile (128 rows or columns x 16 k)
 
-// fp32 x4 -> three bf16 x4 pieces (hi, mid, lo), written as 8-B chunks FX_PIECE apart.  Each piece is the round-to-nearest-even bf16 of what is left
-// (v_cvt_pk_bf16_f32 converts and packs two values per instruction): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  Both subtractions are
-// exact in fp32 and the last remainder has at most 8 significant bits, so hi + mid + lo == x exactly, as with the truncating split (P3D_FX_TRUNC_SPLIT).
+// fp32 -> bf16 pieces.  Each piece is the round-to-nearest-even bf16 of what is left (v_cvt_pk_bf16_f32 converts and packs two values per instruction):
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  Both subtractions are exact in fp32 and the last remainder has at most 8 significant bits,
+// so hi + mid + lo == x exactly.
 using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned fx_pack2(float a, float b) {
     const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
     return __builtin_bit_cast(unsigned, h);
 }
+__device__ __forceinline__ void fx_split2(float x0, float x1, unsigned& hp, unsigned& mp, unsigned& lp) {
+    hp = fx_pack2(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hp << 16), r1 = x1 - __builtin_bit_cast(float, hp & 0xFFFF0000u);
+    mp = fx_pack2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mp << 16), s1 = r1 - __builtin_bit_cast(float, mp & 0xFFFF0000u);
+    lp = fx_pack2(s0, s1);
+}
+// fp32 x4 -> three bf16 x4 pieces, written as 8-B chunks FX_PIECE apart
 __device__ __forceinline__ void fx_split_store(unsigned char* base, const f32x4 v) {
-#if defined(P3D_FX_ABL_NOSPLIT)
-    const u32x2 raw = u32x2{__builtin_bit_cast(unsigned, (float)v[0]), __builtin_bit_cast(unsigned, (float)v[2])};
-    *reinterpret_cast<u32x2*>(base) = raw;
-    *reinterpret_cast<u32x2*>(base + FX_PIECE) = raw;
-    *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = raw;
-#elif defined(P3D_FX_TRUNC_SPLIT)
-    unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e];                         // (a bit_cast straight from an ext-vector element reads element 0 with this clang)
-        const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
-        const float r1 = x - __builtin_bit_cast(float, hb);
-        const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-        const float r2 = r1 - __builtin_bit_cast(float, mb);
-        hi[e] = hb; mid[e] = mb; lo[e] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
-    }
-    *reinterpret_cast<u32x2*>(base) = u32x2{(hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]};
-    *reinterpret_cast<u32x2*>(base + FX_PIECE) = u32x2{(mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]};
-    *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = u32x2{(lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]};
-#else
     unsigned hp[2], mp[2], lp[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float x0 = v[2 * q], x1 = v[2 * q + 1];
-        hp[q] = fx_pack2(x0, x1);
-        const float r0 = x0 - __builtin_bit_cast(float, hp[q] << 16), r1 = x1 - __builtin_bit_cast(float, hp[q] & 0xFFFF0000u);
-        mp[q] = fx_pack2(r0, r1);
-        const float s0 = r0 - __builtin_bit_cast(float, mp[q] << 16), s1 = r1 - __builtin_bit_cast(float, mp[q] & 0xFFFF0000u);
-        lp[q] = fx_pack2(s0, s1);
-    }
+    for (int q = 0; q < 2; ++q) fx_split2(v[2 * q], v[2 * q + 1], hp[q], mp[q], lp[q]);
     *reinterpret_cast<u32x2*>(base) = u32x2{hp[0], hp[1]};
     *reinterpret_cast<u32x2*>(base + FX_PIECE) = u32x2{mp[0], mp[1]};
     *reinterpret_cast<u32x2*>(base + 2 * FX_PIECE) = u32x2{lp[0], lp[1]};
-#endif
 }
 
 // LDS images of one piece of one operand tile:
-//  "rows are the reduction index" (NCHW activations, weights in [k][m] order): 16 rows x 128 bf16 columns, 256-B rows, the 16-B chunks of a row XOR-swizzled;
-//  MFMA fragments (8 consecutive k of one column per lane) come out of ds_read_b64_tr_b16 (two per fragment).
+//  "tr": rows are the reduction index, 16 rows x 128 bf16 columns, 256-B rows, the 16-B chunks of a row XOR-swizzled; MFMA fragments (8 consecutive k of one
+//  column per lane) come out of ds_read_b64_tr_b16 (two per fragment).  Used for fp32 NCHW activations (FWD / DGRAD) and for image-fed WGRAD operands.
 __device__ __forceinline__ int fx_tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
-//  "reduction-contiguous" (weights in [m][k] order, both operands of WGRAD): 128 rows x 16 k, 32-B rows; the two 16-B halves of a row are swapped on rows with
-//  bit 3 set, which makes the 16-lane groups of a ds_read_b128 hit 16 different bank quads (unswizzled they collide two by two).
+//  "rc": reduction-contiguous, 128 rows x 16 k, 32-B rows; the two 16-B halves of a row are swapped on rows with bit 3 set, which makes the 16-lane groups
+//  of a ds_read_b128 hit 16 different bank quads (unswizzled they collide two by two).  Used for weights, image-fed activations (FWD / DGRAD) and for fp32
+//  WGRAD operands.
 __device__ __forceinline__ int fx_rc_off(int row, int half) { return 32 * row + 16 * (half ^ ((row >> 3) & 1)); }
-
-__device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int lane) {
-    // 16-lane group g reads the 4-row x 16-column block of rows 8 (g >> 1) + 4 half .. +3, columns cb + 16 (g & 1) .. +15 (see p3d_hconv.hip)
-    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
-    const int c0 = (cb + 16 * (g & 1)) >> 3;
-    s8v v;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int row = 8 * (g >> 1) + 4 * half + q;
-        const unsigned char* addr = base + fx_tr_off(row, c0 + (pq >> 1)) + 8 * (pq & 1);
-        const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)addr);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
-    }
-    return __builtin_bit_cast(bf8, v);
-}
 
 // NA x NB of the wave's 2 x 2 sub-tiles (32 x 32 each) are computed: a wave whose rows reach beyond the tensor (272 = 2 x 128 + 16 regressor channels,
 // 64-channel layers in a 128-row tile) issues no MFMAs for the sub-tiles that hold nothing
@@ -121,44 +82,17 @@ __device__ __forceinline__ bf8 fx_tr_frag(const unsigned char* base, int cb, int
         _Pragma("unroll") for (int a = 0; a < NA; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                   \
             ACC[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIX[PP[pa]][a], CH[PC[pa]][b], ACC[a][b], 0, 0, 0);    \
     }
-#define P3D_FX_PRODUCTS(ACC, PIX, CH) P3D_FX_PRODUCTS_AB(ACC, PIX, CH, 2, 2)
 // wave-uniform count (0, 1, 2) of 32-row sub-tiles of the wave's 64 rows starting at `first` that begin below `limit`
 __device__ __forceinline__ int fx_live_subtiles(int first, int limit) {
     const int n = (limit - first + 31) >> 5;
     return __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > 2 ? 2 : n));
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------------
-// FWD / DGRAD
-// ------------------------------------------------------------------------------------------------------------------------------------------
-// WMODE 0: weight element (m, k) of tap t at W[t * w_ts + m * w_ld + k]   (forward: [K][C] or the tap-major image [tap][K][C])
-// WMODE 1: weight element (k, m) of tap t at W[t * w_ts + k * w_ld + m]   (dgrad:   [K][C] or [tap][K][C], m = input channel)
-// WMODE 2: pre-split weight image (fx_weight_images_kernel): per (tap, channel tile, K step) the 12 KB that Cs holds for that step -- three bf16 pieces of
-//          128 rows x 16 k in the reduction-contiguous LDS layout -- so the weight operand costs three 16-B copies per thread and K step and no VALU work
-// Every BatchNorm layer owns one table of 8 floats per channel: {sc, sh, mean, invstd, A, B, K, 0} (sc = gamma * invstd, sh = beta - mean * sc: written
-// by the forward finalize; A, B, K: the backward map d c = A * g + B * c + K, written by the backward finalize).
-// PRO: 0 none; 1 relu(x * sc + sh) per reduction channel; 2 A * (mask ? g : 0) + B * c + K per reduction channel with mask = (c * sc + sh > 0)
-//      (X = g, X2 = c); 3 the same without the mask (A * g + B * c + K); 4 x * pmask[pixel] (partial convolution: one factor per pixel, all channels)
-// EPI: 4 store y * emask[pixel] (partial convolution);
-//      0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2; 2 store + partial sums of g, g * (c2 - mean) with g = y * [c2 * sc + sh > 0]
-//      (ep_c = c2 laid out like the output, ep_tab = its BatchNorm's table); under split-K the epilogue work is done by fx_reduce_kernel instead
 // Operand fetches are buffer loads against block-uniform resources: per-thread byte offsets change only when the filter tap changes (they carry the
 // out-of-range bit 0x80000000 for padding pixels / rows beyond the tensor, which the resource's range check turns into zeros), the per-K-step part of an
 // address is a wave-uniform scalar offset.  So a K step's fetch is loads only: no branches, no per-step address arithmetic.
 constexpr int FX_OOB = (int)0x80000000;
-#ifndef P3D_FX_WGRAD_PIPE
-#define P3D_FX_WGRAD_PIPE 0
-#endif
-#ifndef P3D_FX_WGRAD_SCHED
-#define P3D_FX_WGRAD_SCHED 1
-#endif
-constexpr bool FX_WGRAD_PIPE = P3D_FX_WGRAD_PIPE != 0, FX_WGRAD_SCHED = P3D_FX_WGRAD_SCHED != 0;
-#ifndef P3D_FX_WGRAD_MFMA16
-#define P3D_FX_WGRAD_MFMA16 0
-#endif
-constexpr bool FX_WGRAD_MFMA16 = P3D_FX_WGRAD_MFMA16 != 0;
-// tuning ablations (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands),
-// P3D_FX_ABL_NOSPLIT stores the raw bits instead of the three pieces (no split arithmetic)
+// tuning ablation (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands)
 #ifdef P3D_FX_ABL_NOLOAD
 #define FX_SO(x) 0
 #else
@@ -174,10 +108,40 @@ __device__ __forceinline__ i32x4 fx_rsrc(const void* base, size_t bytes) {
     r[0] = (int)(unsigned)a; r[1] = (int)((a >> 32) & 0xffff); r[2] = (int)n; r[3] = 0x00020000;
     return r;
 }
+__device__ __forceinline__ bf8 fx_tr_read(const unsigned char* base, const int (&off)[2]) {
+    s8v v;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)(base + off[half]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
+    }
+    return __builtin_bit_cast(bf8, v);
+}
+// byte offsets of the two transposing 8-B reads that give this lane its fragment (8 consecutive reduction rows of column cb + (lane & 31)) of a "tr" image:
+// 16-lane group g reads the 4-row x 16-column block of rows 8 (g >> 1) + 4 half .. +3, columns cb + 16 (g & 1) .. +15
+__device__ __forceinline__ void fx_tr_frag_off(int lane, int cb, int (&off)[2]) {
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = 8 * (g >> 1) + 4 * half + q;
+        off[half] = fx_tr_off(row, ((cb + 16 * (g & 1)) >> 3) + (pq >> 1)) + 8 * (pq & 1);
+    }
+}
 
-template <int WMODE, int PRO, int EPI>
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// FWD / DGRAD
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The weight operand always comes from a pre-split weight image: three 16-B copies per thread and K step, no VALU work.
+// AMODE 0: the activation operand is fp32 NCHW; a thread fetches four consecutive pixels of two reduction rows per K step and splits them ("tr" image).
+//          PRO 4 multiplies by pmask[pixel] first (partial convolution: one factor per pixel, all channels).
+// AMODE 1: the activation operand is a pre-split activation image; a thread copies one 16-B chunk (pixel, half of the 16 channels) per plane ("rc" image).
+// EPI: 0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2 (the BatchNorm behind the conv); 2 store + partial sums of g, g * (c2 - mean) with
+//      g = y * [c2 * sc + sh > 0] (the BatchNorm + ReLU in front of the conv whose input gradient this is; ep_c = c2 laid out like the output, ep_tab = its
+//      table); 4 store y * emask[pixel] (partial convolution).  Under split-K the epilogue work is done by fx_reduce_kernel instead.
+template <int AMODE, int PRO, int EPI>
 __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
-    constexpr bool WM = WMODE == 1;
+    static_assert(AMODE == 0 || PRO == 0, "the partial-convolution factor is applied by the in-kernel split");
     __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * 3 * FX_PIECE];      // pixel (activation) operand, double buffered
     __shared__ __attribute__((aligned(16))) unsigned char Cs[2 * 3 * FX_PIECE];      // channel (weight) operand
     __shared__ float red[2][2][128];                                                   // EPI 1 / 2: [wave along pixels][sum kind][channel]
@@ -192,29 +156,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     const int m0 = tile_m * FX_BM, n0 = tile_n * FX_BN;
     const int OHW = p.OH * p.OW;
     const int HWi = p.Hi * p.Wi;
-
-    // ---- staging maps ----
-    const int nrow = t >> 2, nkq = t & 3;          // reduction-contiguous operand: rows nrow, nrow + 64; floats 4 nkq .. 4 nkq + 3 of the K step
-    const int trow = t >> 5, tp4 = t & 31;         // row-is-reduction operand: reduction rows trow, trow + 8; columns 4 tp4 .. 4 tp4 + 3
-    // this thread's four consecutive output pixels (one output row: OW % 4 == 0)
-    const int col = n0 + 4 * tp4;
-    const bool col_ok = col < p.NP;
     const int nfirst = n0 / OHW;                   // first image this block touches: base of the activation resources
-    int hbase = 0, wbase = 0, img_off = 0, mimg_off = 0;
-    {
-        const int cc = col_ok ? col : 0;
-        const int pn = cc / OHW;
-        const int rem = cc - pn * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
-        hbase = oh * p.hmul + p.hoff;
-        wbase = ow * p.wmul + p.woff;
-        img_off = ((pn - nfirst) * p.Cred + trow) * HWi;
-        mimg_off = (pn - nfirst) * HWi;                 // PRO 4: the per-pixel factor has one plane per image
-    }
-    const size_t act_left = (size_t)(p.N - nfirst) * p.Cred * HWi * sizeof(float);
-    const i32x4 rX = fx_rsrc(p.X + (size_t)nfirst * p.Cred * HWi, act_left);
-    const i32x4 rX2 = fx_rsrc((PRO == 2 || PRO == 3) ? p.X2 + (size_t)nfirst * p.Cred * HWi : nullptr, (PRO == 2 || PRO == 3) ? act_left : 0);
-    const i32x4 rT = fx_rsrc((PRO >= 1 && PRO <= 3) ? p.tab : nullptr, (PRO >= 1 && PRO <= 3) ? (size_t)p.Cred * FX_TAB * sizeof(float) : 0);
-    const i32x4 rPM = fx_rsrc(PRO == 4 ? p.pmask + (size_t)nfirst * HWi : nullptr, PRO == 4 ? (size_t)(p.N - nfirst) * HWi * sizeof(float) : 0);
     const int csteps = p.Cred / FX_BK;
     int nk = p.ntap * csteps, kt0 = 0;
     if (p.kchunk > 0) {                            // split-K: this block reduces K steps [kt0, kt0 + nk) into slab blockIdx.y
@@ -223,133 +165,122 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     }
     int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
 
-    // weight operand
-    i32x4 rW;
-    int w_voff[3] = {0, 0, 0};                     // WMODE 0 / 1: two rows (index 0, 1); WMODE 2: three 16-B chunks of the K step's 12 KB image tile
-    if constexpr (WMODE == 2) {
-        const size_t img_bytes = (size_t)p.R * p.S * p.tiles_m * csteps * (3 * FX_PIECE);
-        rW = fx_rsrc(p.Wimg, img_bytes);
+    // weight operand: three 16-B chunks of the K step's 12 KB image tile
+    const i32x4 rW = fx_rsrc(p.Wimg, (size_t)p.R * p.S * p.tiles_m * csteps * (3 * FX_PIECE));
+    int w_voff[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) w_voff[j] = 16 * (t + 256 * j);
-    } else if constexpr (WMODE == 1) {
-        rW = fx_rsrc(p.W, ((size_t)p.R * p.S * (p.w_ts ? p.w_ts : 0) + (size_t)p.Cred * p.w_ld) * sizeof(float));
-        const int m = m0 + 4 * tp4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) w_voff[i] = (m < p.M) ? ((trow + 8 * i) * p.w_ld + m) * 4 : FX_OOB;
-    } else {
-        rW = fx_rsrc(p.W, ((size_t)p.R * p.S * (p.w_ts ? p.w_ts : 0) + (size_t)p.M * p.w_ld) * sizeof(float));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int m = m0 + nrow + 64 * i; w_voff[i] = (m < p.M) ? (m * p.w_ld + 4 * nkq) * 4 : FX_OOB; }
+    for (int j = 0; j < 3; ++j) w_voff[j] = 16 * (t + 256 * j);
+
+    // ---- activation operand: staging maps ----
+    // AMODE 0: reduction rows trow, trow + 8; columns (pixels) 4 tp4 .. 4 tp4 + 3.  AMODE 1: pixel pp of the tile, 16-B half ph of its 32-B row.
+    const int trow = t >> 5, tp4 = t & 31;
+    const int pp = t >> 1, ph = t & 1;
+    const int col = n0 + (AMODE == 0 ? 4 * tp4 : pp);
+    const bool col_ok = col < p.NP;
+    int hbase = 0, wbase = 0, img_off = 0, mimg_off = 0;
+    {
+        const int cc = col_ok ? col : 0;
+        const int pn = cc / OHW;
+        const int rem = cc - pn * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+        hbase = oh * p.hmul + p.hoff;
+        wbase = ow * p.wmul + p.woff;
+        img_off = AMODE == 0 ? ((pn - nfirst) * p.Cred + trow) * HWi : (pn - nfirst) * csteps * HWi;       // AMODE 1: in pixels (32-B rows)
+        mimg_off = (pn - nfirst) * HWi;                 // PRO 4: the per-pixel factor has one plane per image
     }
+    i32x4 rX, rXi[3];
+    if constexpr (AMODE == 0) {
+        rX = fx_rsrc(p.X + (size_t)nfirst * p.Cred * HWi, (size_t)(p.N - nfirst) * p.Cred * HWi * sizeof(float));
+    } else {
+        const size_t left = (size_t)(p.N - nfirst) * p.Cred * HWi * 2;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rXi[pc] = fx_rsrc(p.Ximg + pc * p.plane_bytes + (size_t)nfirst * p.Cred * HWi * 2, left);
+    }
+    const i32x4 rPM = fx_rsrc(PRO == 4 ? p.pmask + (size_t)nfirst * HWi : nullptr, PRO == 4 ? (size_t)(p.N - nfirst) * HWi * sizeof(float) : 0);
 
     // per-tap state of the activation gather (recomputed only when the tap changes)
-    int x_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};     // byte offsets of this thread's four pixels in reduction row `trow` of chunk 0 (| out-of-range bit)
+    int x_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};     // AMODE 0: byte offsets of this thread's four pixels in reduction row `trow` of chunk 0; AMODE 1: [0] only
     bool x_vec = false;
-    int w_tapoff = 0;                                      // scalar byte offset of the tap inside the weight operand
+    int w_tapoff = 0;                                      // scalar byte offset of the tap inside the weight image
     int cur_tap = -1;
     f32x4 tmask = {1.f, 1.f, 1.f, 1.f};                    // PRO 4: the factor of this thread's four pixels at the current tap (the same for every K step of the tap)
     auto set_tap = [&](int tap) {
         cur_tap = tap;
         const int ir = tap / p.nS, is = tap - ir * p.nS;
         const int wtap = (p.r0 + p.rstep * ir) * p.S + p.s0 + p.sstep * is;
-        if constexpr (WMODE == 2) w_tapoff = (wtap * p.tiles_m + tile_m) * csteps * (3 * FX_PIECE);
-        else w_tapoff = (int)(wtap * p.w_ts * sizeof(float));
+        w_tapoff = (wtap * p.tiles_m + tile_m) * csteps * (3 * FX_PIECE);
         const int hi = hbase + ir * p.hstep, wshift = is * p.wstep, wi0 = wbase + wshift;
         const bool row_ok = col_ok && (unsigned)hi < (unsigned)p.Hi;
-        x_vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;        // wave-uniform: the four pixels are one aligned 16-B group, in or out together
-        const int base = (img_off + hi * p.Wi + wi0) * 4;
+        if constexpr (AMODE == 1) {
+            x_voff[0] = (row_ok && (unsigned)wi0 < (unsigned)p.Wi) ? (img_off + hi * p.Wi + wi0) * 32 + 16 * ph : FX_OOB;
+        } else {
+            x_vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;        // wave-uniform: the four pixels are one aligned 16-B group, in or out together
+            const int base = (img_off + hi * p.Wi + wi0) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
-            x_voff[e] = ok ? base + e * p.wmul * 4 : FX_OOB;
-        }
-        if constexpr (PRO == 4) {
-            const int mbase = (mimg_off + hi * p.Wi + wi0) * 4;
-            if (x_vec) tmask = fx_buffer_load_f32x4(rPM, x_voff[0] >= 0 ? mbase : FX_OOB, 0, 0);
-            else {
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = row_ok && (unsigned)(wi0 + e * p.wmul) < (unsigned)p.Wi;
+                x_voff[e] = ok ? base + e * p.wmul * 4 : FX_OOB;
+            }
+            if constexpr (PRO == 4) {
+                const int mbase = (mimg_off + hi * p.Wi + wi0) * 4;
+                if (x_vec) tmask = fx_buffer_load_f32x4(rPM, x_voff[0] >= 0 ? mbase : FX_OOB, 0, 0);
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tmask[e] = fx_buffer_load_f32(rPM, x_voff[e] >= 0 ? mbase + e * p.wmul * 4 : FX_OOB, 0, 0);
+                    for (int e = 0; e < 4; ++e) tmask[e] = fx_buffer_load_f32(rPM, x_voff[e] >= 0 ? mbase + e * p.wmul * 4 : FX_OOB, 0, 0);
+                }
             }
         }
     };
 
-    f32x4 rw[2], rx[2], rx2[2];
-    i32x4 rwi[3];                                  // WMODE 2: this thread's three 16-B chunks of the K step's weight image
-    f32x4 rtab[2][2];                              // PRO constants of this thread's two reduction rows
+    f32x4 rx[2];
+    i32x4 rwi[3], rxi[3];                          // this thread's three 16-B chunks of the K step's weight image / activation image
     f32x4 smask = {1.f, 1.f, 1.f, 1.f};            // PRO 4: per-pixel factor of the fetched K step
-    int rvoff[4];                                  // validity of the fetched pixels (the offsets they were fetched with): staged as zeros after a PRO map
     auto fetch = [&]() {
         if (f_tap != cur_tap) { asm volatile("" ::: "memory"); set_tap(f_tap); }       // (a real, wave-uniform branch: taken once per tap, not if-converted into every K step)
-        if constexpr (WMODE == 2) {
+        {
             const int so = w_tapoff + (f_k >> 4) * (3 * FX_PIECE);
 #pragma unroll
             for (int j = 0; j < 3; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], FX_SO(so), 0);
-        } else if constexpr (WMODE == 1) {
-            const int so = w_tapoff + f_k * p.w_ld * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], FX_SO(so), 0);
-        } else {
-            const int so = w_tapoff + f_k * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) rw[i] = fx_buffer_load_f32x4(rW, w_voff[i], FX_SO(so), 0);
         }
+        if constexpr (AMODE == 1) {
+            const int so = (f_k >> 4) * HWi * 32;                  // wave-uniform: the K step's channel group
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int so = (f_k + 8 * i) * HWi * 4;                 // wave-uniform: reduction chunk + this pass's 8-row step
-            if (x_vec) {
-                rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], FX_SO(so), 0);
-                if constexpr (PRO == 2 || PRO == 3) rx2[i] = fx_buffer_load_f32x4(rX2, x_voff[0], FX_SO(so), 0);
-            } else {
+            for (int pc = 0; pc < 3; ++pc) rxi[pc] = fx_buffer_load_i32x4(rXi[pc], x_voff[0], FX_SO(so), 0);
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], FX_SO(so), 0);
-                    if constexpr (PRO == 2 || PRO == 3) rx2[i][e] = fx_buffer_load_f32(rX2, x_voff[e], FX_SO(so), 0);
+            for (int i = 0; i < 2; ++i) {
+                const int so = (f_k + 8 * i) * HWi * 4;             // wave-uniform: reduction chunk + this pass's 8-row step
+                if (x_vec) rx[i] = fx_buffer_load_f32x4(rX, x_voff[0], FX_SO(so), 0);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rx[i][e] = fx_buffer_load_f32(rX, x_voff[e], FX_SO(so), 0);
                 }
             }
-            if constexpr (PRO == 1 || PRO == 2) rtab[i][1] = fx_buffer_load_f32x4(rT, trow * 32, FX_SO((f_k + 8 * i) * 32), 0);           // {sc, sh, mean, invstd}
-            if constexpr (PRO == 2 || PRO == 3) rtab[i][0] = fx_buffer_load_f32x4(rT, trow * 32 + 16, FX_SO((f_k + 8 * i) * 32), 0);                // {A, B, K, 0}
+            if constexpr (PRO == 4) smask = tmask;            // (the factor of the tap these loads belong to: the next fetch may already be at another tap)
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rvoff[e] = x_vec ? x_voff[0] : x_voff[e];
-        if constexpr (PRO == 4) smask = tmask;            // (the factor of the tap these loads belong to: the next fetch may already be at another tap)
         f_k += FX_BK;
         if (f_k == p.Cred) { f_k = 0; ++f_tap; }
     };
-    // LDS addresses of this thread's staging stores and of this lane's fragment reads, relative to a buffer's first piece
+    // LDS addresses of this thread's staging stores, relative to a buffer's first piece
     const int st_p[2] = {fx_tr_off(trow, tp4 >> 1) + 8 * (tp4 & 1), fx_tr_off(trow + 8, tp4 >> 1) + 8 * (tp4 & 1)};
-    const int st_c[2] = {WM ? st_p[0] : fx_rc_off(nrow, nkq >> 1) + 8 * (nkq & 1), WM ? st_p[1] : fx_rc_off(nrow + 64, nkq >> 1) + 8 * (nkq & 1)};
+    const int st_p1 = fx_rc_off(pp, ph);
     auto stage = [&](int buf) {
         unsigned char* pb = Ps + buf * 3 * FX_PIECE;
         unsigned char* cb = Cs + buf * 3 * FX_PIECE;
-        if constexpr (WMODE == 2) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4*>(cb + 16 * (t + 256 * j)) = rwi[j];
-        }
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4*>(cb + 16 * (t + 256 * j)) = rwi[j];
+        if constexpr (AMODE == 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (WMODE != 2) fx_split_store(cb + st_c[i], rw[i]);
-            f32x4 v = rx[i];
-            if constexpr (PRO == 1) {
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(pb + pc * FX_PIECE + st_p1) = rxi[pc];
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rvoff[e] >= 0 ? fmaxf(fmaf(rx[i][e], rtab[i][1][0], rtab[i][1][1]), 0.f) : 0.f;
-            }
-            if constexpr (PRO == 2) {
+            for (int i = 0; i < 2; ++i) {
+                f32x4 v = rx[i];
+                if constexpr (PRO == 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c = rx2[i][e];
-                    const float g = fmaf(c, rtab[i][1][0], rtab[i][1][1]) > 0.f ? rx[i][e] : 0.f;
-                    v[e] = rvoff[e] >= 0 ? fmaf(rtab[i][0][0], g, fmaf(rtab[i][0][1], c, rtab[i][0][2])) : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] *= smask[e];
                 }
+                fx_split_store(pb + st_p[i], v);
             }
-            if constexpr (PRO == 3) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rvoff[e] >= 0 ? fmaf(rtab[i][0][0], rx[i][e], fmaf(rtab[i][0][1], rx2[i][e], rtab[i][0][2])) : 0.f;
-            }
-            if constexpr (PRO == 4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= smask[e];
-            }
-            fx_split_store(pb + st_p[i], v);
         }
     };
 
@@ -361,29 +292,14 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
-    // fragment read offsets (see fx_tr_frag): two transposing 8-B reads per pixel fragment, one 16-B read per reduction-contiguous weight fragment
-    int rd_p[2][2], rd_c[2][2];
-    {
-        const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pq = idx & 3;
+    // fragment read offsets: "tr" image: two transposing 8-B reads per fragment; "rc" image: one 16-B read
+    int rd_p[2][2], rd_c[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int row = 8 * (g >> 1) + 4 * half + q;
-                rd_p[a][half] = fx_tr_off(row, ((wn * 64 + a * 32 + 16 * (g & 1)) >> 3) + (pq >> 1)) + 8 * (pq & 1);
-                rd_c[a][half] = WM ? fx_tr_off(row, ((wm * 64 + a * 32 + 16 * (g & 1)) >> 3) + (pq >> 1)) + 8 * (pq & 1) : fx_rc_off(wm * 64 + a * 32 + fr, fh);
-            }
+    for (int a = 0; a < 2; ++a) {
+        if constexpr (AMODE == 0) fx_tr_frag_off(lane, wn * 64 + a * 32, rd_p[a]);
+        else rd_p[a][0] = rd_p[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
+        rd_c[a] = fx_rc_off(wm * 64 + a * 32 + fr, fh);
     }
-    auto tr_read = [&](const unsigned char* base, const int (&off)[2]) {
-        s8v v;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const s4t r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)(base + off[half]));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * half + e] = r4[e];
-        }
-        return __builtin_bit_cast(bf8, v);
-    };
     const int live_b = fx_live_subtiles(m0 + wm * 64, p.M);       // channel sub-tiles of this wave that hold output channels
     if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
@@ -399,11 +315,9 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        pf[pc][a] = tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
-                        if (a < NB) {
-                            if (WM) cf[pc][a] = tr_read(Cs + (buf * 3 + pc) * FX_PIECE, rd_c[a]);
-                            else cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a][0]);
-                        }
+                        if constexpr (AMODE == 0) pf[pc][a] = fx_tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
+                        else pf[pc][a] = *reinterpret_cast<const bf8*>(Ps + (buf * 3 + pc) * FX_PIECE + rd_p[a][0]);
+                        if (a < NB) cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a]);
                     }
                 P3D_FX_PRODUCTS_AB(acc, pf, cf, 2, NB)
             }
@@ -480,7 +394,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 }
             }
         }
-    if constexpr (EPI >= 1 && EPI <= 3) {
+    if constexpr (EPI == 1 || EPI == 2) {
         if (!split) {
             // the two half-waves hold different pixels of the same channels; then the two waves along the pixel axis
 #pragma unroll
@@ -549,14 +463,16 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
 // WGRAD: dw[k][c][tap] = sum over images n and output pixels p of dyeff[n][k][p] * xeff[n][c][p at tap]
-// Both operands are contiguous along the reduction (pixel) index; a K step is 16 consecutive output pixels of one image (OHW % 16 == 0), a thread fetches
-// 4 of them for two rows of each operand.  grid (C tiles, K tiles, taps * splits); slabs [split][k][tap][c] ("tap-major columns", what
-// wgrad_reduce_tapm_kernel of p3d_conv.hip sums and transposes) or, for 1x1, [split][k][c].
-// PA: 4 dy * amask[output pixel], PB: 2 x * bmask[input pixel] (partial convolution);
-// PA: 0 none; 2 / 3 the BatchNorm-backward map of fx_conv_kernel on dy (per row k: constants live in registers; DY2 = the raw conv output c)
-// PB: 0 none; 1 relu(x * sc + sh) per row c
-template <int PA, int PB>
+// A K step is 16 consecutive output pixels of one image (OHW % 16 == 0).  grid (C tiles, K tiles, taps * splits); slabs [split][k][tap][c] ("tap-major
+// columns", what wgrad_reduce_tapm_kernel of p3d_conv.hip sums and transposes) or, for 1x1, [split][k][c].
+// An fp32 operand (AIMG / BIMG false) is contiguous along the reduction (pixel) index: a thread fetches 4 pixels for two rows and splits them ("rc" image,
+// rows = channels).  An image operand is contiguous along the channels: a thread copies one 16-B chunk (pixel of the step, 8 channels) per plane ("tr" image,
+// rows = the step's 16 pixels, read through ds_read_b64_tr_b16).
+// MASKED (partial convolution, fp32 operands only): dy * amask[output pixel], x * bmask[input pixel].
+// ------------------------------------------------------------------------------------------------------------------------------------------
+template <bool AIMG, bool BIMG, bool MASKED>
 __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
+    static_assert(!MASKED || (!AIMG && !BIMG), "the partial-convolution factors are applied by the in-kernel split");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -569,130 +485,139 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const int total = p.N * steps_per_img;
     const int s0 = split * p.spb, s1 = (s0 + p.spb < total) ? s0 + p.spb : total;
     const int nk = s1 - s0;
+    // fp32 operands: rows row, row + 64 of the tile, pixels 4 kq .. 4 kq + 3 of the step.  Image operands: pixel ipix of the step, channel group icg of the
+    // tile's eight, 16-B half ih of the group's 32-B row.
     const int row = t >> 2, kq = t & 3;
+    const int ih = t & 1, ipix = (t >> 1) & 15, icg = t >> 5;
     const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
-    f32x4 atab[2][2], btab[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        atab[i][0] = atab[i][1] = btab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (PA == 2 || PA == 3) {
-            if (a_ok[i]) {
-                atab[i][0] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i) + 4);      // {A, B, K, 0}
-                atab[i][1] = *reinterpret_cast<const f32x4*>(p.atab + 8 * (m0 + row + 64 * i));          // {sc, sh, mean, invstd}
-            }
-        }
-        if constexpr (PB == 1) {
-            if (b_ok[i]) btab[i] = *reinterpret_cast<const f32x4*>(p.btab + 8 * (n0 + row + 64 * i));
-        }
-    }
+    const int KG = p.K >> 4, CG = p.C >> 4;
+    const int a_cg = (m0 >> 4) + icg, b_cg = (n0 >> 4) + icg;
+    const bool ai_ok = a_cg < KG, bi_ok = b_cg < CG;
     // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
-    // pixel position of the K step in a wave-uniform scalar offset.  (fx_common bounds every tensor below 2^31 elements; the resources are cut to 2 GiB.)
-    const i32x4 rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
-    const i32x4 rA2 = fx_rsrc((PA == 2 || PA == 3) ? p.DY2 : nullptr, (PA == 2 || PA == 3) ? (size_t)p.N * p.K * OHW * sizeof(float) : 0);
-    const i32x4 rAM = fx_rsrc(PA == 4 ? p.amask : nullptr, PA == 4 ? (size_t)p.N * OHW * sizeof(float) : 0);
-    const i32x4 rBM = fx_rsrc(PB == 2 ? p.bmask : nullptr, PB == 2 ? (size_t)p.N * HWi * sizeof(float) : 0);
-    const i32x4 rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
+    // pixel position of the K step in a wave-uniform scalar offset.  (fx_wgrad_applies bounds every tensor below 2^29 elements.)
+    i32x4 rA, rB, rAi[3], rBi[3];
+    if constexpr (AIMG) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rAi[pc] = fx_rsrc(p.DYimg + pc * p.dy_plane, (size_t)p.N * p.K * OHW * 2);
+    } else rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
+    if constexpr (BIMG) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * p.C * HWi * 2);
+    } else rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
+    const i32x4 rAM = fx_rsrc(MASKED ? p.amask : nullptr, MASKED ? (size_t)p.N * OHW * sizeof(float) : 0);
+    const i32x4 rBM = fx_rsrc(MASKED ? p.bmask : nullptr, MASKED ? (size_t)p.N * HWi * sizeof(float) : 0);
     int a_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a_voff[i] = a_ok[i] ? ((m0 + row + 64 * i) * OHW + 4 * kq) * 4 : FX_OOB;
+    const int ai_voff = ai_ok ? (a_cg * OHW + ipix) * 32 + 16 * ih : FX_OOB;
     const bool simple = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;      // 1x1: the input pixel IS the output pixel
     const bool vec = p.stride == 1 && (dw & 3) == 0;        // uniform: the four input pixels are one aligned 16-B group, in or out together
     const int b_row = (n0 + row) * HWi;
-    // Two register sets for fetched tiles: the plain variant (PA == 0 && PB == 0, what the residual-block executor launches by default) keeps the loads of
-    // TWO K steps in flight and splits step kt + 1 while the matrix pipe works on step kt; the others use set 0 only, one step ahead.
-    f32x4 ra[2][2], ra2[2][2], rb[2][2];
-    f32x4 ram[2], rbm[2];        // PA 4 / PB 2: the per-pixel factors of the fetched K step (one value per pixel, whatever the row)
-    int b_voff[2][4] = {{FX_OOB, FX_OOB, FX_OOB, FX_OOB}, {FX_OOB, FX_OOB, FX_OOB, FX_OOB}};
+    f32x4 ra[2], rb[2];
+    i32x4 rai[3], rbi[3];
+    f32x4 ram, rbm;              // MASKED: the per-pixel factors of the fetched K step (one value per pixel, whatever the row)
+    int b_voff[4] = {FX_OOB, FX_OOB, FX_OOB, FX_OOB};
     int f_img = s0 / steps_per_img, f_p = (s0 - f_img * steps_per_img) * FX_BK;
     const bool rowwise = (p.OW & (FX_BK - 1)) == 0;        // uniform: a K step never straddles two output rows
     int f_oh = f_p / p.OW, f_ow = f_p - f_oh * p.OW;       // rowwise: the step's output row and first column (scalars)
     const int tw = 4 * kq * p.stride + dw;
-    auto fetch = [&](auto sel) {
-        constexpr int Q = decltype(sel)::value;
-        const int a_so = (f_img * p.K * OHW + f_p) * 4;
+    auto fetch = [&]() {
+        // operand A (dy)
+        if constexpr (AIMG) {
+            const int a_so = (f_img * KG * OHW + f_p) * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ra[Q][i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
-            if constexpr (PA == 2 || PA == 3) ra2[Q][i] = fx_buffer_load_f32x4(rA2, a_voff[i], FX_SO(a_so), 0);
+            for (int pc = 0; pc < 3; ++pc) rai[pc] = fx_buffer_load_i32x4(rAi[pc], ai_voff, FX_SO(a_so), 0);
+        } else {
+            const int a_so = (f_img * p.K * OHW + f_p) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = fx_buffer_load_f32x4(rA, a_voff[i], FX_SO(a_so), 0);
+            if constexpr (MASKED) ram = fx_buffer_load_f32x4(rAM, 16 * kq, (f_img * OHW + f_p) * 4, 0);
         }
-        if constexpr (PA == 4) ram[Q] = fx_buffer_load_f32x4(rAM, 16 * kq, (f_img * OHW + f_p) * 4, 0);
-        int b_so = f_img * p.C * HWi * 4;
-        if (simple) {
-            b_so += f_p * 4;
+        // operand B (x at this block's filter tap)
+        if constexpr (BIMG) {
+            int b_so = f_img * CG * HWi * 32, voff;
+            if (simple) { b_so += f_p * 32; voff = bi_ok ? (b_cg * HWi + ipix) * 32 + 16 * ih : FX_OOB; }
+            else {
+                int hi, wi;
+                if (rowwise) { hi = f_oh * p.stride + dh; wi = (f_ow + ipix) * p.stride + dw; }        // the step's 16 pixels lie in output row f_oh (a scalar)
+                else { const int q = f_p + ipix, oh = q / p.OW, ow = q - oh * p.OW; hi = oh * p.stride + dh; wi = ow * p.stride + dw; }
+                voff = (bi_ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) ? (b_cg * HWi + hi * p.Wi + wi) * 32 + 16 * ih : FX_OOB;
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (b_row + 4 * kq + e) * 4;
-        } else if (rowwise) {
-            // the K step's 16 pixels lie in output row f_oh (a scalar, like everything that depends on the step): per thread, one add and one range check per pixel
-            const int hi = f_oh * p.stride + dh;
-            const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
-            const int wi0 = f_ow * p.stride + tw;
-            const int base = (b_row + hi * p.Wi + wi0) * 4;
+            for (int pc = 0; pc < 3; ++pc) rbi[pc] = fx_buffer_load_i32x4(rBi[pc], voff, FX_SO(b_so), 0);
+        } else {
+            int b_so = f_img * p.C * HWi * 4;
+            if (simple) {
+                b_so += f_p * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+                for (int e = 0; e < 4; ++e) b_voff[e] = (b_row + 4 * kq + e) * 4;
+            } else {
+                int hi, wi0;
+                if (rowwise) { hi = f_oh * p.stride + dh; wi0 = f_ow * p.stride + tw; }       // per thread, one add and one range check per pixel
+                else { const int q = f_p + 4 * kq, oh = q / p.OW, ow = q - oh * p.OW; hi = oh * p.stride + dh; wi0 = ow * p.stride + dw; }
+                const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
+                const int base = (b_row + hi * p.Wi + wi0) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b_voff[e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int so = b_so + i * 64 * HWi * 4;
+                const int rowbad = b_ok[i] ? 0 : FX_OOB;
+                if (vec) rb[i] = fx_buffer_load_f32x4(rB, b_voff[0] | rowbad, FX_SO(so), 0);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[i][e] = fx_buffer_load_f32(rB, b_voff[e] | rowbad, FX_SO(so), 0);
+                }
+            }
+            if constexpr (MASKED) {        // the factor at the four input pixels: the x offsets without the channel row
+                const int mso = b_so - f_img * (p.C - 1) * HWi * 4;
+                if (vec) rbm = fx_buffer_load_f32x4(rBM, b_voff[0] >= 0 ? b_voff[0] - b_row * 4 : FX_OOB, mso, 0);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rbm[e] = fx_buffer_load_f32(rBM, b_voff[e] >= 0 ? b_voff[e] - b_row * 4 : FX_OOB, mso, 0);
+                }
+            }
+        }
+        if (!simple && rowwise) {
             f_ow += FX_BK;
             if (f_ow == p.OW) { f_ow = 0; ++f_oh; if (f_oh == p.OH) f_oh = 0; }
-        } else {
-            const int pp = f_p + 4 * kq;
-            const int oh = pp / p.OW, ow = pp - oh * p.OW;
-            const int hi = oh * p.stride + dh, wi0 = ow * p.stride + dw;
-            const bool row_ok = (unsigned)hi < (unsigned)p.Hi;
-            const int base = (b_row + hi * p.Wi + wi0) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b_voff[Q][e] = (row_ok && (unsigned)(wi0 + e * p.stride) < (unsigned)p.Wi) ? base + e * p.stride * 4 : FX_OOB;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int so = b_so + i * 64 * HWi * 4;
-            const int rowbad = b_ok[i] ? 0 : FX_OOB;
-            if (vec) rb[Q][i] = fx_buffer_load_f32x4(rB, b_voff[Q][0] | rowbad, FX_SO(so), 0);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rb[Q][i][e] = fx_buffer_load_f32(rB, b_voff[Q][e] | rowbad, FX_SO(so), 0);
-            }
-        }
-        if constexpr (PB == 2) {        // the factor at the four input pixels: the x offsets without the channel row
-            const int mso = b_so - f_img * (p.C - 1) * HWi * 4;
-            if (vec) rbm[Q] = fx_buffer_load_f32x4(rBM, b_voff[Q][0] >= 0 ? b_voff[Q][0] - b_row * 4 : FX_OOB, mso, 0);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rbm[Q][e] = fx_buffer_load_f32(rBM, b_voff[Q][e] >= 0 ? b_voff[Q][e] - b_row * 4 : FX_OOB, mso, 0);
-            }
         }
         f_p += FX_BK;
         if (f_p == OHW) { f_p = 0; ++f_img; }
     };
     const int st_off[2] = {fx_rc_off(row, kq >> 1) + 8 * (kq & 1), fx_rc_off(row + 64, kq >> 1) + 8 * (kq & 1)};
-    auto stage = [&](auto sel, int buf) {
-        constexpr int Q = decltype(sel)::value;
+    const int st_img = fx_tr_off(ipix, 2 * icg + ih);
+    auto stage = [&](int buf) {
+        unsigned char* ab = As + buf * 3 * FX_PIECE;
+        unsigned char* bb = Bs + buf * 3 * FX_PIECE;
+        if constexpr (AIMG) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 va = ra[Q][i], vb = rb[Q][i];
-            if constexpr (PA == 2) {
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(ab + pc * FX_PIECE + st_img) = rai[pc];
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c = ra2[Q][i][e];
-                    const float g = fmaf(c, atab[i][1][0], atab[i][1][1]) > 0.f ? ra[Q][i][e] : 0.f;
-                    va[e] = fmaf(atab[i][0][0], g, fmaf(atab[i][0][1], c, atab[i][0][2]));      // (rows k >= K have all-zero constants)
+            for (int i = 0; i < 2; ++i) {
+                f32x4 va = ra[i];
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) va[e] *= ram[e];
                 }
+                fx_split_store(ab + st_off[i], va);
             }
-            if constexpr (PA == 3) {
+        }
+        if constexpr (BIMG) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) va[e] = fmaf(atab[i][0][0], ra[Q][i][e], fmaf(atab[i][0][1], ra2[Q][i][e], atab[i][0][2]));
-            }
-            if constexpr (PB == 1) {
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(bb + pc * FX_PIECE + st_img) = rbi[pc];
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) vb[e] = (b_ok[i] && (vec ? b_voff[Q][0] : b_voff[Q][e]) >= 0) ? fmaxf(fmaf(rb[Q][i][e], btab[i][0], btab[i][1]), 0.f) : 0.f;
-            }
-            if constexpr (PA == 4) {
+            for (int i = 0; i < 2; ++i) {
+                f32x4 vb = rb[i];
+                if constexpr (MASKED) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) va[e] *= ram[Q][e];
+                    for (int e = 0; e < 4; ++e) vb[e] *= rbm[e];
+                }
+                fx_split_store(bb + st_off[i], vb);
             }
-            if constexpr (PB == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vb[e] *= rbm[Q][e];
-            }
-            fx_split_store(As + buf * 3 * FX_PIECE + st_off[i], va);
-            fx_split_store(Bs + buf * 3 * FX_PIECE + st_off[i], vb);
         }
     };
     f32x16 acc[2][2];
@@ -703,123 +628,54 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
-    const int rd_a[2] = {fx_rc_off(wm * 64 + fr, fh), fx_rc_off(wm * 64 + 32 + fr, fh)}, rd_b[2] = {fx_rc_off(wn * 64 + fr, fh), fx_rc_off(wn * 64 + 32 + fr, fh)};
-    // FX_WGRAD_MFMA16: the same six products on v_mfma_f32_16x16x32_bf16.  Its 32-deep reduction is used as TWO piece products over the step's 16 k: lanes
-    // 0-31 feed one (A piece, B piece) pair, lanes 32-63 another, so three instructions per 16 x 16 tile give lo*hi + hi*lo, mid*hi + mid*mid, hi*hi + hi*mid.
-    // Lane l holds row (l & 15), k half (l >> 4) & 1 of the piece its half-wave reads; sub-tiles are 16 rows apart (512 B in the 32-B-row image).
-    f32x4 acc16[4][4];
-    const int r16 = lane & 15, kh16 = (lane >> 4) & 1, ps16 = lane >> 5;
-    int rd16_a[3], rd16_b[2];
-    {
-        const int pa[3][2] = {{2, 0}, {1, 1}, {0, 0}}, pb[2][2] = {{0, 2}, {0, 1}};      // [pair][half-wave] piece: pairs run smallest first; B of pairs 1 and 2 is the same
+    int rd_a[2][2], rd_b[2][2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rd16_a[q] = pa[q][ps16] * FX_PIECE + fx_rc_off(wm * 64 + r16, kh16);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) rd16_b[q] = pb[q][ps16] * FX_PIECE + fx_rc_off(wn * 64 + r16, kh16);
-    }
-    if constexpr (FX_WGRAD_MFMA16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 2; ++a) {
+        if constexpr (AIMG) fx_tr_frag_off(lane, wm * 64 + a * 32, rd_a[a]);
+        else rd_a[a][0] = rd_a[a][1] = fx_rc_off(wm * 64 + a * 32 + fr, fh);
+        if constexpr (BIMG) fx_tr_frag_off(lane, wn * 64 + a * 32, rd_b[a]);
+        else rd_b[a][0] = rd_b[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
     }
     const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
-    using Q0 = std::integral_constant<int, 0>;
-    using Q1 = std::integral_constant<int, 1>;
-    constexpr bool PIPE = PA == 0 && PB == 0 && FX_WGRAD_PIPE;        // (the masked and the fused variants use set 0 only)
-    if (nk > 0) { fetch(Q0{}); stage(Q0{}, 0); }
-    if (PIPE && nk > 1) fetch(Q1{});
+    if (nk > 0) { fetch(); stage(0); }
     __syncthreads();
-    auto kloop = [&](auto nat) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles along k
-        constexpr int NA = decltype(nat)::value;
-        auto compute = [&](int buf) {
-            if constexpr (NA > 0 && FX_WGRAD_MFMA16) {
-                const unsigned char* ab = As + buf * 3 * FX_PIECE;
-                const unsigned char* bb = Bs + buf * 3 * FX_PIECE;
-                bf8 bq[2][4];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bq[q][j] = *reinterpret_cast<const bf8*>(bb + rd16_b[q] + 512 * j);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    bf8 aq[2 * NA];
-#pragma unroll
-                    for (int i = 0; i < 2 * NA; ++i) aq[i] = *reinterpret_cast<const bf8*>(ab + rd16_a[q] + 512 * i);
-#pragma unroll
-                    for (int i = 0; i < 2 * NA; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[q == 0 ? 0 : 1][j], acc16[i][j], 0, 0, 0);
-                }
-            } else if constexpr (NA > 0) {
+    auto kloop = [&](auto nat, auto nbt) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles
+        constexpr int NA = decltype(nat)::value, NB = decltype(nbt)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch();
+            if constexpr (NA > 0 && NB > 0) {
                 bf8 af[3][2], bf[3][2];
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        if (a < NA) af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a]);
-                        bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a]);
+                        if (a < NA) {
+                            if constexpr (AIMG) af[pc][a] = fx_tr_read(As + (buf * 3 + pc) * FX_PIECE, rd_a[a]);
+                            else af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a][0]);
+                        }
+                        if (a < NB) {
+                            if constexpr (BIMG) bf[pc][a] = fx_tr_read(Bs + (buf * 3 + pc) * FX_PIECE, rd_b[a]);
+                            else bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a][0]);
+                        }
                     }
-                P3D_FX_PRODUCTS_AB(acc, af, bf, NA, 2)
+                P3D_FX_PRODUCTS_AB(acc, af, bf, NA, NB)
             }
-        };
-        if constexpr (PIPE) {
-            // step kt: tile kt is in LDS buffer kt & 1, tile kt + 1 in register set (kt + 1) & 1 (fetched a whole step ago), tile kt + 2 goes into set kt & 1
-            // (the last step splits a stale register set into the LDS buffer nobody reads any more: the split stays unconditional, in the MFMAs' basic block)
-            auto step = [&](auto par, int kt) {
-                constexpr int P = decltype(par)::value;
-                if (kt + 2 < nk) fetch(std::integral_constant<int, P>{});
-                compute(P);
-                stage(std::integral_constant<int, P ^ 1>{}, P ^ 1);
-                if constexpr (NA == 2 && FX_WGRAD_SCHED) {
-                    // one basic block: 12 fragment reads, 24 MFMAs, ~90 VALU of the split and its 8 LDS stores -- spread the split into the MFMAs' shadow
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                }
-                __syncthreads();
-            };
-            for (int kt = 0; kt < nk; kt += 2) {
-                step(Q0{}, kt);
-                if (kt + 1 < nk) step(Q1{}, kt + 1);
-            }
-        } else {
-            for (int kt = 0; kt < nk; ++kt) {
-                const int buf = kt & 1;
-                if (kt + 1 < nk) fetch(Q0{});
-                compute(buf);
-                if (kt + 1 < nk) stage(Q0{}, buf ^ 1);
-                __syncthreads();
-            }
+            if (kt + 1 < nk) stage(buf ^ 1);
+            __syncthreads();
         }
     };
-    if (live_a == 0 || live_b == 0) kloop(std::integral_constant<int, 0>{});
-    else if (live_a == 1) kloop(std::integral_constant<int, 1>{});
-    else kloop(std::integral_constant<int, 2>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (live_a == 0 || live_b == 0) kloop(I0{}, I0{});
+    else if (live_a == 2 && live_b == 2) kloop(I2{}, I2{});
+    else if (live_a == 1 && live_b == 2) kloop(I1{}, I2{});
+    else if (live_a == 2 && live_b == 1) kloop(I2{}, I1{});
+    else kloop(I1{}, I1{});
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
     const int RS = p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;
-    if constexpr (FX_WGRAD_MFMA16) {
-        // 16 x 16 C/D layout: col = lane & 15 (input channel c), row = 4 (lane >> 4) + reg (output channel k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = n0 + wn * 64 + 16 * j + r16;
-                if (c >= p.C) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = m0 + wm * 64 + 16 * i + 4 * (lane >> 4) + r;
-                    if (k < p.K) out[((size_t)k * RS + tap) * p.C + c] = acc16[i][j][r];
-                }
-            }
-        return;
-    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -832,6 +688,79 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
                 if (k < p.K) out[((size_t)k * RS + tap) * p.C + c] = acc[a][b][r];
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Activation images: fp32 NCHW [N][C][HW] -> three bf16 planes [N][C/16][HW][16], optionally through the BatchNorm + ReLU of the forward pass (MODE 1) or
+// the BatchNorm-backward map (MODE 2) of the layer the tensor belongs to (depthnet.py:98-116: out = relu(bn(conv(x))) and its autograd).
+// A thread owns four consecutive pixels of eight channels (one 16-B chunk per pixel and plane): it reads eight 16-B groups (one per channel, pixels
+// contiguous) and writes twelve 16-B chunks; the partner lane (ih) owns the other eight channels of the same pixels, so a lane pair writes 32-B rows.
+// grid (ceil(N * HW / 4 * 2 / 256), C / 16)
+// ------------------------------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ tab,
+                                                           unsigned char* __restrict__ img, size_t plane_bytes, int N, int C, int HW, int masked) {
+    __shared__ float cst[16][FX_TAB];
+    const int cg = blockIdx.y, t = threadIdx.x;
+    if constexpr (MODE != 0) {
+        if (t < 16 * FX_TAB) cst[t >> 3][t & 7] = tab[(size_t)(cg * 16) * FX_TAB + t];
+        __syncthreads();
+    }
+    const int ih = t & 1;
+    const int q4 = HW >> 2;
+    const long long quad = ((long long)blockIdx.x * 256 + t) >> 1;
+    if (quad >= (long long)N * q4) return;
+    const int n = (int)(quad / q4), pq = (int)(quad - (long long)n * q4);
+    const size_t in0 = ((size_t)n * C + cg * 16 + 8 * ih) * HW + 4 * pq;
+    f32x4 v[8], c2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = *reinterpret_cast<const f32x4*>(X + in0 + (size_t)j * HW);
+        if constexpr (MODE == 2) c2[j] = *reinterpret_cast<const f32x4*>(X2 + in0 + (size_t)j * HW);
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = cst[8 * ih + j][0], sh = cst[8 * ih + j][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(fmaf(v[j][e], sc, sh), 0.f);
+        }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = cst[8 * ih + j][0], sh = cst[8 * ih + j][1], A = cst[8 * ih + j][4], B = cst[8 * ih + j][5], K = cst[8 * ih + j][6];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = (!masked || fmaf(c2[j][e], sc, sh) > 0.f) ? v[j][e] : 0.f;
+                v[j][e] = fmaf(A, gg, fmaf(B, c2[j][e], K));
+            }
+        }
+    }
+    unsigned char* dst = img + (((size_t)n * (C >> 4) + cg) * HW + 4 * pq) * 32 + 16 * ih;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hp[4], mp[4], lp[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) fx_split2(v[2 * jj][e], v[2 * jj + 1][e], hp[jj], mp[jj], lp[jj]);
+        *reinterpret_cast<i32x4*>(dst + 32 * e) = i32x4{(int)hp[0], (int)hp[1], (int)hp[2], (int)hp[3]};
+        *reinterpret_cast<i32x4*>(dst + plane_bytes + 32 * e) = i32x4{(int)mp[0], (int)mp[1], (int)mp[2], (int)mp[3]};
+        *reinterpret_cast<i32x4*>(dst + 2 * plane_bytes + 32 * e) = i32x4{(int)lp[0], (int)lp[1], (int)lp[2], (int)lp[3]};
+    }
+}
+
+size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW) { return (size_t)(3 * N * C * HW * 2); }
+
+int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st) {
+    if (!x || !img || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3) || (mode != 0 && !table) || (mode == 2 && !x2) || mode < 0 || mode > 2) {
+        set_error("fx_act_image: bad argument (N=%d C=%d HW=%d mode=%d; C %% 16 == 0 and HW %% 4 == 0 are required)", N, C, HW, mode); return P3D_EINVAL;
+    }
+    const size_t plane = (size_t)N * C * HW * 2;
+    const dim3 grid((unsigned)ceil_div((int64_t)N * (HW >> 2) * 2, 256), (unsigned)(C >> 4));
+    if (mode == 0) hipLaunchKernelGGL(fx_act_image_kernel<0>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
+    else if (mode == 1) hipLaunchKernelGGL(fx_act_image_kernel<1>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
+    else hipLaunchKernelGGL(fx_act_image_kernel<2>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
+    return check_launch("fx_act_image");
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
@@ -863,7 +792,8 @@ static int fx_min_m(int asked) {      // tuning aid: P3D_FX_MIN_M lowers the cha
 
 static bool fx_common(const p3d_conv_desc* d) {
     return fx_enabled() && d->c_offset == 0 && d->c_total == d->C && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
-           (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31);
+           (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31) &&
+           (int64_t)(d->K + 127) * (d->C + 127) * d->R * d->S * 6 < (1ll << 31);          // (32-bit byte offsets into the weight images)
 }
 // forward: reduction channels C in steps of 16, four consecutive output pixels in one row, a reasonably filled channel tile
 bool fx_fwd_applies(const p3d_conv_desc* d, int min_m) {
@@ -887,11 +817,10 @@ void fx_tune(int what, int value) { (what == 0 ? g_force_wgrad_splits : what == 
 struct FxSplit { int splits, kchunk; };
 static FxSplit fx_plan_split(int64_t tiles, int nk) {
     FxSplit s{1, 0};
-    static const bool nosplit = getenv("P3D_FX_NOSPLIT") != nullptr;      // debugging aid
     int64_t want;
     if (g_force_conv_splits > 0) want = g_force_conv_splits < nk ? g_force_conv_splits : nk;
     else {
-        if (nosplit || tiles > 400 || nk < 64) return s;
+        if (tiles > 400 || nk < 64) return s;
         want = ceil_div(768, tiles);
         if (want > nk / 32) want = nk / 32;
         if (want > 8) want = 8;
@@ -903,7 +832,11 @@ static FxSplit fx_plan_split(int64_t tiles, int nk) {
     return s;
 }
 
-size_t fx_image_bytes(const p3d_conv_desc* d) { return d->R * d->S > 1 ? ((((size_t)d->K * d->C * d->R * d->S * sizeof(float)) + 255) & ~(size_t)255) : 0; }
+size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd) {
+    const int rows = bwd ? C : K, red = bwd ? K : C;
+    return (size_t)RS * ((rows + 127) / 128) * (red / FX_BK) * (3 * FX_PIECE);
+}
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static FxSplit fx_fwd_split(const p3d_conv_desc* d) {
     return fx_plan_split(ceil_div(d->K, FX_BM) * ceil_div((int64_t)d->N * d->Ho * d->Wo, FX_BN), d->R * d->S * (d->C / FX_BK));
@@ -917,13 +850,14 @@ static bool fx_masked_on() { static const bool on = [] { const char* e = getenv(
 bool fx_fwd_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_fwd_applies(d, 64) && fx_fwd_split(d).splits == 1; }
 bool fx_dgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_dgrad_applies(d, 64) && (d->stride != 1 || fx_dgrad_split(d).splits == 1); }
 bool fx_wgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_wgrad_applies(d, 96); }
+// workspace of a call: room for the weight image (built by the call unless the caller hands one in) + the split-K slabs
 size_t fx_fwd_workspace(const p3d_conv_desc* d) {
     const FxSplit s = fx_fwd_split(d);
-    return fx_image_bytes(d) + (s.splits > 1 ? (size_t)s.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
+    return align256(fx_weight_image_bytes(d->K, d->C, d->R * d->S, false)) + (s.splits > 1 ? (size_t)s.splits * d->N * d->K * d->Ho * d->Wo * sizeof(float) : 0);
 }
 size_t fx_dgrad_workspace(const p3d_conv_desc* d) {
     const FxSplit s = fx_dgrad_split(d);
-    return fx_image_bytes(d) + (s.splits > 1 ? (size_t)s.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
+    return align256(fx_weight_image_bytes(d->K, d->C, d->R * d->S, true)) + (s.splits > 1 ? (size_t)s.splits * d->N * d->C * d->H * d->W * sizeof(float) : 0);
 }
 int fx_partial_rows_fwd(const p3d_conv_desc* d) {
     const FxSplit s = fx_fwd_split(d);
@@ -934,22 +868,18 @@ int fx_partial_rows_dgrad(const p3d_conv_desc* d) {
     return s.splits > 1 ? (d->N < 16 ? d->N : 16) : (int)ceil_div((int64_t)d->N * d->H * d->W, FX_BN);
 }
 
-__global__ __launch_bounds__(256) void fx_weight_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ wT, int K, int C, int RS) {
-    const size_t KC = (size_t)K * C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < KC; i += (size_t)gridDim.x * 256)
-        for (int tap = 0; tap < RS; ++tap) wT[(size_t)tap * KC + i] = w[i * RS + tap];
-}
-
 // Pre-split weight images of one conv weight w [K][C][R*S] (fp32): blockIdx.y = 0 the forward image (rows = output channels, reduction = input channels),
-// 1 the data-gradient image (rows = input channels, reduction = output channels).  One thread per 16-B chunk position (tap, row tile, K step, row, half):
-// eight fp32 weights -> three bf16 pieces, written where fx_conv_kernel<2, ..>'s linear 12 KB copy wants them.
+// 1 the data-gradient image (rows = input channels, reduction = output channels); a null image pointer skips that direction.  One thread per 16-B chunk
+// position (tap, row tile, K step, row, half): eight fp32 weights -> three bf16 pieces (here the truncating split: piece = the top 16 bits of what is left;
+// exact like the rounding one), written where fx_conv_kernel's linear 12 KB copy wants them.
 __global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __restrict__ w, unsigned char* __restrict__ img_fwd, unsigned char* __restrict__ img_bwd, int K,
                                                                int C, int RS) {
     const bool bwd = blockIdx.y == 1;
+    unsigned char* img = bwd ? img_bwd : img_fwd;
+    if (!img) return;
     const int rows = bwd ? C : K, red = bwd ? K : C;
     const int tiles = (rows + 127) / 128, ksteps = red / FX_BK;
     const size_t total = (size_t)RS * tiles * ksteps * 256;
-    unsigned char* img = bwd ? img_bwd : img_fwd;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int half = (int)(i & 1), row = (int)((i >> 1) & 127);
         size_t j = i >> 8;
@@ -975,25 +905,19 @@ __global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __re
     }
 }
 
-size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd) {
-    const int rows = bwd ? C : K, red = bwd ? K : C;
-    return (size_t)RS * ((rows + 127) / 128) * (red / FX_BK) * (3 * FX_PIECE);
-}
-
 int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st) {
-    const size_t a = fx_weight_image_bytes(K, C, RS, false) / 48, b = fx_weight_image_bytes(K, C, RS, true) / 48;        // chunk positions (3 chunks each)
+    const size_t a = img_fwd ? fx_weight_image_bytes(K, C, RS, false) / 48 : 0, b = img_bwd ? fx_weight_image_bytes(K, C, RS, true) / 48 : 0;        // chunk positions (3 chunks each)
     const size_t total = a > b ? a : b;
+    if (total == 0) return P3D_OK;
     const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 4096 ? ceil_div((int64_t)total, 256) : 4096);
     hipLaunchKernelGGL(fx_weight_images_kernel, dim3(blocks, 2), dim3(256), 0, st, w, (unsigned char*)img_fwd, (unsigned char*)img_bwd, K, C, RS);
     return check_launch("fx_build_weight_images");
 }
 
-template <int WMODE>
-static void fx_launch_conv(const FxConvParams& p, int pro, int epi, dim3 grid, hipStream_t st) {
-#define P3D_FX_CASE(PRO, EPI) if (pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<WMODE, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
-    if constexpr (WMODE == 0) { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(1, 0) P3D_FX_CASE(1, 1) P3D_FX_CASE(4, 4) }
-    else if constexpr (WMODE == 1) { P3D_FX_CASE(4, 4) P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 2) P3D_FX_CASE(2, 0) P3D_FX_CASE(2, 2) P3D_FX_CASE(3, 0) P3D_FX_CASE(3, 2) }
-    else { P3D_FX_CASE(0, 0) P3D_FX_CASE(0, 1) P3D_FX_CASE(0, 2) }       // image mode: the block executor's default (BatchNorm apply as passes of its own)
+static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, dim3 grid, hipStream_t st) {
+#define P3D_FX_CASE(AM, PRO, EPI) if ((int)img == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
+    P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 4)
+    P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2)
 #undef P3D_FX_CASE
 }
 
@@ -1004,18 +928,20 @@ static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* sl
     else hipLaunchKernelGGL(fx_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
 }
 
-// y = conv(pro(x), w) (+ bias); fuse may be null (plain convolution)
+// y = conv(x, w) (+ bias); fuse may be null (plain convolution from fp32 x, the weight image built here)
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st) {
     const bool masked = fuse && fuse->pmask;
-    const void* wimg = (fuse && !fuse->pro_tab && !masked) ? fuse->wimg : nullptr;
-    if (masked && (!fuse->emask || bias || fuse->pro_tab || fuse->partial || fx_fwd_split(d).splits > 1)) {
-        set_error("fx_conv_fwd: the partial-convolution instance takes both factors, no bias and an unsplit launch"); return P3D_EINVAL;
+    const bool img = fuse && fuse->act_img;
+    const void* wimg = fuse ? fuse->wimg : nullptr;
+    if (masked && (!fuse->emask || bias || img || fuse->partial || fx_fwd_split(d).splits > 1)) {
+        set_error("fx_conv_fwd: the partial-convolution instance takes both factors, fp32 operands, no bias and an unsplit launch"); return P3D_EINVAL;
     }
     const size_t need = fx_fwd_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
     p.X = x; p.Y = y; p.bias = bias;
+    if (img) { p.Ximg = (const unsigned char*)fuse->act_img; p.plane_bytes = (size_t)d->N * d->C * d->H * d->W * 2; }
     p.N = d->N; p.Cred = d->C; p.Hi = d->H; p.Wi = d->W; p.M = d->K; p.OH = d->Ho; p.OW = d->Wo; p.NP = d->N * d->Ho * d->Wo;
     p.YH = d->Ho; p.YW = d->Wo; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
     p.R = d->R; p.S = d->S; p.nR = d->R; p.nS = d->S; p.ntap = d->R * d->S; p.r0 = 0; p.rstep = 1; p.s0 = 0; p.sstep = 1;
@@ -1023,16 +949,14 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     p.accumulate = d->accumulate;
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
-    if (wimg) { p.Wimg = (const unsigned char*)wimg; if (RS > 1) ws += fx_image_bytes(d); }
-    else if (RS > 1) {
-        const int64_t kc = (int64_t)d->K * d->C;
-        hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
-        p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
-        ws += fx_image_bytes(d);
-    } else { p.W = w; p.w_ts = 0; p.w_ld = d->C; }
+    if (!wimg) {
+        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, ws, nullptr, st)) return e;
+        wimg = ws;
+    }
+    ws += align256(fx_weight_image_bytes(d->K, d->C, RS, false));
+    p.Wimg = (const unsigned char*)wimg;
     int pro = 0, epi = 0;
     if (fuse) {
-        if (fuse->pro_tab) { pro = 1; p.tab = fuse->pro_tab; }
         if (fuse->partial) { epi = 1; p.partial = fuse->partial; }
         if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
@@ -1041,46 +965,43 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     const FxSplit sp = fx_fwd_split(d);
     if (sp.splits > 1) {
         p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
-        if (wimg) fx_launch_conv<2>(p, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
-        else fx_launch_conv<0>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        fx_launch_conv(p, img, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
         fx_launch_reduce(epi, dim3((unsigned)d->K, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, y, bias, sp.splits, p.slab_stride, d->N, d->K,
                          d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial);
-    } else if (wimg) {
-        fx_launch_conv<2>(p, 0, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     } else {
-        fx_launch_conv<0>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+        fx_launch_conv(p, img, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     }
     return check_launch("fx_conv_fwd");
 }
 
-// dx (=|+=) dgrad(pro(dy), w); strided: one launch per parity class of the input, written straight into dx
+// dx (=|+=) dgrad(dy, w); strided: one launch per parity class of the input, written straight into dx
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,
                       hipStream_t st) {
     const bool masked = fuse && fuse->pmask;
-    const void* wimg = (fuse && !fuse->pro_tab && !masked) ? fuse->wimg : nullptr;
-    if (masked && (!fuse->emask || fuse->pro_tab || fuse->partial || (d->stride == 1 && fx_dgrad_split(d).splits > 1))) {
-        set_error("fx_conv_dgrad: the partial-convolution instance takes both factors and an unsplit launch"); return P3D_EINVAL;
+    const bool img = fuse && fuse->act_img;
+    const void* wimg = fuse ? fuse->wimg : nullptr;
+    if (masked && (!fuse->emask || img || fuse->partial || (d->stride == 1 && fx_dgrad_split(d).splits > 1))) {
+        set_error("fx_conv_dgrad: the partial-convolution instance takes both factors, fp32 operands and an unsplit launch"); return P3D_EINVAL;
     }
     const size_t need = fx_dgrad_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxConvParams p{};
     p.X = dy; p.Y = dx;
+    if (img) { p.Ximg = (const unsigned char*)fuse->act_img; p.plane_bytes = (size_t)d->N * d->K * d->Ho * d->Wo * 2; }
     p.N = d->N; p.Cred = d->K; p.Hi = d->Ho; p.Wi = d->Wo; p.M = d->C;
     p.YH = d->H; p.YW = d->W;
     p.R = d->R; p.S = d->S;
     p.accumulate = d->accumulate;
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
-    if (wimg) { p.Wimg = (const unsigned char*)wimg; if (RS > 1) ws += fx_image_bytes(d); }
-    else if (RS > 1) {
-        const int64_t kc = (int64_t)d->K * d->C;
-        hipLaunchKernelGGL(fx_weight_tapmajor_kernel, dim3((unsigned)(ceil_div(kc, 256) < 2048 ? ceil_div(kc, 256) : 2048)), dim3(256), 0, st, w, (float*)ws, d->K, d->C, RS);
-        p.W = (const float*)ws; p.w_ts = (size_t)d->K * d->C; p.w_ld = d->C;
-        ws += fx_image_bytes(d);
-    } else { p.W = w; p.w_ts = 0; p.w_ld = d->C; }
+    if (!wimg) {
+        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, nullptr, ws, st)) return e;
+        wimg = ws;
+    }
+    ws += align256(fx_weight_image_bytes(d->K, d->C, RS, true));
+    p.Wimg = (const unsigned char*)wimg;
     int pro = 0, epi = 0;
     if (fuse) {
-        if (fuse->pro_tab) { pro = fuse->pro_masked ? 2 : 3; p.tab = fuse->pro_tab; p.X2 = fuse->pro_c; }
         if (fuse->partial) { epi = 2; p.partial = fuse->partial; p.ep_c = fuse->ep_c; p.ep_tab = fuse->ep_tab; }
         if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
@@ -1093,14 +1014,11 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         const FxSplit sp = fx_dgrad_split(d);
         if (sp.splits > 1) {
             p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
-            if (wimg) fx_launch_conv<2>(p, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
-            else fx_launch_conv<1>(p, pro, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            fx_launch_conv(p, img, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
             fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
                              d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
-        } else if (wimg) {
-            fx_launch_conv<2>(p, 0, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         } else {
-            fx_launch_conv<1>(p, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+            fx_launch_conv(p, img, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         }
         return check_launch("fx_conv_dgrad");
     }
@@ -1110,26 +1028,24 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     p.OH = d->H / st2; p.OW = d->W / st2; p.NP = d->N * p.OH * p.OW; p.oys = st2; p.oxs = st2;
     p.hmul = 1; p.wmul = 1;
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
-    bool any_dead = false;
     for (int ph = 0; ph < st2; ++ph)
         for (int pw = 0; pw < st2; ++pw) {
             int nr = 0, ns = 0, r0 = -1, r1 = -1, q0 = -1, q1 = -1;
             for (int r = 0; r < d->R; ++r) { const int tt = ph + d->pad - r * d->dil; if (((tt % st2) + st2) % st2 == 0) { if (r0 < 0) r0 = r; else if (r1 < 0) r1 = r; ++nr; } }
             for (int s = 0; s < d->S; ++s) { const int tt = pw + d->pad - s * d->dil; if (((tt % st2) + st2) % st2 == 0) { if (q0 < 0) q0 = s; else if (q1 < 0) q1 = s; ++ns; } }
-            if (nr == 0 || ns == 0) { any_dead = true; continue; }
+            if (nr == 0 || ns == 0) continue;      // a class no tap reaches keeps what dx held: see fx_dgrad_has_dead_classes
             FxConvParams c = p;
             c.nR = nr; c.nS = ns; c.ntap = nr * ns; c.r0 = r0; c.rstep = r1 < 0 ? 1 : r1 - r0; c.s0 = q0; c.sstep = q1 < 0 ? 1 : q1 - q0;
             const int th = ph + d->pad - r0 * d->dil, tw = pw + d->pad - q0 * d->dil;       // divisible by the stride
             c.hoff = th >= 0 ? th / st2 : -((-th) / st2); c.hstep = -(c.rstep * d->dil) / st2;
             c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
             c.oy0 = ph; c.ox0 = pw;
-            if (wimg) fx_launch_conv<2>(c, 0, 0, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
-            else fx_launch_conv<1>(c, pro, epi, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            fx_launch_conv(c, img, pro, epi, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
         }
-    (void)any_dead;      // classes no tap reaches keep what dx held: the caller zero-fills dx first unless it accumulates (p3d_conv2d_dgrad does)
     return check_launch("fx_conv_dgrad");
 }
 
+// input pixels of a strided 1x1 that no tap reaches: fx_conv_dgrad leaves them untouched, so a caller that does not accumulate zero-fills dx first
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 && d->R == 1; }
 
 // How many slabs (splits of the pixel reduction) a weight gradient is cut into.  Measured on MI355X over the ResNet layer classes at batch 64
@@ -1140,8 +1056,7 @@ bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 &&
 int fx_wgrad_splits(const p3d_conv_desc* d) {
     const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
-    static const int env_target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning aids
-    static const int minsteps = [] { const char* e = getenv("P3D_FX_WGRAD_MINSTEPS"); return e ? atoi(e) : 32; }();
+    static const int env_target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning aid
     int64_t target;
     if (g_wgrad_target > 0) target = g_wgrad_target;
     else if (env_target > 0) target = env_target;
@@ -1150,7 +1065,7 @@ int fx_wgrad_splits(const p3d_conv_desc* d) {
     else if (d->stride > 1) target = tiles < 16 ? 768 : 512;
     else target = 576;
     int64_t splits = (2 * target + tiles) / (2 * tiles);                 // nearest
-    if (splits > total / minsteps) splits = total / minsteps;           // at least 32 K steps per block
+    if (splits > total / 32) splits = total / 32;                        // at least 32 K steps per block
     if (g_force_wgrad_splits > 0) splits = g_force_wgrad_splits < total ? g_force_wgrad_splits : total;
     if (splits < 1) splits = 1;
     const int64_t spb = ceil_div(total, splits);
@@ -1165,19 +1080,21 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.nsplit = splits;
     p.spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / FX_BK), splits);
-    int pa = 0, pb = 0;
+    bool aimg = false, bimg = false, masked = false;
     if (fuse) {
-        if (fuse->pro_tab) { pa = fuse->pro_masked ? 2 : 3; p.atab = fuse->pro_tab; p.DY2 = fuse->pro_c; }
-        if (fuse->x_tab) { pb = 1; p.btab = fuse->x_tab; }
+        if (fuse->dy_img) { aimg = true; p.DYimg = (const unsigned char*)fuse->dy_img; p.dy_plane = (size_t)d->N * d->K * d->Ho * d->Wo * 2; }
+        if (fuse->x_img) { bimg = true; p.Ximg = (const unsigned char*)fuse->x_img; p.x_plane = (size_t)d->N * d->C * d->H * d->W * 2; }
         if (fuse->pmask) {
-            if (pa != 0 || pb != 0 || !fuse->emask) { set_error("fx_conv_wgrad: the partial-convolution instance takes both factors and plain operands"); return P3D_EINVAL; }
-            pa = 4; pb = 2; p.amask = fuse->pmask; p.bmask = fuse->emask;
+            if (aimg || bimg || !fuse->emask) { set_error("fx_conv_wgrad: the partial-convolution instance takes both factors and fp32 operands"); return P3D_EINVAL; }
+            masked = true; p.amask = fuse->pmask; p.bmask = fuse->emask;
         }
     }
+    if ((aimg && (d->K & 15)) || (bimg && (d->C & 15)) || (bimg && !aimg)) { set_error("fx_conv_wgrad: image operands need channel counts in steps of 16 (and a dy image beside an x image)"); return P3D_EINVAL; }
     const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
-#define P3D_FX_WCASE(PA, PB) if (pa == PA && pb == PB) hipLaunchKernelGGL((fx_wgrad_kernel<PA, PB>), grid, dim3(256), 0, st, p);
-    P3D_FX_WCASE(0, 0) P3D_FX_WCASE(4, 2) P3D_FX_WCASE(0, 1) P3D_FX_WCASE(2, 0) P3D_FX_WCASE(2, 1) P3D_FX_WCASE(3, 0) P3D_FX_WCASE(3, 1)
-#undef P3D_FX_WCASE
+    if (masked) hipLaunchKernelGGL((fx_wgrad_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    else if (aimg && bimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false>), grid, dim3(256), 0, st, p);
+    else if (aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fx_wgrad_kernel<false, false, false>), grid, dim3(256), 0, st, p);
     return check_launch("fx_conv_wgrad");
 }
 

@@ -202,6 +202,7 @@ class Trainer:
     # ---- the hot loop --------------------------------------------------------------------------
     def train_step(self, color_image, depth_image, true_cam, true_val):
         """One optimisation step on device tensors; returns the loss as a 0-d device tensor (no host sync)."""
+        self.reducer.begin_step()
         side_out = (self.side_in - 1) // self.stride + 1
         if self.do_fusion:
             cam_feat = self.fusion_infer(color_image, depth_image)
@@ -382,6 +383,7 @@ class Trainer:
 
     def distill_step(self, epoch, color_image, depth_image, true_cam, true_val, atten_map):
         """One iteration of distill_train on device tensors; returns (cam_loss, dist_loss) as 0-d device tensors."""
+        self.reducer.begin_step()
         side_out = (self.side_in - 1) // self.stride + 1
         with torch.no_grad():
             teach_cam, teach_last = self.teach_infer(color_image, depth_image)

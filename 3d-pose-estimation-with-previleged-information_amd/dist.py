@@ -94,11 +94,22 @@ class GradReducer:
                 # of flat_g.  Forward passes are counted per step; with more than one, no bucket is launched from a hook and finish()
                 # sends them all after backward has returned.
                 self._fwd_hook = model.register_forward_pre_hook(self._on_forward)
+        self._warned = False
         self.reset()
 
     def _on_forward(self, module, inputs):
         if torch.is_grad_enabled():
             self._forwards += 1
+            if self._forwards == 2 and not self._warned:
+                self._warned = True
+                import warnings
+                warnings.warn('GradReducer: a second grad-enabled forward before finish(): this step\'s buckets are all-reduced after backward '
+                              '(no overlap). Expected for -semi_teach; otherwise run validation passes under torch.no_grad().')
+
+    def begin_step(self):
+        """Start of a training step: forget forward passes that were never followed by finish() (a validation pass run without no_grad, a
+        warm-up on an attached reducer), which would otherwise defer every bucket of this step to finish()."""
+        self.reset()
 
     def reset(self):
         self._forwards = 0
@@ -184,6 +195,8 @@ def broadcast_state(optimizer, model, src=0, group=None):
         optimizer.dev_state = None
         for buf in model.buffers():
             dist.broadcast(buf, src, group=group)
+    from . import ops
+    ops.weights_changed()          # flat_p was written under the parameter views: derived images (ops_block.weight_images) of the old values are stale
 
 
 def global_valid_divisor(true_val, group=None):

@@ -54,6 +54,7 @@ class GraphedStep:
                 dst.copy_(src)
             for dst, src in zip(tr.model.buffers(), saved_buffers):
                 dst.copy_(src)
+        ops.weights_changed()          # the restore wrote flat_p under the parameter views; the capture below must contain the image rebuild of every weight
         if tr.half_acc:
             from . import ops_half
             ops_half.refresh_weights(tr.model, opt.flat_p)

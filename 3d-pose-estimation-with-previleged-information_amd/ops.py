@@ -795,7 +795,49 @@ def set_x3(on):
 
 
 X3_EPOCH = 0
-WEIGHT_EPOCH = 0          # bumped by FlatAdam after every optimizer step: cached per-weight derivatives (ops_block.weight_images) are stale
+WEIGHT_EPOCH = 0          # bumped whenever parameters are written behind torch's back (FlatAdam's kernels, broadcasts into / restores of flat_p): cached per-weight derivatives (ops_block.weight_images) are stale
+
+
+def weights_changed():
+    """Call after writing parameters through anything torch's version counters do not see on the parameter itself: the optimizer kernels, a
+    broadcast or copy into FlatAdam.flat_p (the parameters are views of it, and an in-place write to the base does not bump a view's _version)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def act_image(x, mode=0, x2=None, table=None, masked=False):
+    """Pre-split activation image of a fp32 NCHW tensor (p3d_fx_act_image): uint8 tensor of 6 bytes per element = three bf16 planes [N][C/16][H*W][16].
+    mode 0: x; 1: relu(x * sc + sh); 2: A * (masked ? x * [x2 * sc + sh > 0] : x) + B * x2 + K, constants per channel from `table` [C][8]."""
+    _need_gpu(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    img = torch.empty(lib().p3d_fx_act_image_bytes(n, c, h * w), dtype=torch.uint8, device=x.device)
+    check(lib().p3d_fx_act_image(mode, _p(x), None if x2 is None else _p(x2.contiguous()), None if table is None else _p(table.contiguous()), int(bool(masked)),
+                                 _p(img), n, c, h * w, _stream()), 'p3d_fx_act_image')
+    return img
+
+
+def conv2d_img(pass_, x_shape, w, stride, pad, dil, x_img=None, dy_img=None, x=None, bias=None, accumulate_into=None):
+    """One pass of a convolution on pre-split image operands (p3d_fx_conv_*_img; what the block executor launches): 'fwd' -> y from x_img,
+    'dgrad' -> dx from dy_img, 'wgrad' -> dw from dy_img and x_img (or the fp32 x).  For tests and tools/conv_bench.py."""
+    _need_gpu(w)
+    w = w.contiguous()
+    d = _desc(x_shape, w.shape, stride, pad, dil)
+    which = {'fwd': 0, 'dgrad': 1, 'wgrad': 2}[pass_]
+    ws = workspace(w.device, lib().p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), which))
+    if which == 0:
+        y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=w.device)
+        check(lib().p3d_fx_conv_fwd_img(ctypes.byref(d), _p(x_img), _p(w), None, None if bias is None else _p(bias), _p(y), _p(ws), ws.numel(), _stream()), 'p3d_fx_conv_fwd_img')
+        return y
+    if which == 1:
+        dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=w.device) if accumulate_into is None else accumulate_into
+        d.accumulate = int(accumulate_into is not None)
+        check(lib().p3d_fx_conv_dgrad_img(ctypes.byref(d), _p(dy_img), _p(w), None, _p(dx), _p(ws), ws.numel(), _stream()), 'p3d_fx_conv_dgrad_img')
+        return dx
+    dw = torch.empty_like(w)
+    check(lib().p3d_fx_conv_wgrad_img(ctypes.byref(d), _p(dy_img), None if x is None else _p(x.contiguous()), None if x_img is None else _p(x_img), _p(dw), _p(ws),
+                                      ws.numel(), _stream()), 'p3d_fx_conv_wgrad_img')
+    return dw
 
 
 def profile_convs(on):

@@ -16,9 +16,8 @@ from ._lib import ConvDesc, P3DError, check, lib
 _vp = ctypes.c_void_p
 
 # P3D_BLOCK_SIDE=0: keep the weight-gradient kernels of the block executor on the launch stream.  By default they run on the second HIP stream
-# (p3d_block_bwd orders them with events), as in the per-layer path.  History: with the BatchNorm folded into the operand fetch (P3D_BLOCK_FUSE=1) the
-# two-stream step was not bitwise reproducible run to run, so that mode is single-stream inside the library; the default mode is reproducible
-# (tests/test_step_gpu.py::test_training_is_bitwise_reproducible, tools/debug_det.py on ResNet-18 / -50 at batch 4 .. 64).
+# (p3d_block_bwd orders them with events), as in the per-layer path; the step is bitwise reproducible either way
+# (tests/test_step_gpu.py::test_training_is_bitwise_reproducible).
 BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '1') != '0'
 
 
@@ -31,9 +30,9 @@ class BlockDesc(ctypes.Structure):
 
 class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
-    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
-                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcl', _vp), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
-                ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('dcl_ds', _vp)]
+    _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('aimg', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
+                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcimg', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
+                ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
 
 
 def _one(v):
@@ -144,9 +143,9 @@ class ResidualBlockFn(torch.autograd.Function):
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), c.data_ptr()
             if USE_WEIGHT_IMAGES:
                 io.wimg[slot] = weight_images(conv)[0].data_ptr()
-            if slot < plan.desc.nconv - 1:
-                acts[slot] = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
-                io.a[slot] = acts[slot].data_ptr()
+            if slot < plan.desc.nconv - 1:              # a_slot = relu(bn(c_slot)) exists only as a pre-split image (three bf16 planes: 6 B per element)
+                acts[slot] = torch.empty(6 * c.numel(), dtype=torch.uint8, device=x.device)
+                io.aimg[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32
             row += plan.shapes[slot][1]
             io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -166,6 +165,9 @@ class ResidualBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         block, plan = ctx.block, ctx.plan
         x, out = ctx.saved_tensors
+        if ctx.saved is None:
+            raise P3DError('residual_block: backward called a second time on the same graph (retain_graph / re-entrant checkpointing): the block executor '
+                           'releases its saved activations after the first backward; run the forward again')
         _, _, cs, tables, acts = ctx.saved
         ctx.saved = None
         layers = _layers(block)
@@ -187,7 +189,7 @@ class ResidualBlockFn(torch.autograd.Function):
             if USE_WEIGHT_IMAGES:
                 io.wimgT[slot] = weight_images(conv)[1].data_ptr()
             if slot in acts:
-                io.a[slot] = acts[slot].data_ptr()
+                io.aimg[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32
             row += plan.shapes[slot][1]
             io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
@@ -195,13 +197,11 @@ class ResidualBlockFn(torch.autograd.Function):
             getattr(io, kind)[slot] = g.data_ptr()
         keep = []
         gbuf = torch.empty_like(out)
-        dcl = torch.empty_like(out)
-        io.gbuf, io.dcl = gbuf.data_ptr(), dcl.data_ptr()
-        if d.has_downsample:                                # its BatchNorm's input gradient gets a buffer of its own: no wait for the weight-gradient stream
-            dcl_ds = torch.empty_like(out)
-            keep.append(dcl_ds)
-            io.dcl_ds = dcl_ds.data_ptr()
+        io.gbuf = gbuf.data_ptr()
         for slot, _, _ in layers:
+            dcimg = torch.empty(6 * cs[slot].numel(), dtype=torch.uint8, device=x.device)      # image of d c_slot: what conv slot's wgrad and dgrad read
+            keep.append(dcimg)
+            io.dcimg[slot] = dcimg.data_ptr()
             if slot < d.nconv - 1:
                 da = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
                 keep.append(da)
@@ -227,7 +227,7 @@ class ResidualBlockFn(torch.autograd.Function):
             side_handle = None
         check(L.p3d_block_bwd(ctypes.byref(desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._p(sws), sws.numel(), ops._stream(), side_handle), 'p3d_block_bwd')
         if two:
-            for t in [x, dout, gbuf, dcl, tables] + list(cs.values()) + list(acts.values()) + keep:      # freed by autograd while the second stream may still read them
+            for t in [x, dout, gbuf, tables] + list(cs.values()) + list(acts.values()) + keep:      # freed by autograd while the second stream may still read them
                 t.record_stream(side)
         if direct:
             for _, _, p in params:

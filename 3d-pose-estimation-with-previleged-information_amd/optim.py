@@ -14,8 +14,8 @@ because adapt_learn_rate writes both (depth_train.py:637-638).
 Difference from torch.optim.Adam, by construction: the update runs over the WHOLE flat buffer, so a parameter that received no gradient
 in a step is still pulled by the weight decay (g = wd * p) and its moments decay, where optim.Adam skips parameters whose .grad is None.
 The two agree whenever every registered parameter takes part in every step, which holds for every network / flag combination of the
-reference (only `requires_grad` parameters are registered; frozen ones never enter the buffer).  `P3D_CHECK_GRADS=1` makes
-`clip_and_step*` verify that on the device (a parameter whose gradient range is exactly zero raises).
+reference (only `requires_grad` parameters are registered; frozen ones never enter the buffer).  `clip_and_step*` verify that on the first
+step of every optimizer (a parameter whose gradient range is exactly zero raises), and on every step with `P3D_CHECK_GRADS=1`.
 """
 import math
 import os
@@ -62,6 +62,7 @@ class FlatAdam:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.param_groups = [dict(lr=lr), dict(lr=lr)]
         self.step_count = 0
+        self._checked = False
         self.norm_sq = torch.zeros(1, dtype=torch.float64, device=device)
         self.dev_state = None            # int32[2] on the device (steps taken, steps skipped) once clip_and_step_dev has been used
         self._dev_scratch = None
@@ -77,10 +78,17 @@ class FlatAdam:
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p)
 
     def _check_all_touched(self):
-        if not os.environ.get('P3D_CHECK_GRADS'):
+        # always on the first step (a network / flag combination that leaves a registered parameter out of the graph shows up there), afterwards
+        # only with P3D_CHECK_GRADS=1: the check reads one flag per parameter back from the device
+        if self._checked and not os.environ.get('P3D_CHECK_GRADS'):
             return
-        for name, p in zip(self.names, self.params):
-            if p.grad is not None and not bool(p.grad.ne(0).any()):
+        if self.flat_g.is_cuda and torch.cuda.is_current_stream_capturing():
+            return                                           # (no read-back inside a graph capture; the first eager step checks)
+        self._checked = True
+        live = [(n, p) for n, p in zip(self.names, self.params) if p.grad is not None]
+        touched = torch.stack([p.grad.ne(0).any() for _, p in live]).cpu().tolist()          # one read-back for all parameters
+        for (name, _), ok in zip(live, touched):
+            if not ok:
                 raise RuntimeError('FlatAdam: parameter %r received no gradient this step; the flat update would still apply weight decay to it' % name)
 
     def clip_and_step(self, max_norm, grad_scale=1.0, skip_nonfinite=False):
@@ -94,7 +102,7 @@ class FlatAdam:
         if skip_nonfinite and not math.isfinite(float(self.norm_sq.item())):
             return False
         self.step_count += 1
-        ops.WEIGHT_EPOCH += 1
+        ops.weights_changed()
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, max_norm or 0.0,
                       self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
@@ -108,7 +116,7 @@ class FlatAdam:
             self._dev_scratch = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
         self._check_all_touched()
         self.norm_sq.zero_()
-        ops.WEIGHT_EPOCH += 1
+        ops.weights_changed()
         ops.l2norm_sq_accum(self.flat_g, self.norm_sq)
         ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0], self.betas[1],
                           self.eps, self.weight_decay, self.dev_state, max_norm or 0.0, self.norm_sq, grad_scale, skip_nonfinite, self._dev_scratch)

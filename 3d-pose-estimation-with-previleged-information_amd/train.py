@@ -66,6 +66,7 @@ class Trainer:
         return ops.pose_loss(relat_cam, true_cam, true_val, self.data_info.key_index, 1.0, self.criterion, count_override=count)
 
     def train_step(self, image, true_cam, true_val):
+        self.reducer.begin_step()
         count = p3d_dist.global_valid_divisor(true_val) if self.world > 1 else None
         loss, _ = self._head(image, true_cam, true_val, count)
         self.optimizer.zero_grad()
@@ -89,6 +90,7 @@ class Trainer:
         return cam_loss, mat_loss, spec_cam, spec_mat, relat_cam, count
 
     def joint_step(self, image, true_cam, true_mat, true_val, intrinsics, do_track):
+        self.reducer.begin_step()
         cam_loss, mat_loss, _, spec_mat, relat_cam, count = self._joint_head(image, true_cam, true_mat, true_val)
         loss = cam_loss + mat_loss
         recon_loss = None

@@ -32,8 +32,31 @@ FLAGS = ['-suffix', 'bench', '-data_name', 'h36m', '-save_path', '/tmp/p3d_bench
          '-weight_decay', '4e-5', '-grad_norm', '5']
 
 
-def cpu_baseline(pkg, model_name, batch, steps):
-    """The oracle's PyTorch-CPU port of the same step, timed on this box's host cores (bounded sample)."""
+def contract_parity(pkg, model_name, batch, device, want):
+    """One step of the HIP trainer from the oracle's deterministic weights on the batch the oracle's warm-up step saw (BASELINE batch, the
+    workload of `value`): relative error of the loss and of the 3-D joints (depth_train.py:393-405) against the CPU port's step."""
+    import numpy as np
+    import torch
+    args = pkg.opts.parse(['-model', model_name] + FLAGS)
+    model, _ = pkg.depth_main.create_model(args)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in pkg.synth.det_state_dict(shapes, 0).items()})
+    model = model.to(device).train()
+    trainer = pkg.depth_train.Trainer(args, model, pkg.utils.get_info())
+    trainer.verbose = False
+    trainer.adapt_learn_rate(1)
+    c, d, tc, tv = pkg.synth.make_batch(batch, side=256, rank=0, step=0)
+    loss = float(trainer.train_step(torch.from_numpy(c).to(device), None, torch.from_numpy(tc).to(device), torch.from_numpy(tv).to(device)))
+    spec = trainer.last_spec_cam.cpu().numpy()
+    return dict(loss_rel=float('%.3e' % (abs(loss - want['loss']) / abs(want['loss']))),
+                spec_cam_rel=float('%.3e' % (np.abs(spec - want['spec_cam']).max() / np.abs(want['spec_cam']).max())),
+                batch=batch, loss=round(loss, 6), oracle_loss=round(float(want['loss']), 6), tolerance=1e-3,
+                note='HIP step vs oracle/torch_port.py step, same deterministic weights (synth.det_state_dict) and batch (synth.make_batch step 0)')
+
+
+def cpu_baseline(pkg, model_name, batch, steps, device=None):
+    """The oracle's PyTorch-CPU port of the same step, timed on this box's host cores (bounded sample).  Its warm-up step is also the checker of
+    `parity_at_contract_batch`: the HIP trainer repeats that step from the same weights on the same batch."""
     import torch
     from oracle.torch_port import TorchPort
     torch.manual_seed(0)
@@ -42,13 +65,15 @@ def cpu_baseline(pkg, model_name, batch, steps):
     port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family='depthnet', model=model_name)
     cores = torch.get_num_threads()
     batches = [pkg.synth.make_batch(batch, side=256, rank=0, step=i) for i in range(2)]
-    port.train_step(*batches[0], lr=1e-5)                          # warm-up
+    first = port.train_step(*batches[0], lr=1e-5)                  # warm-up (and the oracle side of the parity check)
     t0 = time.perf_counter()
     for i in range(steps):
         port.train_step(*batches[i % 2], lr=1e-5)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit='crops/s', cores=cores, kind='port', cpu=cpu_model(),
+    base = dict(value=round(batch * steps / dt, 3), unit='crops/s', cores=cores, kind='port', cpu=cpu_model(),
                 sample='%s 256x256 bs=%d, %d timed steps after 1 warm-up (oracle/torch_port.py, fp32)' % (model_name, batch, steps))
+    parity = contract_parity(pkg, model_name, batch, device, first) if device is not None else None
+    return base, parity
 
 
 def cpu_model():
@@ -158,6 +183,10 @@ def main():
             pkg.dist.init_from_env()
         trainer.attach_reducer()
 
+    # what the process group itself reports (N > 1: 'nccl' = RCCL with the world size it was built with; N = 1: no group)
+    dist_backend = dist.get_backend() if dist.is_initialized() else None
+    dist_world = dist.get_world_size() if dist.is_initialized() else 1
+
     def sync():
         if dist.is_initialized():
             dist.barrier()
@@ -183,7 +212,8 @@ def main():
     if opt.lean:
         if rank == 0:
             print(json.dumps({'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU', 'value': round(opt.batch * world * opt.steps / elapsed, 2), 'unit': 'crops/s',
-                              'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True}), flush=True)
+                              'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True,
+                              'dist_backend': dist_backend, 'dist_world_size': dist_world}), flush=True)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -275,7 +305,7 @@ def main():
         # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r02_traffic.json);
         # a profiler cannot run inside the timed region, so the committed measurement of the same workload is quoted
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+        tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_traffic.json' % r) for r in (3, 2)) if os.path.exists(q)), '')
         if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64 and opt.family == 'depthnet' and not opt.half:
             with open(tpath) as f:
                 traffic = round(json.load(f)['bytes_per_launch'])
@@ -295,6 +325,7 @@ def main():
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4),
+                       'dist_backend': dist_backend, 'dist_world_size': dist_world,
                        'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank)))},
             'roofline': {'bound': 'mfma',
                          'kernel': 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)' if opt.half else
@@ -314,7 +345,9 @@ def main():
                          'whole_step_frac_of_fp32_mfma_peak': None if opt.half else round(step_tflops / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
         if world == 1 and not opt.no_cpu_baseline and opt.family == 'depthnet' and not opt.half:
-            out['cpu_baseline'] = cpu_baseline(pkg, opt.model, opt.cpu_batch, opt.cpu_steps)
+            del trainer, model, batches                     # the parity step builds its own model
+            torch.cuda.empty_cache()
+            out['cpu_baseline'], out['parity_at_contract_batch'] = cpu_baseline(pkg, opt.model, opt.cpu_batch, opt.cpu_steps, device)
         if fp32_line is not None:
             out['fp32_mfma_only'] = fp32_line
         print(json.dumps(out), flush=True)

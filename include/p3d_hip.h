@@ -145,7 +145,8 @@ typedef struct p3d_block_io {
     const void* wimg[4];        /* pre-split weight images (p3d_fx_weight_images) of w[i] for the forward pass / the data gradient, or NULL: the kernels split */
     const void* wimgT[4];       /*   the fp32 weights on the fly.  The caller rebuilds an image whenever its weight changes. */
     float* c[4];
-    float* a[4];                /* a[i] = relu(bn_i(c[i])), i < nconv-1: written by forward, read by backward (the x operand of conv i+1's weight gradient) */
+    void* aimg[4];              /* pre-split activation image (p3d_fx_act_image_bytes(N, K_i, Ho_i * Wo_i) bytes) of a[i] = relu(bn_i(c[i])), i < nconv-1: written by
+                                   forward; read by conv i+1 in forward and by its weight gradient in backward.  a[i] itself never exists as fp32. */
     float* table[4];
     const float* gamma[4];
     const float* beta[4];
@@ -154,16 +155,17 @@ typedef struct p3d_block_io {
     /* backward only */
     const float* dout;
     float* gbuf;
-    float* dcl;                 /* like out: scratch for the input gradient of the closing BatchNorm (then of the downsample BatchNorm) */
+    void* dcimg[4];             /* scratch, one per convolution (slot 3: the downsample branch): image of d c_i, the gradient w.r.t. conv i's raw output
+                                   (p3d_fx_act_image_bytes(N, K_i, Ho_i * Wo_i) bytes); read by conv i's weight gradient and data gradient */
     float* da[4];
     float* dx;
     float* dw[4];
     float* dgamma[4];
     float* dbeta[4];
-    float* dcl_ds;              /* like dcl, for the downsample BatchNorm's input gradient; may be NULL (dcl is re-used then, after a wait for the weight-gradient stream) */
 } p3d_block_io;
 
-/* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 96, four-pixel-aligned rows, stride <= 2) */
+/* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 64, four-pixel-aligned rows, maps of a
+ * multiple of 16 pixels, stride <= 2 and never on a 1x1 of the main chain) */
 int32_t p3d_block_supported(const p3d_block_desc* b);
 int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
 int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* stream);
@@ -175,6 +177,22 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
  * each (filter tap, 128-channel tile, 16-deep K step) of the conv kernels consumes, so the weight operand costs the kernels no arithmetic.  w [K][C][R*S]. */
 int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_bytes, size_t* bwd_bytes);
 int32_t p3d_fx_weight_images(const float* w, int32_t K, int32_t C, int32_t RS, void* img_fwd, void* img_bwd, void* stream);
+
+/* Pre-split activation images: a fp32 NCHW tensor [N][C][HW] (C % 16 == 0, HW % 4 == 0) as three bf16 planes [N][C/16][HW][16] with hi + mid + lo == the fp32
+ * value exactly -- the form in which the x3 convolution kernels take an operand without splitting it (16-B copies into LDS whatever the filter tap).
+ * mode 0: the tensor x itself; 1: relu(x * sc + sh) (depthnet.py:98-105: relu(bn(conv))); 2: A * (masked ? x * [x2 * sc + sh > 0] : x) + B * x2 + K, the
+ * BatchNorm-backward map of the gradient x at the raw conv output x2.  table: the layer's [C][8] floats {sc, sh, mean, invstd, A, B, K, 0} as p3d_block_io.table. */
+size_t p3d_fx_act_image_bytes(int32_t N, int32_t C, int32_t HW);
+int32_t p3d_fx_act_image(int32_t mode, const float* x, const float* x2, const float* table, int32_t masked, void* img, int32_t N, int32_t C, int32_t HW, void* stream);
+/* The three passes of a convolution on image operands (what p3d_block_* launches inside a block).  pass: 0 forward, 1 data gradient, 2 weight gradient.
+ * wimg / wimgT: the p3d_fx_weight_images image of w for that pass, or NULL (built into the workspace).  wgrad: x (fp32) is read when x_img is NULL. */
+size_t p3d_fx_conv_img_workspace_bytes(const p3d_conv_desc* d, int32_t pass);
+int32_t p3d_fx_conv_fwd_img(const p3d_conv_desc* d, const void* x_img, const float* w, const void* wimg, const float* bias, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int32_t p3d_fx_conv_dgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* w, const void* wimgT, float* dx, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int32_t p3d_fx_conv_wgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* x, const void* x_img, float* dw, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */

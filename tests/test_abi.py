@@ -37,12 +37,13 @@ def test_workspace_queries_are_host_only(pkg):
     lib = pkg._lib.lib()
     d = pkg.ops._desc((64, 256, 16, 16), (256, 256, 3, 3), 1, 1, 1)
     assert lib.p3d_conv2d_wgrad_workspace_bytes(ctypes.byref(d)) >= 256 * 256 * 9 * 4
-    slabs, image = 3 * 64 * 256 * 16 * 16 * 4, 256 * 256 * 9 * 4             # stride 1: optional split-K slabs + optional tap-major weight image
+    slabs, image = 3 * 64 * 256 * 16 * 16 * 4, 256 * 256 * 9 * 6             # stride 1: optional split-K slabs + the pre-split weight image (three bf16 pieces per weight)
     assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d)) in (0, slabs, image, slabs + image)
     d1 = pkg.ops._desc((64, 64, 64, 64), (256, 64, 1, 1), 1, 0, 1)
-    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d1)) == 0                              # thousands of blocks: never split
+    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d1)) in (0, 128 * 256 * 6)              # thousands of blocks: never split; image rows are padded to the 128-row tile
     d2 = pkg.ops._desc((4, 128, 64, 64), (128, 128, 3, 3), 2, 1, 1)
-    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d2)) == 4 * 4 * 128 * 32 * 32 * 4
+    assert lib.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d2)) in (4 * 4 * 128 * 32 * 32 * 4, 128 * 128 * 9 * 6)          # fp32-MFMA class staging | x3 weight image
+    assert lib.p3d_fx_act_image_bytes(64, 256, 256) == 3 * 64 * 256 * 256 * 2
     assert lib.p3d_bn_workspace_bytes(64, 256, 256) > 0
     bad = pkg.ops._desc((4, 128, 64, 64), (128, 128, 3, 3), 2, 1, 1)
     bad.Ho = 7

@@ -41,3 +41,23 @@ def test_bench_line_schema():
     assert side['unit'] == 'crops/s' and side['value'] > 0 and 'NOT the contract' in side['note']
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['unit'] == 'crops/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
+    # the CPU leg's first step doubles as the oracle of the contract workload (ResNet-50, batch 64): north_star bar 1e-3 on loss and joints
+    par = line['parity_at_contract_batch']
+    assert par['batch'] == 64 and par['loss_rel'] < 1e-3 and par['spec_cam_rel'] < 1e-3, par
+    assert line['config']['dist_backend'] is None and line['config']['dist_world_size'] == 1          # N = 1: no process group
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks (depth_main.py:72's -n_cudas N needs no launcher either).  On the one-GPU
+    box both ranks share cuda:0 and exchange gradients through gloo (P3D_BENCH_SHARE_GPU=1): the launcher, rendezvous on 127.0.0.1, replica
+    broadcast, bucketed all-reduce, barriers and MAX-reduced timing of the N > 1 flow run end to end; rank 0 prints ONE line."""
+    env = dict(os.environ, P3D_BENCH_SHARE_GPU='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--lean', '--steps', '3', '--warmup', '1', '--batch', '8'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['lean'] is True and line['value'] > 0
+    assert line['dist_backend'] == 'gloo' and line['dist_world_size'] == 2          # what the process group itself reports

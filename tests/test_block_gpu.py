@@ -71,15 +71,34 @@ def reference(block, x0, dy, with_ds):
     xr = x0.double().requires_grad_(True)
     out, closest = xr, float('inf')
     chain = block._chain
+    bn_io = []                                                                          # (BatchNorm name, its input, its output) for the reduction scales below
     for i, (cname, bname) in enumerate(chain):
-        out = getattr(ref, bname)(getattr(ref, cname)(out))
+        pre = getattr(ref, cname)(out)
+        out = getattr(ref, bname)(pre)
+        out.retain_grad()
+        bn_io.append((bname, pre, out))
         if i < len(chain) - 1:
             closest = min(closest, float(out.detach().abs().min()))
             out = out.relu()
-    res = xr if not with_ds else ref.downsample[1](ref.downsample[0](xr))
+    if with_ds:
+        pre = ref.downsample[0](xr)
+        res = ref.downsample[1](pre)
+        res.retain_grad()
+        bn_io.append(('downsample.1', pre, res))
+    else:
+        res = xr
     closest = min(closest, float((out + res).detach().abs().min()))
     yr = (out + res).relu()
     yr.backward(dy.double())
+    # what each BatchNorm parameter gradient sums over: dbeta = sum g, dgamma = sum g * xhat; sum |terms| is the scale rounding errors of the sum live on
+    ref._grad_scales = {}
+    with torch.no_grad():
+        for bname, pre, o in bn_io:
+            g = o.grad
+            mean, var = pre.mean((0, 2, 3), keepdim=True), pre.var((0, 2, 3), unbiased=False, keepdim=True)
+            xhat = (pre - mean) / torch.sqrt(var + 1e-5)
+            ref._grad_scales[bname + '.bias'] = g.abs().sum((0, 2, 3))
+            ref._grad_scales[bname + '.weight'] = (g * xhat).abs().sum((0, 2, 3))
     return ref, xr, yr.detach(), closest
 
 
@@ -128,6 +147,90 @@ def test_fused_block_matches_per_layer_path_and_float64(case, pkg):
             if 'tracked' in k:
                 assert int(got['buffers'][k]) == int(v) + 1          # (the float64 copy runs functional batch_norm, which does not count)
     assert rel(fused['y'], plain['y']) < 1e-5 and err(fused['dx'], plain['dx']) < tol
+
+
+# The eight block geometries of ResNet-50 at the bench's size (256 x 256 crops, -stride 16, batch 64: depthnet.py:59-116,130-146), i.e. the kernel
+# instances, split plans, partial-sum row counts and half-dead tiles that carry the bench step, each through p3d_block_fwd / p3d_block_bwd:
+#            name       inplanes planes stride dil  H  downsample
+R50_BLOCKS = [('layer1.0', 64, 64, 1, 1, 64, True), ('layer1.1', 256, 64, 1, 1, 64, False),
+              ('layer2.0', 256, 128, 2, 1, 64, True), ('layer2.1', 512, 128, 1, 1, 32, False),
+              ('layer3.0', 512, 256, 2, 1, 32, True), ('layer3.1', 1024, 256, 1, 1, 16, False),
+              ('layer4.0', 1024, 512, 1, 2, 16, True), ('layer4.1', 2048, 512, 1, 1, 16, False)]
+
+
+def _decide_relus(block, seed):
+    """BatchNorm parameters that put every pre-ReLU value far from zero: beta = +-8 per channel (random sign) and gamma in [0.5, 1] on the inner
+    layers, beta = +-14 on the closing layer (its ReLU sees bn(c) + shortcut, |shortcut| < 6), a small-offset downsample BatchNorm.  A ReLU
+    then is on or off for a whole channel, whatever the arithmetic, and gradients can be compared element by element at batch 64 -- with
+    ordinary parameters ~1e-6 of the 10^7..10^8 activations of these blocks lie within fp32 rounding of zero, and a ReLU that two correct
+    implementations put on different sides moves single gradient entries by percents (the norm-wise half of the test covers that regime)."""
+    gen = torch.Generator().manual_seed(seed)
+    last = len(block._chain) - 1
+    with torch.no_grad():
+        for i, (_, bname) in enumerate(block._chain):
+            bn = getattr(block, bname)
+            sign = torch.where(torch.rand(bn.bias.numel(), generator=gen) < 0.5, -1.0, 1.0)
+            bn.weight.copy_((0.5 + 0.5 * torch.rand(bn.weight.numel(), generator=gen)).to(bn.weight.device))
+            bn.bias.copy_((sign * (14.0 if i == last else 8.0)).to(bn.bias.device))
+        if block.downsample is not None:
+            bn = block.downsample[1]
+            bn.weight.copy_((0.5 + 0.5 * torch.rand(bn.weight.numel(), generator=gen)).to(bn.weight.device))
+            bn.bias.copy_((0.3 * torch.randn(bn.bias.numel(), generator=gen)).to(bn.bias.device))
+
+
+def _sampled_max_err(got, want, rng, count=4096):
+    """max |got - want| over `count` random entries (all of them if the tensor is smaller), relative to max |want| over the whole tensor."""
+    g, w = got.reshape(-1), want.reshape(-1)
+    if g.numel() > count:
+        idx = torch.from_numpy(rng.choice(g.numel(), count, replace=False)).to(g.device)
+        g, w_s = g[idx], w[idx]
+    else:
+        w_s = w
+    return ((g.double() - w_s.double()).abs().max() / w.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('geom', R50_BLOCKS, ids=[g[0] for g in R50_BLOCKS])
+def test_resnet50_block_geometries_at_batch_64(geom, pkg):
+    name, inplanes, planes, stride, dil, h, with_ds = geom
+    n = 64
+    rng = np.random.default_rng(inplanes + planes + h)
+    # (a) decided ReLUs: element-wise, >= 4096 sampled entries of y, dx and every weight gradient, all of dgamma / dbeta, against float64
+    block = build(pkg, 'bottleneck', inplanes, planes, stride, dil, with_ds, seed=11 + inplanes)
+    _decide_relus(block, seed=inplanes + h)
+    gen = torch.Generator(device='cuda').manual_seed(5 + planes)
+    x0 = torch.randn(n, inplanes, h, h, device='cuda', generator=gen).relu_()
+    with torch.no_grad():
+        shape = block(x0).shape
+    dy = torch.randn(shape, device='cuda', generator=gen)
+    assert pkg.ops_block.usable(block, x0)
+    ref, xr, yr, closest = reference(block, x0, dy, with_ds)
+    assert closest > 1e-3, closest                       # no ReLU decision depends on rounding
+    got = run(pkg, block, x0, dy, fused=True)
+    assert _sampled_max_err(got['y'], yr, rng) < 2e-5
+    assert _sampled_max_err(got['dx'], xr.grad, rng) < 2e-5, ('dx', _sampled_max_err(got['dx'], xr.grad, rng))
+    for pname, p in ref.named_parameters():
+        if p.dim() == 4:
+            e = _sampled_max_err(got['grads'][pname], p.grad, rng)
+            assert e < 5e-5, (pname, e)
+        else:
+            # dgamma / dbeta: every channel, against a bound that scales with the channel's own reduction -- sums of N * H * W = 16 k .. 262 k terms that
+            # largely cancel (behind a BatchNorm the incoming gradient sums to ~0 per channel): 2e-6 of the sum of the terms' magnitudes
+            err = (got['grads'][pname].double() - p.grad).abs()
+            bound = 2e-6 * ref._grad_scales[pname] + 1e-30
+            assert (err <= bound).all(), (pname, float((err / bound).max()))
+    for k, v in ref.state_dict().items():
+        if 'running' in k:
+            assert rel(got['buffers'][k], v) < 1e-5, k
+    del ref, xr, yr, got
+    torch.cuda.empty_cache()
+    # (b) ordinary BatchNorm parameters (ReLUs switch element by element; some pre-activations lie within rounding of zero): norm-wise
+    block = build(pkg, 'bottleneck', inplanes, planes, stride, dil, with_ds, seed=13 + inplanes)
+    ref, xr, yr, closest = reference(block, x0, dy, with_ds)
+    got = run(pkg, block, x0, dy, fused=True)
+    assert rel(got['y'], yr) < 2e-5
+    assert rel2(got['dx'], xr.grad) < 2e-3, ('dx', rel2(got['dx'], xr.grad), closest)
+    for pname, p in ref.named_parameters():
+        assert rel2(got['grads'][pname], p.grad) < 8e-3, (pname, rel2(got['grads'][pname], p.grad), closest)
 
 
 def test_blocks_outside_the_executor_stay_on_the_per_layer_path(pkg):

@@ -609,3 +609,72 @@ def test_paste_over_and_brightness_contrast_match_reference_golden(pkg):
         img = dev(g['bc%d.image' % i].astype(np.float32).transpose(2, 0, 1)[None].copy())
         pkg.ops.augment_colour_(img, dev(np.array([[b, c, 0.0, 1.0]], dtype=np.float32)))
         assert np.array_equal(host(img)[0].transpose(1, 2, 0), g['bc%d.out' % i].astype(np.float32)), i
+
+
+# ---- pre-split activation images and the image-fed x3 kernels (what p3d_block_* launches inside a residual block) ------------------------------------
+def _image_planes(img, n, c, hw):
+    """The three bf16 planes of an activation image as float32 [3][N][C][HW] (layout [plane][n][c / 16][hw][16])."""
+    raw = img.view(torch.bfloat16).reshape(3, n, c // 16, hw, 16).float()
+    return raw.permute(0, 1, 2, 4, 3).reshape(3, n, c, hw)
+
+
+def test_activation_image_is_an_exact_split(pkg):
+    """hi + mid + lo == x bit for bit, each piece a bf16, laid out [n][c/16][pixel][16]; modes 1 / 2 apply relu(bn) / the BatchNorm-backward map first."""
+    ops = pkg.ops
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    n, c, h = 3, 48, 12
+    x = torch.randn(n, c, h, h, device='cuda', generator=gen) * torch.logspace(-6, 6, c, device='cuda').view(1, c, 1, 1)
+    planes = _image_planes(ops.act_image(x), n, c, h * h)
+    back = (planes[0].double() + planes[1].double() + planes[2].double()).float().reshape(x.shape)
+    assert torch.equal(back, x)
+    assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -7 + 1e-45).all() and (planes[2].abs() <= planes[0].abs() * 2.0 ** -15 + 1e-45).all()
+    tab = torch.randn(c, 8, device='cuda', generator=gen)
+    x = torch.randn(n, c, h, h, device='cuda', generator=gen)
+    c2 = torch.randn(n, c, h, h, device='cuda', generator=gen)
+    col = lambda j: tab[:, j].view(1, c, 1, 1)
+    want1 = torch.relu(torch.addcmul(col(1), x, col(0)))
+    got1 = _image_planes(ops.act_image(x, 1, table=tab), n, c, h * h).double().sum(0).float().reshape(x.shape)
+    assert (got1 - want1).abs().max() <= 1e-6 * want1.abs().max()
+    for masked in (False, True):
+        g = torch.where(torch.addcmul(col(1), c2, col(0)) > 0, x, torch.zeros_like(x)) if masked else x
+        want2 = col(4) * g + (col(5) * c2 + col(6))
+        got2 = _image_planes(ops.act_image(x, 2, x2=c2, table=tab, masked=masked), n, c, h * h).double().sum(0).float().reshape(x.shape)
+        assert (got2 - want2).abs().max() <= 2e-6 * want2.abs().max()
+
+
+#             N   C    H   K  ks st dil
+IMG_CASES = [(2, 64, 16, 64, 3, 1, 1), (2, 128, 16, 272, 3, 1, 1), (3, 256, 16, 128, 1, 1, 1), (2, 128, 32, 128, 3, 2, 1), (2, 128, 16, 128, 3, 1, 2),
+             (2, 64, 32, 256, 1, 1, 1), (2, 256, 32, 64, 1, 1, 1), (2, 256, 32, 512, 1, 2, 1), (5, 128, 8, 160, 3, 1, 1), (16, 512, 16, 512, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('case', IMG_CASES, ids=['n%d_c%d_h%d_k%d_%dx%d_s%d_d%d' % (c[0], c[1], c[2], c[3], c[4], c[4], c[5], c[6]) for c in IMG_CASES])
+def test_image_fed_kernels_match_the_oracle(case, pkg):
+    """Forward, data gradient and weight gradient fed by pre-split activation images (AMODE 1 / AIMG / BIMG instances of csrc/p3d_fx.hip) against the float64
+    oracle, and against the same kernels fed fp32 tensors (the in-kernel split): the two must agree to rounding of the accumulation order."""
+    ops = pkg.ops
+    n, c, h, k, ks, st, dil = case
+    pad = dil * (ks - 1) // 2
+    gen = torch.Generator(device='cuda').manual_seed(c + k + ks + st)
+    x = torch.randn(n, c, h, h, device='cuda', generator=gen).requires_grad_(True)
+    w = (torch.randn(k, c, ks, ks, device='cuda', generator=gen) / (c * ks * ks) ** 0.5).requires_grad_(True)
+    y0 = ops.conv2d(x, w, None, st, pad, dil)
+    dy = torch.randn(y0.shape, device='cuda', generator=gen)
+    y0.backward(dy)
+    x_img, dy_img = ops.act_image(x.detach()), ops.act_image(dy)
+    y = ops.conv2d_img('fwd', x.shape, w.detach(), st, pad, dil, x_img=x_img)
+    dx = ops.conv2d_img('dgrad', x.shape, w.detach(), st, pad, dil, dy_img=dy_img)
+    dw = ops.conv2d_img('wgrad', x.shape, w.detach(), st, pad, dil, dy_img=dy_img, x_img=x_img)
+    dw2 = ops.conv2d_img('wgrad', x.shape, w.detach(), st, pad, dil, dy_img=dy_img, x=x.detach())
+    torch.cuda.synchronize()
+    xh, wh, dyh = host(x), host(w), host(dy)
+    want_y = ref.conv2d_fwd(xh, wh, None, st, pad, dil)
+    want_dx = ref.conv2d_dgrad(dyh, wh, x.shape, st, pad, dil)
+    want_dw = ref.conv2d_wgrad(dyh, xh, w.shape, st, pad, dil)
+    for name, got, want, tol in (('fwd', y, want_y, 2e-5), ('dgrad', dx, want_dx, 2e-5), ('wgrad', dw, want_dw, 5e-5), ('wgrad fp32 x', dw2, want_dw, 5e-5)):
+        err = np.abs(host(got) - want).max() / np.abs(want).max()
+        assert err < tol, (name, err)
+    for name, got, other in (('fwd', y, y0.detach()), ('dgrad', dx, x.grad), ('wgrad', dw, w.grad)):
+        assert (got - other).abs().max() <= 4e-6 * other.abs().max(), name
+    acc = torch.ones_like(x.detach())
+    ops.conv2d_img('dgrad', x.shape, w.detach(), st, pad, dil, dy_img=dy_img, accumulate_into=acc)
+    assert (acc - 1 - dx).abs().max() <= 4e-6 * dx.abs().max()

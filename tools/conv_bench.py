@@ -43,8 +43,10 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--mode', default='all', help='all | fwd | dgrad | wgrad')
+    ap.add_argument('--img', action='store_true', help='also time the image-fed instances (pre-split activation / gradient images, pre-built weight images: what the block executor launches)')
     a = ap.parse_args()
     tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0)
+    tot_img = dict(fwd=0.0, dgrad=0.0, wgrad=0.0)
     totf = 0.0
     print('%-34s %8s | %8s %6s | %8s %6s | %8s %6s' % ('shape', 'GFLOP', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
     for (c, h, k, ks, st, dil, cnt) in R50:
@@ -69,12 +71,32 @@ def main():
         t_d = timeit(lambda: L.p3d_conv2d_dgrad(ctypes.byref(d), p(dy), p(w), None, None, p(dx), p(wsd), wsd.numel(), st_), a.iters) if (c > 4 and a.mode in ('all', 'dgrad')) else 0.0
         t_w = timeit(lambda: L.p3d_conv2d_wgrad(ctypes.byref(d), p(dy), p(x), None, None, p(dw), p(ws), ws.numel(), st_), a.iters) if a.mode in ('all', 'wgrad') else 1e9
         print('%-34s %8.1f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f' % (tag, gflop, t_f, gflop / t_f, t_d, gflop / t_d if t_d else 0, t_w, gflop / t_w))
+        if a.img and c % 16 == 0 and k % 16 == 0:
+            fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
+            L.p3d_fx_weight_image_bytes(k, c, ks * ks, ctypes.byref(fb), ctypes.byref(bb))
+            wf, wb = torch.empty(fb.value, dtype=torch.uint8, device='cuda'), torch.empty(bb.value, dtype=torch.uint8, device='cuda')
+            L.p3d_fx_weight_images(p(w), k, c, ks * ks, p(wf), p(wb), st_)
+            xi, dyi = ops.act_image(x), ops.act_image(dy)
+            w0 = torch.empty(max(L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 0), 16), dtype=torch.uint8, device='cuda')
+            w1 = torch.empty(max(L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 1), 16), dtype=torch.uint8, device='cuda')
+            w2 = torch.empty(max(L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 2), 16), dtype=torch.uint8, device='cuda')
+            i_f = timeit(lambda: L.p3d_fx_conv_fwd_img(ctypes.byref(d), p(xi), p(w), p(wf), None, p(y), p(w0), w0.numel(), st_), a.iters)
+            i_d = timeit(lambda: L.p3d_fx_conv_dgrad_img(ctypes.byref(d), p(dyi), p(w), p(wb), p(dx), p(w1), w1.numel(), st_), a.iters)
+            i_w = timeit(lambda: L.p3d_fx_conv_wgrad_img(ctypes.byref(d), p(dyi), None, p(xi), p(dw), p(w2), w2.numel(), st_), a.iters)
+            i_w2 = timeit(lambda: L.p3d_fx_conv_wgrad_img(ctypes.byref(d), p(dyi), p(x), None, p(dw), p(w2), w2.numel(), st_), a.iters)
+            t_img = timeit(lambda: ops.act_image(dy), a.iters)
+            print('%-34s %8s | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f   wgrad(fp32 x) %.3f %.1f   image pass of dy %.3f ms (%.0f GB/s)'
+                  % ('  image-fed', '', i_f, gflop / i_f, i_d, gflop / i_d, i_w, gflop / i_w, i_w2, gflop / i_w2, t_img, dy.numel() * 10 / t_img / 1e6))
+            for key, v in (('fwd', i_f), ('dgrad', i_d), ('wgrad', i_w)):
+                tot_img[key] += v * cnt
         tot['fwd'] += t_f * cnt
         tot['dgrad'] += t_d * cnt
         tot['wgrad'] += t_w * cnt
         totf += gflop * cnt
     print('total per step: fwd %.2f ms  dgrad %.2f ms  wgrad %.2f ms  sum %.2f ms   (%.1f GFLOP fwd -> %.1f TF/s overall)'
           % (tot['fwd'], tot['dgrad'], tot['wgrad'], sum(tot.values()), totf, 3 * totf / sum(tot.values())))
+    if a.img:
+        print('image-fed (shapes with C %% 16 == 0): fwd %.2f ms  dgrad %.2f ms  wgrad %.2f ms' % (tot_img['fwd'], tot_img['dgrad'], tot_img['wgrad']))
 
 
 if __name__ == '__main__':
