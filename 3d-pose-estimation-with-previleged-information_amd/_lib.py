@@ -49,9 +49,18 @@ SIGNATURES = {
     'p3d_fx_act_image_bytes': (_sz, [_i32, _i32, _i32]),
     'p3d_fx_act_image': (_i32, [_i32, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i32, _i32, _ptr]),
     'p3d_fx_conv_img_workspace_bytes': (_sz, [_ptr, _i32]),
+    'p3d_fx_conv_img_supported': (_i32, [_ptr]),
     'p3d_fx_conv_fwd_img': (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_fx_conv_dgrad_img': (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_fx_conv_wgrad_img': (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    'p3d_stem_supported': (_i32, [_i32] * 5),
+    'p3d_stem_image_bytes': (_sz, [_i32] * 3),
+    'p3d_stem_weight_image_bytes': (_sz, [_i32]),
+    'p3d_stem_workspace_bytes': (_sz, [_i32] * 4),
+    'p3d_stem_image': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_stem_weight_image': (_i32, [_ptr, _i32, _i32, _ptr, _ptr, _sz, _ptr]),
+    'p3d_stem_fwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_stem_wgrad': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_profile_enable': (_i32, [_i32]),
     'p3d_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),

@@ -514,6 +514,12 @@ size_t p3d_fx_conv_img_workspace_bytes(const p3d_conv_desc* d, int32_t pass) {
     return (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
+// bit 0 / 1 / 2: the forward / data-gradient / weight-gradient pass of this convolution can run on image operands
+int32_t p3d_fx_conv_img_supported(const p3d_conv_desc* d) {
+    if (!d || !fx_enabled() || d->C % 16 != 0 || d->K % 16 != 0 || (d->H * d->W) % 4 != 0 || (d->Ho * d->Wo) % 4 != 0) return 0;
+    return (fx_fwd_applies(d, 32) ? 1 : 0) | (fx_dgrad_applies(d, 32) ? 2 : 0) | (fx_wgrad_applies(d, 32) ? 4 : 0);
+}
+
 int32_t p3d_fx_conv_fwd_img(const p3d_conv_desc* d, const void* x_img, const float* w, const void* wimg, const float* bias, float* y, void* workspace,
                             size_t workspace_bytes, void* stream) {
     P3D_REQUIRE(d && x_img && w && y, "fx_conv_fwd_img: null argument");
@@ -521,6 +527,7 @@ int32_t p3d_fx_conv_fwd_img(const p3d_conv_desc* d, const void* x_img, const flo
     FxFuse f{};
     f.act_img = x_img; f.wimg = wimg;
     ProfScope ps(0, d, (hipStream_t)stream);
+    fx_count(0, d);
     return fx_conv_fwd(d, nullptr, w, bias, y, workspace, workspace_bytes, &f, (hipStream_t)stream);
 }
 
@@ -531,6 +538,7 @@ int32_t p3d_fx_conv_dgrad_img(const p3d_conv_desc* d, const void* dy_img, const 
     FxFuse f{};
     f.act_img = dy_img; f.wimg = wimgT;
     ProfScope ps(1, d, (hipStream_t)stream);
+    fx_count(1, d);
     if (fx_dgrad_has_dead_classes(d) && !d->accumulate)
         if (hipMemsetAsync(dx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), (hipStream_t)stream) != hipSuccess) { set_error("fx_conv_dgrad_img: memset failed"); return P3D_ELAUNCH; }
     return fx_conv_dgrad(d, nullptr, w, dx, workspace, workspace_bytes, &f, (hipStream_t)stream);
@@ -547,8 +555,51 @@ int32_t p3d_fx_conv_wgrad_img(const p3d_conv_desc* d, const void* dy_img, const 
     FxFuse f{};
     f.dy_img = dy_img; f.x_img = x_img;
     ProfScope ps(2, d, (hipStream_t)stream);
+    fx_count(2, d);
     if (int32_t e = fx_conv_wgrad_slabs(d, nullptr, x, (float*)workspace, splits, &f, (hipStream_t)stream)) return e;
     return wgrad_finish(d, (float*)workspace, splits, d->R * d->S > 1, dw, (hipStream_t)stream);
+}
+
+// The stem conv1 = Conv2d(Cin <= 4, K, 7, stride 2, padding 3) (depthnet.py:138) on the x3 kernels: a 4x4 stride-1 convolution over a space-to-depth image of the
+// input (csrc/p3d_fx.hip).  The caller builds the input image once per batch (p3d_stem_image: forward and weight gradient both read it) and the weight image
+// once per optimizer step (p3d_stem_weight_image).
+static p3d_conv_desc stem_desc(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K) {
+    p3d_conv_desc d{};
+    d.N = N; d.C = Cin; d.H = H; d.W = W; d.K = K; d.R = 7; d.S = 7; d.stride = 2; d.pad = 3; d.dil = 1; d.Ho = H / 2; d.Wo = W / 2; d.c_total = Cin;
+    return d;
+}
+int32_t p3d_stem_supported(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K) { return fx_stem_applies(N, Cin, H, W, K) ? 1 : 0; }
+size_t p3d_stem_image_bytes(int32_t N, int32_t H, int32_t W) { return fx_stem_image_bytes(N, H, W); }
+size_t p3d_stem_weight_image_bytes(int32_t K) { return fx_stem_weight_image_bytes(K); }
+size_t p3d_stem_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t K) { return fx_stem_workspace(N, H, W, K); }
+
+int32_t p3d_stem_image(const float* x, void* img, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream) {
+    P3D_REQUIRE(x && img && N > 0 && Cin >= 1 && Cin <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_image: bad argument");
+    return fx_stem_image(x, img, N, Cin, H, W, (hipStream_t)stream);
+}
+
+int32_t p3d_stem_weight_image(const float* w, int32_t K, int32_t Cin, void* wimg, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(w && wimg && workspace && K > 0 && K % 16 == 0 && Cin >= 1 && Cin <= 4 && workspace_bytes >= (size_t)K * 256 * sizeof(float), "stem_weight_image: bad argument");
+    return fx_stem_weight_image(w, K, Cin, wimg, workspace, (hipStream_t)stream);
+}
+
+int32_t p3d_stem_fwd(const void* x_img, const void* wimg, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream) {
+    P3D_REQUIRE(x_img && wimg && y, "stem_fwd: null argument");
+    P3D_REQUIRE(fx_stem_applies(N, Cin, H, W, K), "stem_fwd: shape outside the restated stem (N=%d Cin=%d %dx%d K=%d)", N, Cin, H, W, K);
+    const p3d_conv_desc d = stem_desc(N, Cin, H, W, K);
+    ProfScope ps(0, &d, (hipStream_t)stream);
+    fx_count(0, &d);
+    return fx_stem_fwd(x_img, wimg, y, N, H, W, K, (hipStream_t)stream);
+}
+
+int32_t p3d_stem_wgrad(const float* dy, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(dy && x_img && dw, "stem_wgrad: null argument");
+    P3D_REQUIRE(fx_stem_applies(N, Cin, H, W, K), "stem_wgrad: shape outside the restated stem (N=%d Cin=%d %dx%d K=%d)", N, Cin, H, W, K);
+    const p3d_conv_desc d = stem_desc(N, Cin, H, W, K);
+    ProfScope ps(2, &d, (hipStream_t)stream);
+    fx_count(2, &d);
+    return fx_stem_wgrad(dy, x_img, dw, N, Cin, H, W, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- profile of the conv launches made by the executor (and by p3d_conv2d_* when enabled) ---------------------------------------------------------

@@ -104,4 +104,15 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);
 int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st);
 
+// The 7x7 stride-2 stem (Cin = 1..4) as a 4x4 stride-1 convolution over a space-to-depth image of the input (p3d_fx.hip)
+bool fx_stem_applies(int N, int Cin, int H, int W, int K);
+size_t fx_stem_image_bytes(int N, int H, int W);
+size_t fx_stem_weight_image_bytes(int K);
+size_t fx_stem_workspace(int N, int H, int W, int K);
+int32_t fx_stem_image(const float* x, void* img, int N, int Cin, int H, int W, hipStream_t st);
+int32_t fx_stem_weight_image(const float* w, int K, int Cin, void* wimg, void* workspace, hipStream_t st);
+int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H, int W, int K, hipStream_t st);
+int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace, size_t workspace_bytes,
+                      hipStream_t st);
+
 }  // namespace p3d

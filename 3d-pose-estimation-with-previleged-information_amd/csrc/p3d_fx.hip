@@ -470,14 +470,18 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // rows = the step's 16 pixels, read through ds_read_b64_tr_b16).
 // MASKED (partial convolution, fp32 operands only): dy * amask[output pixel], x * bmask[input pixel].
 // ------------------------------------------------------------------------------------------------------------------------------------------
-template <bool AIMG, bool BIMG, bool MASKED>
+// TAPS (the 7x7 stride-2 stem restated as a 4x4 stride-1 convolution over a space-to-depth image with ONE 16-channel group: fx_stem_*): the columns of the
+// GEMM are (filter tap, channel) pairs, a 128-column tile = eight taps, and what is a channel group for an ordinary image operand is a tap here: the thread's
+// chunk is the pixel's one 32-B row, fetched at the tap's offset.  grid (taps / 8, K tiles, splits); slabs [split][k][taps * 16].
+template <bool AIMG, bool BIMG, bool MASKED, bool TAPS = false>
 __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
     static_assert(!MASKED || (!AIMG && !BIMG), "the partial-convolution factors are applied by the in-kernel split");
+    static_assert(!TAPS || BIMG, "tap-major columns come from an image operand");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * FX_BM, n0 = blockIdx.x * FX_BN;
-    const int tap = blockIdx.z / p.nsplit, split = blockIdx.z - tap * p.nsplit;
+    const int tap = TAPS ? 0 : blockIdx.z / p.nsplit, split = blockIdx.z - tap * p.nsplit;
     const int tr = tap / p.S, ts = tap - tr * p.S;
     const int dh = tr * p.dil - p.pad, dw = ts * p.dil - p.pad;             // input coordinate = output coordinate * stride + (dh, dw)
     const int OHW = p.OH * p.OW, HWi = p.Hi * p.Wi;
@@ -490,9 +494,10 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const int row = t >> 2, kq = t & 3;
     const int ih = t & 1, ipix = (t >> 1) & 15, icg = t >> 5;
     const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
-    const int KG = p.K >> 4, CG = p.C >> 4;
-    const int a_cg = (m0 >> 4) + icg, b_cg = (n0 >> 4) + icg;
-    const bool ai_ok = a_cg < KG, bi_ok = b_cg < CG;
+    const int KG = p.K >> 4, CG = TAPS ? 1 : p.C >> 4;
+    const int a_cg = (m0 >> 4) + icg, b_cg = TAPS ? 0 : (n0 >> 4) + icg;
+    const bool ai_ok = a_cg < KG, bi_ok = TAPS ? true : b_cg < CG;
+    const int t_tap = (n0 >> 4) + icg, t_dh = t_tap / p.S - p.pad, t_dw = t_tap - (t_tap / p.S) * p.S - p.pad;      // TAPS: this thread's filter tap (stride 1)
     // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
     // pixel position of the K step in a wave-uniform scalar offset.  (fx_wgrad_applies bounds every tensor below 2^29 elements.)
     i32x4 rA, rB, rAi[3], rBi[3];
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     } else rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
     if constexpr (BIMG) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * p.C * HWi * 2);
+        for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * (TAPS ? 16 : p.C) * HWi * 2);
     } else rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
     const i32x4 rAM = fx_rsrc(MASKED ? p.amask : nullptr, MASKED ? (size_t)p.N * OHW * sizeof(float) : 0);
     const i32x4 rBM = fx_rsrc(MASKED ? p.bmask : nullptr, MASKED ? (size_t)p.N * HWi * sizeof(float) : 0);
@@ -536,11 +541,12 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
         // operand B (x at this block's filter tap)
         if constexpr (BIMG) {
             int b_so = f_img * CG * HWi * 32, voff;
-            if (simple) { b_so += f_p * 32; voff = bi_ok ? (b_cg * HWi + ipix) * 32 + 16 * ih : FX_OOB; }
+            if (!TAPS && simple) { b_so += f_p * 32; voff = bi_ok ? (b_cg * HWi + ipix) * 32 + 16 * ih : FX_OOB; }
             else {
                 int hi, wi;
-                if (rowwise) { hi = f_oh * p.stride + dh; wi = (f_ow + ipix) * p.stride + dw; }        // the step's 16 pixels lie in output row f_oh (a scalar)
-                else { const int q = f_p + ipix, oh = q / p.OW, ow = q - oh * p.OW; hi = oh * p.stride + dh; wi = ow * p.stride + dw; }
+                const int tdh = TAPS ? t_dh : dh, tdw = TAPS ? t_dw : dw;
+                if (rowwise) { hi = f_oh * p.stride + tdh; wi = (f_ow + ipix) * p.stride + tdw; }        // the step's 16 pixels lie in output row f_oh (a scalar)
+                else { const int q = f_p + ipix, oh = q / p.OW, ow = q - oh * p.OW; hi = oh * p.stride + tdh; wi = ow * p.stride + tdw; }
                 voff = (bi_ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) ? (b_cg * HWi + hi * p.Wi + wi) * 32 + 16 * ih : FX_OOB;
             }
 #pragma unroll
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
                 }
             }
         }
-        if (!simple && rowwise) {
+        if ((TAPS || !simple) && rowwise) {
             f_ow += FX_BK;
             if (f_ow == p.OW) { f_ow = 0; ++f_oh; if (f_oh == p.OH) f_oh = 0; }
         }
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     else if (live_a == 2 && live_b == 1) kloop(I2{}, I1{});
     else kloop(I1{}, I1{});
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
-    const int RS = p.R * p.S;
+    const int RS = TAPS ? 1 : p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1096,6 +1102,134 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     else if (aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fx_wgrad_kernel<false, false, false>), grid, dim3(256), 0, st, p);
     return check_launch("fx_conv_wgrad");
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The stem: conv1 = Conv2d(Cin, K, 7, stride 2, padding 3) with Cin = 3 (RGB) or 1 (depth) (depthnet.py:138).  Three input channels cannot feed a 16-deep
+// K step, so the convolution is restated over a space-to-depth image of the input: x'[n][c * 4 + pi * 2 + pj][i][j] = x[n][c][2 i + pi][2 j + pj]
+// (4 Cin <= 16 channels = ONE channel group, the rest zero).  Then   y[n][k][oh][ow] = sum_{r', s' in 0..3} sum_c' w'[k][c'][r'][s'] x'[n][c'][oh + r' - 2][ow + s' - 2]
+// with w'[k][c * 4 + pi * 2 + pj][r'][s'] = w[k][c][2 r' - 1 + pi][2 s' - 1 + pj] (zero where that index leaves 0..6): a 4x4 stride-1 convolution over 16
+// channels, 256 multiply-adds per output instead of 147 but on the bf16 pipe (fx_conv_kernel<AMODE 1>, 16 taps x 1 K step), and a weight gradient whose GEMM
+// columns are the 16 x 16 (tap, channel) pairs (fx_wgrad_kernel<.., TAPS>).
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// one thread per pixel of the half-resolution grid: 4 Cin input values -> three 32-B rows
+__global__ __launch_bounds__(256) void fx_s2d_image_kernel(const float* __restrict__ x, unsigned char* __restrict__ img, size_t plane_bytes, int N, int Cin, int H, int W) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)N * H2 * W2) return;
+    const int j2 = (int)(i % W2), i2 = (int)((i / W2) % H2), n = (int)(i / ((long long)W2 * H2));
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)                       // (static indices into v: a runtime-indexed register array would live in scratch)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+            if (c < Cin) {
+                const f32x2 q = *reinterpret_cast<const f32x2*>(x + (((size_t)n * Cin + c) * H + 2 * i2 + pi) * W + 2 * j2);
+                v[c * 4 + pi * 2] = q[0]; v[c * 4 + pi * 2 + 1] = q[1];
+            }
+    unsigned hp[8], mp[8], lp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fx_split2(v[2 * e], v[2 * e + 1], hp[e], mp[e], lp[e]);
+    unsigned char* dst = img + (size_t)i * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<i32x4*>(dst + 16 * h) = i32x4{(int)hp[4 * h], (int)hp[4 * h + 1], (int)hp[4 * h + 2], (int)hp[4 * h + 3]};
+        *reinterpret_cast<i32x4*>(dst + plane_bytes + 16 * h) = i32x4{(int)mp[4 * h], (int)mp[4 * h + 1], (int)mp[4 * h + 2], (int)mp[4 * h + 3]};
+        *reinterpret_cast<i32x4*>(dst + 2 * plane_bytes + 16 * h) = i32x4{(int)lp[4 * h], (int)lp[4 * h + 1], (int)lp[4 * h + 2], (int)lp[4 * h + 3]};
+    }
+}
+
+// w [K][Cin][7][7] -> w' [K][16][4][4]
+__global__ __launch_bounds__(256) void fx_stem_weights_kernel(const float* __restrict__ w, float* __restrict__ w2, int K, int Cin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * 256) return;
+    const int s2 = i & 3, r2 = (i >> 2) & 3, c2 = (i >> 4) & 15, k = i >> 8;
+    const int c = c2 >> 2, pi = (c2 >> 1) & 1, pj = c2 & 1;
+    const int r = 2 * r2 - 1 + pi, q = 2 * s2 - 1 + pj;
+    w2[i] = (c < Cin && r >= 0 && r < 7 && q >= 0 && q < 7) ? w[((size_t)(k * Cin + c) * 7 + r) * 7 + q] : 0.f;
+}
+
+// slabs [split][K][256 = tap * 16 + c'] -> dw [K][Cin][7][7] (=|+=): every weight has exactly one (tap, c') column
+__global__ __launch_bounds__(256) void fx_stem_dw_kernel(const float* __restrict__ slabs, int nsplit, float* __restrict__ dw, int K, int Cin, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * Cin * 49) return;
+    const int q = i % 7, r = (i / 7) % 7, c = (i / 49) % Cin, k = i / (49 * Cin);
+    const int r2 = (r + 1) >> 1, pi = (r + 1) & 1, s2 = (q + 1) >> 1, pj = (q + 1) & 1;
+    const int col = (r2 * 4 + s2) * 16 + c * 4 + pi * 2 + pj;
+    float acc = 0.f;
+    for (int z = 0; z < nsplit; ++z) acc += slabs[((size_t)z * K + k) * 256 + col];
+    dw[i] = accumulate ? dw[i] + acc : acc;
+}
+
+bool fx_stem_applies(int N, int Cin, int H, int W, int K) {
+    return fx_enabled() && N > 0 && (Cin == 1 || Cin == 3 || Cin == 2 || Cin == 4) && K >= 32 && K % 16 == 0 && K <= 128 && H % 2 == 0 && W % 8 == 0 && ((H / 2) * (W / 2)) % 16 == 0 &&
+           (int64_t)N * K * (H / 2) * (W / 2) < (1ll << 29);
+}
+size_t fx_stem_image_bytes(int N, int H, int W) { return (size_t)3 * N * (H / 2) * (W / 2) * 32; }
+size_t fx_stem_weight_image_bytes(int K) { return fx_weight_image_bytes(K, 16, 16, false); }
+static int fx_stem_splits(int N, int H, int W) {
+    const int64_t total = (int64_t)N * ((H / 2) * (W / 2) / FX_BK);
+    int64_t splits = 384;                      // 2 column tiles x 384 = 768 blocks: one resident round
+    if (splits > total / 32) splits = total / 32;
+    if (splits < 1) splits = 1;
+    const int64_t spb = ceil_div(total, splits);
+    return (int)ceil_div(total, spb);
+}
+size_t fx_stem_workspace(int N, int H, int W, int K) {
+    const size_t w2 = align256((size_t)K * 256 * sizeof(float));
+    const size_t slabs = (size_t)fx_stem_splits(N, H, W) * K * 256 * sizeof(float);
+    return w2 > slabs ? w2 : slabs;
+}
+
+int32_t fx_stem_image(const float* x, void* img, int N, int Cin, int H, int W, hipStream_t st) {
+    const long long total = (long long)N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(fx_s2d_image_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, x, (unsigned char*)img, (size_t)total * 32, N, Cin, H, W);
+    return check_launch("fx_stem_image");
+}
+
+// w [K][Cin][7][7] -> the forward weight image of the restated convolution (workspace: K * 256 floats)
+int32_t fx_stem_weight_image(const float* w, int K, int Cin, void* wimg, void* workspace, hipStream_t st) {
+    hipLaunchKernelGGL(fx_stem_weights_kernel, dim3((unsigned)ceil_div((int64_t)K * 256, 256)), dim3(256), 0, st, w, (float*)workspace, K, Cin);
+    return fx_build_weight_images((const float*)workspace, K, 16, 16, wimg, nullptr, st);
+}
+
+static FxConvParams fx_stem_params(int N, int H, int W, int K) {
+    FxConvParams p{};
+    const int H2 = H / 2, W2 = W / 2;
+    p.N = N; p.Cred = 16; p.Hi = H2; p.Wi = W2; p.M = K; p.OH = H2; p.OW = W2; p.NP = N * H2 * W2;
+    p.YH = H2; p.YW = W2; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
+    p.R = 4; p.S = 4; p.nR = 4; p.nS = 4; p.ntap = 16; p.r0 = 0; p.rstep = 1; p.s0 = 0; p.sstep = 1;
+    p.hmul = 1; p.hoff = -2; p.hstep = 1; p.wmul = 1; p.woff = -2; p.wstep = 1;
+    p.tiles_m = (int)ceil_div(K, FX_BM);
+    return p;
+}
+
+// y [N][K][H/2][W/2] = conv1(x) from the space-to-depth image of x and the restated weight image
+int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H, int W, int K, hipStream_t st) {
+    FxConvParams p = fx_stem_params(N, H, W, K);
+    p.Ximg = (const unsigned char*)x_img; p.plane_bytes = (size_t)N * (H / 2) * (W / 2) * 32;
+    p.Wimg = (const unsigned char*)wimg; p.Y = y;
+    const int tiles_n = (int)ceil_div(p.NP, FX_BN);
+    fx_launch_conv(p, true, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+    return check_launch("fx_stem_fwd");
+}
+
+// dw [K][Cin][7][7] (=|+=) from dy [N][K][H/2][W/2] (fp32) and the space-to-depth image of x
+int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace, size_t workspace_bytes,
+                      hipStream_t st) {
+    if (!workspace || workspace_bytes < fx_stem_workspace(N, H, W, K)) { set_error("fx_stem_wgrad: workspace %zu B < required %zu B", workspace_bytes, fx_stem_workspace(N, H, W, K)); return P3D_EWORKSPACE; }
+    FxWgradParams p{};
+    const int H2 = H / 2, W2 = W / 2;
+    p.DY = dy; p.Ximg = (const unsigned char*)x_img; p.x_plane = (size_t)N * H2 * W2 * 32; p.slabs = (float*)workspace;
+    p.N = N; p.K = K; p.C = 256; p.Hi = H2; p.Wi = W2; p.OH = H2; p.OW = W2; p.R = 4; p.S = 4; p.stride = 1; p.pad = 2; p.dil = 1;
+    p.nsplit = fx_stem_splits(N, H, W);
+    p.spb = (int)ceil_div((int64_t)N * (H2 * W2 / FX_BK), p.nsplit);
+    hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)ceil_div((int64_t)K * Cin * 49, 256)), dim3(256), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
+    return check_launch("fx_stem_wgrad");
 }
 
 }  // namespace p3d

@@ -31,6 +31,12 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, join_put=None, join_take=None):
         if x.dtype == torch.float16:                        # -half_acc: NHWC fp16 kernels (ops_half.py)
             return ops_half.conv2d(x, self, _one(self.stride), _one(self.padding), _one(self.dilation), join_put, join_take)
+        if join_put is None and join_take is None and torch.is_grad_enabled() and self.weight.requires_grad:
+            from . import ops_block
+            if not x.requires_grad and ops_block.stem_takes_x3(self, x):      # the 7x7 stride-2 stem: restated over a space-to-depth image (csrc/p3d_fx.hip)
+                return ops_block.stem_conv(self, x)
+            if ops_block.conv_takes_images(self, x):        # multi-tap convolutions outside a residual block (the regressor): operands as pre-split images
+                return ops_block.conv2d_images(self, x)
         return ops.conv2d(x, self.weight, self.bias, _one(self.stride), _one(self.padding), _one(self.dilation),
                           join_put=join_put, join_take=join_take)
 

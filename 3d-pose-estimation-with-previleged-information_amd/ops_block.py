@@ -241,3 +241,181 @@ def residual_block(block, x):
     for _, conv, bn in _layers(block):
         params += [conv.weight, bn.weight, bn.bias]
     return ResidualBlockFn.apply(x, block, *params)
+
+
+# ---- a single convolution on image operands (the 3x3 `regressor` behind layer4: depthnet.py:156,199) ------------------------------------------------------
+# Multi-tap and strided convolutions gain most from operands that are split once instead of per channel tile and filter tap (profiles/r03_summary.md:
+# ResNet-50's 2048 -> 272 3x3 regressor 3.33 -> 2.78 ms per step over its three passes, image passes included); plain 1x1 layers do not repay the extra
+# pass, so they stay on ops.conv2d.
+IMAGE_CONVS = os.environ.get('P3D_IMAGE_CONVS', '1') != '0'
+
+
+def conv_takes_images(conv, x):
+    if not (IMAGE_CONVS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv).__name__ == 'Conv2d'):
+        return False
+    k = conv.kernel_size[0]
+    if k < 2 or conv.in_channels < 64:
+        return False
+    cache = conv.__dict__.setdefault('_img_ok', {})
+    key = (tuple(x.shape), ops.X3_EPOCH)
+    ok = cache.get(key)
+    if ok is None:
+        d = ops._desc(x.shape, conv.weight.shape, _one(conv.stride), _one(conv.padding), _one(conv.dilation))
+        ok = cache[key] = lib().p3d_fx_conv_img_supported(ctypes.byref(d)) == 7
+    return ok
+
+
+class ConvImagesFn(torch.autograd.Function):
+    """conv(x, w) + bias with x, dy (and w) travelling as pre-split images: forward = image pass of x + p3d_fx_conv_fwd_img; backward = image pass of dy +
+    p3d_fx_conv_dgrad_img on the launch stream + p3d_fx_conv_wgrad_img (dy image, the x image kept from forward) on the weight-gradient stream."""
+
+    @staticmethod
+    def forward(ctx, x, conv, w, bias):
+        x = x.contiguous()
+        L = lib()
+        stride, pad, dil = _one(conv.stride), _one(conv.padding), _one(conv.dilation)
+        d = ops._desc(x.shape, w.shape, stride, pad, dil)
+        x_img = ops.act_image(x)
+        y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        wimg = weight_images(conv)[0] if USE_WEIGHT_IMAGES else None
+        ws = ops.workspace(x.device, L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 0))
+        with ops._Timed('fwd', d):
+            check(L.p3d_fx_conv_fwd_img(ctypes.byref(d), ops._p(x_img), ops._p(w), ops._p(wimg), ops._p(bias), ops._p(y), ops._p(ws), ws.numel(), ops._stream()),
+                  'p3d_fx_conv_fwd_img')
+        ctx.conv, ctx.cfg, ctx.x_shape = conv, (stride, pad, dil), tuple(x.shape)
+        ctx.save_for_backward(x_img)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_img,) = ctx.saved_tensors
+        conv = ctx.conv
+        w, bias = conv.weight, conv.bias
+        stride, pad, dil = ctx.cfg
+        L, st = lib(), ops._stream()
+        dy = dy.contiguous()
+        d = ops._desc(ctx.x_shape, w.shape, stride, pad, dil)
+        dy_img = ops.act_image(dy)
+        dy_ready = ops._mark_ready() if (ops.WGRAD_STREAM and ctx.needs_input_grad[2]) else None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy.device)
+            wimgT = weight_images(conv)[1] if USE_WEIGHT_IMAGES else None
+            ws = ops.workspace(dy.device, L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 1))
+            with ops._Timed('dgrad', d):
+                check(L.p3d_fx_conv_dgrad_img(ctypes.byref(d), ops._p(dy_img), ops._p(w), ops._p(wimgT), ops._p(dx), ops._p(ws), ws.numel(), st), 'p3d_fx_conv_dgrad_img')
+        if ctx.needs_input_grad[2]:
+            sink = ops._grad_sink(w)
+            dw = torch.empty_like(w) if sink is None else sink
+            d.accumulate = 0 if sink is None else 1
+            nbytes = L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 2)
+            if ops.WGRAD_STREAM and sink is not None:
+                side = ops._side_stream(dy.device)
+                ops._queue_join()
+                side.wait_event(dy_ready)
+                sws = ops._side_workspace(dy.device, nbytes)
+                with torch.cuda.stream(side):
+                    with ops._Timed('wgrad', d):
+                        check(L.p3d_fx_conv_wgrad_img(ctypes.byref(d), ops._p(dy_img), None, ops._p(x_img), ops._p(dw), ops._p(sws), sws.numel(), ops._stream()),
+                              'p3d_fx_conv_wgrad_img')
+                for t in (dy_img, x_img):                   # freed by autograd while the side stream may still read them
+                    t.record_stream(side)
+            else:
+                sws = ops.workspace(dy.device, nbytes)
+                with ops._Timed('wgrad', d):
+                    check(L.p3d_fx_conv_wgrad_img(ctypes.byref(d), ops._p(dy_img), None, ops._p(x_img), ops._p(dw), ops._p(sws), sws.numel(), st), 'p3d_fx_conv_wgrad_img')
+            d.accumulate = 0
+            if sink is not None:
+                dw = None
+                ops._grad_done(w)
+        if bias is not None and ctx.needs_input_grad[3]:
+            sink = ops._grad_sink(bias)
+            db = torch.empty(d.K, dtype=torch.float32, device=dy.device) if sink is None else sink
+            check(L.p3d_conv2d_bgrad(ops._p(dy), d.N, d.K, d.Ho * d.Wo, ops._p(db), 0 if sink is None else 1, st), 'p3d_conv2d_bgrad')
+            if sink is not None:
+                db = None
+                ops._grad_done(bias)
+        return dx, None, dw, db
+
+
+def conv2d_images(conv, x):
+    return ConvImagesFn.apply(x, conv, conv.weight, conv.bias)
+
+
+# ---- the stem conv1 (7x7, stride 2, Cin = 3 or 1: depthnet.py:138) on the x3 kernels -------------------------------------------------------------------------
+def stem_takes_x3(conv, x):
+    if not (IMAGE_CONVS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv).__name__ == 'Conv2d' and conv.bias is None):
+        return False
+    if (conv.kernel_size[0], _one(conv.stride), _one(conv.padding), _one(conv.dilation)) != (7, 2, 3, 1) or conv.in_channels > 4:
+        return False
+    n, c, h, w = x.shape
+    return bool(lib().p3d_stem_supported(n, c, h, w, conv.out_channels))
+
+
+def stem_weight_image(conv):
+    """The restated stem's forward weight image, rebuilt when the weight has changed (same key as weight_images)."""
+    w = conv.weight
+    key = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+    cached = conv.__dict__.get('_stem_image')
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    k, c = w.shape[0], w.shape[1]
+    img = cached[1] if cached is not None else torch.empty(lib().p3d_stem_weight_image_bytes(k), dtype=torch.uint8, device=w.device)
+    ws = ops.workspace(w.device, k * 256 * 4)
+    check(lib().p3d_stem_weight_image(ops._p(w.detach()), k, c, ops._p(img), ops._p(ws), ws.numel(), ops._stream()), 'p3d_stem_weight_image')
+    conv.__dict__['_stem_image'] = (key, img)
+    return img
+
+
+class StemConvFn(torch.autograd.Function):
+    """conv1(x): the space-to-depth image of the batch is built once in forward and read again by the weight gradient (no data gradient: x is the input)."""
+
+    @staticmethod
+    def forward(ctx, x, conv, w):
+        if x.requires_grad:
+            raise P3DError('StemConvFn: a data gradient for the network input is not implemented (the reference never asks for one)')
+        x = x.contiguous()
+        L = lib()
+        n, c, h, wd = x.shape
+        k = w.shape[0]
+        x_img = torch.empty(L.p3d_stem_image_bytes(n, h, wd), dtype=torch.uint8, device=x.device)
+        check(L.p3d_stem_image(ops._p(x), ops._p(x_img), n, c, h, wd, ops._stream()), 'p3d_stem_image')
+        y = torch.empty((n, k, h // 2, wd // 2), dtype=torch.float32, device=x.device)
+        check(L.p3d_stem_fwd(ops._p(x_img), ops._p(stem_weight_image(conv)), ops._p(y), n, c, h, wd, k, ops._stream()), 'p3d_stem_fwd')
+        ctx.conv, ctx.shape = conv, (n, c, h, wd, k)
+        ctx.save_for_backward(x_img)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_img,) = ctx.saved_tensors
+        n, c, h, wd, k = ctx.shape
+        w = ctx.conv.weight
+        L = lib()
+        dy = dy.contiguous()
+        dw = None
+        if ctx.needs_input_grad[2]:
+            sink = ops._grad_sink(w)
+            dw = torch.empty_like(w) if sink is None else sink
+            nbytes = L.p3d_stem_workspace_bytes(n, h, wd, k)
+            if ops.WGRAD_STREAM and sink is not None:
+                dy_ready = ops._mark_ready()
+                side = ops._side_stream(dy.device)
+                ops._queue_join()
+                side.wait_event(dy_ready)
+                sws = ops._side_workspace(dy.device, nbytes)
+                with torch.cuda.stream(side):
+                    check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
+                for t in (dy, x_img):
+                    t.record_stream(side)
+            else:
+                sws = ops.workspace(dy.device, nbytes)
+                check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 0 if sink is None else 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
+            if sink is not None:
+                dw = None
+                ops._grad_done(w)
+        return None, None, dw
+
+
+def stem_conv(conv, x):
+    return StemConvFn.apply(x, conv, conv.weight)

@@ -187,12 +187,26 @@ int32_t p3d_fx_act_image(int32_t mode, const float* x, const float* x2, const fl
 /* The three passes of a convolution on image operands (what p3d_block_* launches inside a block).  pass: 0 forward, 1 data gradient, 2 weight gradient.
  * wimg / wimgT: the p3d_fx_weight_images image of w for that pass, or NULL (built into the workspace).  wgrad: x (fp32) is read when x_img is NULL. */
 size_t p3d_fx_conv_img_workspace_bytes(const p3d_conv_desc* d, int32_t pass);
+int32_t p3d_fx_conv_img_supported(const p3d_conv_desc* d);      /* bit 0 / 1 / 2: forward / data gradient / weight gradient can take image operands */
 int32_t p3d_fx_conv_fwd_img(const p3d_conv_desc* d, const void* x_img, const float* w, const void* wimg, const float* bias, float* y, void* workspace,
                             size_t workspace_bytes, void* stream);
 int32_t p3d_fx_conv_dgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* w, const void* wimgT, float* dx, void* workspace, size_t workspace_bytes,
                               void* stream);
 int32_t p3d_fx_conv_wgrad_img(const p3d_conv_desc* d, const void* dy_img, const float* x, const void* x_img, float* dw, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/* The stem conv1 = Conv2d(Cin <= 4, K, 7, stride 2, padding 3) (depthnet.py:138) on the x3 kernels: restated as a 4x4 stride-1 convolution over a space-to-depth
+ * image of the input (x'[c * 4 + pi * 2 + pj][i][j] = x[c][2 i + pi][2 j + pj], one 16-channel group).  p3d_stem_image: once per batch (forward and weight
+ * gradient read it); p3d_stem_weight_image: once per weight update (workspace >= K * 256 floats).  H even, W % 8 == 0, K % 16 == 0, K <= 128. */
+int32_t p3d_stem_supported(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K);
+size_t p3d_stem_image_bytes(int32_t N, int32_t H, int32_t W);
+size_t p3d_stem_weight_image_bytes(int32_t K);
+size_t p3d_stem_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t K);
+int32_t p3d_stem_image(const float* x, void* img, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream);
+int32_t p3d_stem_weight_image(const float* w, int32_t K, int32_t Cin, void* wimg, void* workspace, size_t workspace_bytes, void* stream);
+int32_t p3d_stem_fwd(const void* x_img, const void* wimg, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream);
+int32_t p3d_stem_wgrad(const float* dy, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */

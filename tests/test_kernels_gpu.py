@@ -678,3 +678,54 @@ def test_image_fed_kernels_match_the_oracle(case, pkg):
     acc = torch.ones_like(x.detach())
     ops.conv2d_img('dgrad', x.shape, w.detach(), st, pad, dil, dy_img=dy_img, accumulate_into=acc)
     assert (acc - 1 - dx).abs().max() <= 4e-6 * dx.abs().max()
+
+
+@pytest.mark.parametrize('case', [(2, 3, 64, 64, 64), (3, 1, 48, 64, 64), (2, 3, 32, 32, 96), (5, 3, 128, 128, 64)], ids=lambda c: 'n%d_c%d_%dx%d_k%d' % c)
+def test_stem_on_the_x3_kernels(case, pkg):
+    """conv1 = Conv2d(Cin, K, 7, stride 2, padding 3) (depthnet.py:138) restated as a 4x4 stride-1 convolution over a space-to-depth image of the input
+    (p3d_stem_*): forward and weight gradient against the float64 oracle's plain 7x7 stride-2 convolution."""
+    n, cin, h, w, k = case
+    conv = pkg.nn.Conv2d(cin, k, kernel_size=7, stride=2, padding=3, bias=False).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(n + cin + h)
+    x = torch.randn(n, cin, h, w, device='cuda', generator=gen)
+    assert pkg.ops_block.stem_takes_x3(conv, x)
+    y = conv(x)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith('StemConvFn')
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    pkg.ops.join_side_stream()
+    torch.cuda.synchronize()
+    xh, wh, dyh = host(x), host(conv.weight), host(dy)
+    want_y = ref.conv2d_fwd(xh, wh, None, 2, 3, 1)
+    want_dw = ref.conv2d_wgrad(dyh, xh, conv.weight.shape, 2, 3, 1)
+    assert np.abs(host(y) - want_y).max() < 2e-5 * np.abs(want_y).max()
+    assert np.abs(host(conv.weight.grad) - want_dw).max() < 5e-5 * np.abs(want_dw).max()
+    # a second step after a weight update: the cached weight image follows ops.weights_changed()
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    y2 = conv(x)
+    assert np.abs(host(y2) - 0.5 * want_y).max() < 2e-5 * np.abs(want_y).max()
+
+
+def test_multi_tap_conv_outside_a_block_takes_image_operands(pkg):
+    """nn.Conv2d routes a 3x3 convolution that is not part of a residual block (the `regressor`, depthnet.py:156) through image operands: bias, data gradient,
+    weight gradient and bias gradient against the float64 oracle."""
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    conv = pkg.nn.Conv2d(128, 272, 3, padding=1).cuda()
+    x = torch.randn(3, 128, 16, 16, device='cuda', generator=gen).requires_grad_(True)
+    assert pkg.ops_block.conv_takes_images(conv, x)
+    y = conv(x)
+    assert type(y.grad_fn).__name__.startswith('ConvImagesFn')
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    pkg.ops.join_side_stream()
+    torch.cuda.synchronize()
+    xh, wh, bh, dyh = host(x), host(conv.weight), host(conv.bias), host(dy)
+    want = ref.conv2d_fwd(xh, wh, bh, 1, 1, 1)
+    assert np.abs(host(y) - want).max() < 2e-5 * np.abs(want).max()
+    want = ref.conv2d_dgrad(dyh, wh, x.shape, 1, 1, 1)
+    assert np.abs(host(x.grad) - want).max() < 2e-5 * np.abs(want).max()
+    want = ref.conv2d_wgrad(dyh, xh, conv.weight.shape, 1, 1, 1)
+    assert np.abs(host(conv.weight.grad) - want).max() < 5e-5 * np.abs(want).max()
+    want = dyh.astype(np.float64).sum((0, 2, 3))
+    assert np.abs(host(conv.bias.grad) - want).max() < 2e-5 * np.abs(want).max()

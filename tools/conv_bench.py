@@ -71,6 +71,17 @@ def main():
         t_d = timeit(lambda: L.p3d_conv2d_dgrad(ctypes.byref(d), p(dy), p(w), None, None, p(dx), p(wsd), wsd.numel(), st_), a.iters) if (c > 4 and a.mode in ('all', 'dgrad')) else 0.0
         t_w = timeit(lambda: L.p3d_conv2d_wgrad(ctypes.byref(d), p(dy), p(x), None, None, p(dw), p(ws), ws.numel(), st_), a.iters) if a.mode in ('all', 'wgrad') else 1e9
         print('%-34s %8.1f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f' % (tag, gflop, t_f, gflop / t_f, t_d, gflop / t_d if t_d else 0, t_w, gflop / t_w))
+        if a.img and c <= 4 and ks == 7 and L.p3d_stem_supported(a.batch, c, h, h, k):
+            ximg = torch.empty(L.p3d_stem_image_bytes(a.batch, h, h), dtype=torch.uint8, device='cuda')
+            wimg = torch.empty(L.p3d_stem_weight_image_bytes(k), dtype=torch.uint8, device='cuda')
+            wsx = torch.empty(max(L.p3d_stem_workspace_bytes(a.batch, h, h, k), k * 1024), dtype=torch.uint8, device='cuda')
+            L.p3d_stem_weight_image(p(w), k, c, p(wimg), p(wsx), wsx.numel(), st_)
+            t_i = timeit(lambda: L.p3d_stem_image(p(x), p(ximg), a.batch, c, h, h, st_), a.iters)
+            i_f = timeit(lambda: L.p3d_stem_fwd(p(ximg), p(wimg), p(y), a.batch, c, h, h, k, st_), a.iters)
+            i_w = timeit(lambda: L.p3d_stem_wgrad(p(dy), p(ximg), p(dw), a.batch, c, h, h, k, 0, p(wsx), wsx.numel(), st_), a.iters)
+            print('%-34s %8s | %8.3f %6.1f | %8s %6s | %8.3f %6.1f   space-to-depth image of x %.3f ms' % ('  restated (x3)', '', i_f, gflop / i_f, '', '', i_w, gflop / i_w, t_i))
+            tot_img['fwd'] += i_f * cnt
+            tot_img['wgrad'] += i_w * cnt
         if a.img and c % 16 == 0 and k % 16 == 0:
             fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
             L.p3d_fx_weight_image_bytes(k, c, ks * ks, ctypes.byref(fb), ctypes.byref(bb))
