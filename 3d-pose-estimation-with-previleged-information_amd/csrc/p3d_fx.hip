@@ -142,8 +142,9 @@ __device__ __forceinline__ void fx_tr_frag_off(int lane, int cb, int (&off)[2]) 
 template <int AMODE, int PRO, int EPI>
 __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     static_assert(AMODE == 0 || PRO == 0, "the partial-convolution factor is applied by the in-kernel split");
-    __shared__ __attribute__((aligned(16))) unsigned char Ps[2 * 3 * FX_PIECE];      // pixel (activation) operand, double buffered
-    __shared__ __attribute__((aligned(16))) unsigned char Cs[2 * 3 * FX_PIECE];      // channel (weight) operand
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 3 * FX_PIECE];     // both operands, double buffered; after the K loop: the result tile on its way out
+    unsigned char* const Ps = lds;                                                     // pixel (activation) operand
+    unsigned char* const Cs = lds + 2 * 3 * FX_PIECE;                                  // channel (weight) operand
     __shared__ float red[2][2][128];                                                   // EPI 1 / 2: [wave along pixels][sum kind][channel]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     // XCD-aware remap (bijective): blocks b, b+8, ... share an XCD; give each XCD a contiguous run of logical ids (pixel tile outer, channel tile inner)
@@ -330,8 +331,13 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     else kloop(std::integral_constant<int, 0>{});
 
     // ---- epilogue: lane = output channel (m), registers = pixels; acc[a][b][4 g + e] is pixel 32 a + 8 g + 4 fh + e of the wave's 64 ----
+    // Dense results (every stride-1 launch, every split-K slab) leave through LDS: in the accumulator a store instruction would put 64 separate 16-B pieces
+    // into 32 channel planes; transposed through a [64 channels][128 pixels] staging tile (two rounds, one per channel sub-tile) a wave stores two whole
+    // 512-B channel rows per instruction.  Everything per element that needs the registers' view (bias, the partial-convolution factor, the BatchNorm sums
+    // and their c2 operand) is done first, in place in the accumulator.
     const bool split = p.kchunk > 0;
     float* yout = p.Y + (split ? (size_t)blockIdx.y * p.slab_stride : 0);
+    const bool dense = split || (p.oxs == 1 && p.oys == 1 && p.oy0 == 0 && p.ox0 == 0 && p.YW == p.OW && p.YH == p.OH);
     float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
     float esc[2] = {0.f, 0.f}, esh[2] = {0.f, 0.f}, emean[2] = {0.f, 0.f};
     if constexpr (EPI == 2) {
@@ -356,25 +362,32 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 if (!split) {
                     if (p.bias) { const float bb = p.bias[m]; v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb; }
                 }
-                if (split || p.oxs == 1) {
-                    const size_t o = split ? ((size_t)n * p.M + m) * OHW + rem
-                                           : (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow;
-                    f32x4* dst = reinterpret_cast<f32x4*>(yout + o);
+                if (dense) {
                     if constexpr (EPI == 4) {           // partial convolution: the result times the per-pixel factor (before it joins an existing gradient)
-                        const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow);
+                        const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + oh) * p.YW + ow);
                         v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
                     }
-                    if (!split && p.accumulate) { const f32x4 o4 = *dst; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
-                    *dst = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[a][b][4 * g + e] = v[e];
                 } else {
                     float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
-                    if constexpr (EPI == 4) {
-                        const float* em = p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+                    if (p.oxs == 1) {
+                        if constexpr (EPI == 4) {
+                            const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow);
+                            v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
+                        }
+                        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+                        if (p.accumulate) { const f32x4 o4 = *d4; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                        *d4 = v;
+                    } else {
+                        if constexpr (EPI == 4) {
+                            const float* em = p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= em[e * p.oxs];
+                            for (int e = 0; e < 4; ++e) v[e] *= em[e * p.oxs];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[e * p.oxs] = p.accumulate ? dst[e * p.oxs] + v[e] : v[e];
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[e * p.oxs] = p.accumulate ? dst[e * p.oxs] + v[e] : v[e];
                 }
                 if constexpr (EPI == 1) {
                     if (!split) {
@@ -394,6 +407,34 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 }
             }
         }
+    if (dense) {
+        // (every wave left the K loop through its last barrier: the operand buffers are free)
+        constexpr int EROW = 512 + 16;               // bytes per staged channel row: 128 pixels + one 16-B pad (staging stores of 8 consecutive rows hit 32 different banks)
+        const bool accum = !split && p.accumulate;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b == 1) __syncthreads();             // round 0's rows have been read
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(lds + (wm * 32 + fr) * EROW + (wn * 64 + a * 32 + 8 * g + 4 * fh) * 4) =
+                        f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = t + 256 * i, row = id >> 5, q = id & 31;
+                const int m = m0 + (row >> 5) * 64 + b * 32 + (row & 31);
+                const int c4 = n0 + 4 * q;
+                if (m >= p.M || c4 >= p.NP) continue;
+                const int n = c4 / OHW, rem = c4 - n * OHW;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * EROW + q * 16);
+                f32x4* dst = reinterpret_cast<f32x4*>(yout + ((size_t)n * p.M + m) * OHW + rem);
+                if (accum) { const f32x4 o4 = *dst; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                *dst = v;
+            }
+        }
+    }
     if constexpr (EPI == 1 || EPI == 2) {
         if (!split) {
             // the two half-waves hold different pixels of the same channels; then the two waves along the pixel axis
