@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void weight_tapmajor_kernel(const float* __res
 // MALL / HBM.  Such weights are re-laid tap-major into the call's workspace first (one streaming pass, ~2x|w| bytes); forward and
 // dgrad then read them with unit stride (forward: 64-B runs along c, dgrad: 256-B runs along c).
 static size_t weight_image_bytes(const p3d_conv_desc* d) {
-    static const double min_mb = [] { const char* e = getenv("P3D_WT_MIN_MB"); return e ? atof(e) : 2.0; }();
+    constexpr double min_mb = 2.0;
     const size_t bytes = (size_t)d->K * d->C * d->R * d->S * sizeof(float);
     if (d->R * d->S == 1 || d->C < 16 || d->c_total != d->C || d->c_offset != 0 || (double)bytes < min_mb * 1048576.0) return 0;
     return (bytes + 255) & ~(size_t)255;
@@ -1381,7 +1381,6 @@ int32_t p3d_conv2d_wgrad(const p3d_conv_desc* d, const float* dy, const float* x
         wv = 1;
         if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && al16(x) && al16(mask_in)) wv = 2;
     }
-    { static const int fwv = [] { const char* e = getenv("P3D_FORCE_WV"); return e ? atoi(e) : -1; }(); if (fwv >= 0 && fwv < wv) wv = fwv; }   // tuning aid
     if (fx) {
         FxFuse f{};
         f.pmask = mult; f.emask = mask_in;

@@ -832,11 +832,6 @@ void fx_stats(unsigned long long* counts, double* flops, int reset) {
     if (reset) for (int i = 0; i < 6; ++i) { g_fx_count[i] = 0; g_fx_flops[i] = 0.0; }
 }
 
-static int fx_min_m(int asked) {      // tuning aid: P3D_FX_MIN_M lowers the channel-tile fill the per-layer entry points ask for (default 96 of 128 rows)
-    static const int forced = [] { const char* e = getenv("P3D_FX_MIN_M"); return e ? atoi(e) : 0; }();
-    return forced > 0 && forced < asked ? forced : asked;
-}
-
 static bool fx_common(const p3d_conv_desc* d) {
     return fx_enabled() && d->c_offset == 0 && d->c_total == d->C && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
            (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31) &&
@@ -844,17 +839,17 @@ static bool fx_common(const p3d_conv_desc* d) {
 }
 // forward: reduction channels C in steps of 16, four consecutive output pixels in one row, a reasonably filled channel tile
 bool fx_fwd_applies(const p3d_conv_desc* d, int min_m) {
-    return fx_common(d) && d->C % FX_BK == 0 && d->C >= 32 && d->Wo % 4 == 0 && d->W % 4 == 0 && d->K >= fx_min_m(min_m);
+    return fx_common(d) && d->C % FX_BK == 0 && d->C >= 32 && d->Wo % 4 == 0 && d->W % 4 == 0 && d->K >= min_m;
 }
 // dgrad: reduction channels K in steps of 16; the GEMM columns are the pixels of one stride^2 parity class of the input
 bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m) {
-    if (!(fx_common(d) && d->K % FX_BK == 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= fx_min_m(min_m) && d->Wo % 4 == 0)) return false;
+    if (!(fx_common(d) && d->K % FX_BK == 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= min_m && d->Wo % 4 == 0)) return false;
     if (d->stride == 1) return d->W % 4 == 0;
     return d->H % 2 == 0 && d->W % 8 == 0 && d->pad == d->dil * (d->R - 1) / 2 && (d->R == 1 || d->dil == 1);      // stride 2: classes of equal size
 }
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
     if ((int64_t)d->N * d->C * d->H * d->W >= (1ll << 29) || (int64_t)d->N * d->K * d->Ho * d->Wo >= (1ll << 29)) return false;      // 32-bit byte offsets into whole tensors
-    return fx_common(d) && d->K >= fx_min_m(min_m) && d->C >= fx_min_m(min_m) && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
+    return fx_common(d) && d->K >= min_m && d->C >= min_m && (d->Ho * d->Wo) % FX_BK == 0 && d->Wo % 4 == 0 && d->W % 4 == 0 && (d->R == 1 || d->C % 64 == 0);
 }
 
 // tuning aid (p3d_fx_tune): forced split counts, 0 = the built-in plan
@@ -1103,10 +1098,8 @@ bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 &&
 int fx_wgrad_splits(const p3d_conv_desc* d) {
     const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
-    static const int env_target = [] { const char* e = getenv("P3D_FX_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();      // tuning aid
     int64_t target;
-    if (g_wgrad_target > 0) target = g_wgrad_target;
-    else if (env_target > 0) target = env_target;
+    if (g_wgrad_target > 0) target = g_wgrad_target;          // (tuning aid: p3d_fx_tune, tools/split_sweep.py)
     else if (tiles >= 256) target = 3072;
     else if ((tiles & (tiles - 1)) == 0) target = (tiles <= 8 || tiles >= 128) ? 768 : 512;
     else if (d->stride > 1) target = tiles < 16 ? 768 : 512;
@@ -1193,16 +1186,20 @@ __global__ __launch_bounds__(256) void fx_stem_weights_kernel(const float* __res
     w2[i] = (c < Cin && r >= 0 && r < 7 && q >= 0 && q < 7) ? w[((size_t)(k * Cin + c) * 7 + r) * 7 + q] : 0.f;
 }
 
-// slabs [split][K][256 = tap * 16 + c'] -> dw [K][Cin][7][7] (=|+=): every weight has exactly one (tap, c') column
+// slabs [split][K][256 = tap * 16 + c'] -> dw [K][Cin][7][7] (=|+=).  One thread per (k, column): consecutive threads sum consecutive columns over the splits
+// (coalesced), then the columns that are a weight (c < Cin, the tap inside the 7x7 window) are scattered to it.
 __global__ __launch_bounds__(256) void fx_stem_dw_kernel(const float* __restrict__ slabs, int nsplit, float* __restrict__ dw, int K, int Cin, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K * Cin * 49) return;
-    const int q = i % 7, r = (i / 7) % 7, c = (i / 49) % Cin, k = i / (49 * Cin);
-    const int r2 = (r + 1) >> 1, pi = (r + 1) & 1, s2 = (q + 1) >> 1, pj = (q + 1) & 1;
-    const int col = (r2 * 4 + s2) * 16 + c * 4 + pi * 2 + pj;
+    if (i >= K * 256) return;
     float acc = 0.f;
-    for (int z = 0; z < nsplit; ++z) acc += slabs[((size_t)z * K + k) * 256 + col];
-    dw[i] = accumulate ? dw[i] + acc : acc;
+    for (int z = 0; z < nsplit; ++z) acc += slabs[(size_t)z * K * 256 + i];
+    const int k = i >> 8, col = i & 255, tp = col >> 4, c2 = col & 15;
+    const int c = c2 >> 2, pi = (c2 >> 1) & 1, pj = c2 & 1;
+    const int r = 2 * (tp >> 2) - 1 + pi, q = 2 * (tp & 3) - 1 + pj;
+    if (c < Cin && r >= 0 && r < 7 && q >= 0 && q < 7) {
+        float* d = dw + ((size_t)(k * Cin + c) * 7 + r) * 7 + q;
+        *d = accumulate ? *d + acc : acc;
+    }
 }
 
 bool fx_stem_applies(int N, int Cin, int H, int W, int K) {
@@ -1269,7 +1266,7 @@ int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int 
     p.nsplit = fx_stem_splits(N, H, W);
     p.spb = (int)ceil_div((int64_t)N * (H2 * W2 / FX_BK), p.nsplit);
     hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)ceil_div((int64_t)K * Cin * 49, 256)), dim3(256), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
+    hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K), dim3(256), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
     return check_launch("fx_stem_wgrad");
 }
 

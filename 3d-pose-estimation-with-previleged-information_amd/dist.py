@@ -127,7 +127,7 @@ class GradReducer:
             self._seen[idx] = True
             b = self._bucket_of[idx]
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not os.environ.get('P3D_REDUCE_AT_END'):      # debugging aid: defer every bucket to finish()
+            if self._pending[b] == 0:
                 self._launch(b)
         return hook
 
@@ -146,9 +146,6 @@ class GradReducer:
                 side.wait_stream(torch.cuda.current_stream(bucket.device))
             else:
                 ops.join_side_stream(bucket.device)
-        if os.environ.get('P3D_REDUCE_BLOCKING'):                     # debugging aid
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
-            return
         if side is not None:
             with torch.cuda.stream(side):
                 self._handles.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

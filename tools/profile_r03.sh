@@ -13,4 +13,4 @@ if [ "$1" = "all" ]; then
     P3D_WGRAD_STREAM=0 P3D_BLOCK_SIDE=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --lean > gpurun_out/pmc_$c.log 2>&1 || exit 1
   done
 fi
-python3 tools/kernel_table.py gpurun_out/prof_serial 7 > gpurun_out/r3_serial_table.txt; cat gpurun_out/r3_serial_table.txt
+python3 tools/kernel_table.py gpurun_out/prof_serial 7 > gpurun_out/r3_serial_table.txt; cat gpurun_out/r3_serial_table.txt; [ "$1" = "all" ] && python3 tools/summarize_r03.py
