@@ -1090,20 +1090,26 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
 // input pixels of a strided 1x1 that no tap reaches: fx_conv_dgrad leaves them untouched, so a caller that does not accumulate zero-fills dx first
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 && d->R == 1; }
 
-// How many slabs (splits of the pixel reduction) a weight gradient is cut into.  Measured on MI355X over the ResNet layer classes at batch 64
-// (tools/split_sweep.py, profiles/r02_summary.md): one resident round of blocks -- two or three per CU, 512 to 768 in all -- beats the 1024+ blocks
-// the first plan asked for by 5-25 % per layer; grids that are an exact multiple of the 256 CUs do best, so tile counts that divide 256 aim at
-// 512 (mid-sized) or 768 blocks, the 3x3 grids (9, 36, 144 tiles) at 576, and a grid that cannot fit one round (the 272-channel regressor: a third of
-// its blocks are nearly empty) goes the other way, to many short blocks that balance themselves.
+// How many slabs (splits of the pixel reduction) a weight gradient is cut into.  Measured on MI355X over the ResNet layer classes at batch 64 with
+// image operands (tools/split_sweep.py, profiles/r03_split_sweep.txt): the best block count depends on the tile count more than on anything else -- all
+// blocks are resident at once (two or three per CU), so what matters is how evenly tiles x slabs covers the 256 CUs and whether the taps of one slab land on
+// one XCD.  The round-2 plan (576 blocks for the 3x3 grids, 512 / 768 for powers of two, 3072 for the regressor) left 15-22 % on the 9-, 16-, 36- and
+// 144-tile classes and 3 % on the regressor; other tile counts aim at one full round of three blocks per CU.
 int fx_wgrad_splits(const p3d_conv_desc* d) {
     const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
     int64_t target;
     if (g_wgrad_target > 0) target = g_wgrad_target;          // (tuning aid: p3d_fx_tune, tools/split_sweep.py)
-    else if (tiles >= 256) target = 3072;
-    else if ((tiles & (tiles - 1)) == 0) target = (tiles <= 8 || tiles >= 128) ? 768 : 512;
-    else if (d->stride > 1) target = tiles < 16 ? 768 : 512;
-    else target = 576;
+    else if (tiles >= 256) target = 1536;
+    else switch ((int)tiles) {
+        case 4: target = 384; break;
+        case 8: case 36: target = 512; break;
+        case 9: target = d->stride > 1 ? 576 : (d->C <= 64 ? 720 : 768); break;
+        case 16: target = 896; break;
+        case 32: target = d->stride > 1 ? 720 : 512; break;
+        case 144: target = 720; break;
+        default: target = 768;
+    }
     int64_t splits = (2 * target + tiles) / (2 * tiles);                 // nearest
     if (splits > total / 32) splits = total / 32;                        // at least 32 K steps per block
     if (g_force_wgrad_splits > 0) splits = g_force_wgrad_splits < total ? g_force_wgrad_splits : total;

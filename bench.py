@@ -197,9 +197,14 @@ def main():
     sync()
     # (no event brackets inside the timed region: the per-launch durations of `roofline` come from the kernel pass below)
     ops.conv_path_stats(reset=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(opt.steps + 1)] if opt.lean else None      # (lean runs only: per-step spread as a diagnostic)
     t0 = time.perf_counter()
     for i in range(opt.steps):
+        if marks:
+            marks[i].record()
         loss = trainer.train_step(*batches[i % nbuf])
+    if marks:
+        marks[opt.steps].record()
     sync()
     elapsed = time.perf_counter() - t0
     paths = ops.conv_path_stats(reset=True)
@@ -213,7 +218,10 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU', 'value': round(opt.batch * world * opt.steps / elapsed, 2), 'unit': 'crops/s',
                               'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True,
-                              'dist_backend': dist_backend, 'dist_world_size': dist_world}), flush=True)
+                              'dist_backend': dist_backend, 'dist_world_size': dist_world,
+                              'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank))),
+                              'step_ms_min_med_max': [round(v, 2) for v in (lambda d: (d[0], d[len(d) // 2], d[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps)))]}),
+                  flush=True)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
