@@ -117,13 +117,54 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const void* __res
     t[4] = A; t[5] = -A * is * m2; t[6] = A * (mean * is * m2 - m1); t[7] = 0.f;
 }
 
+// What bn_finalize_fwd_kernel does for ONE channel, by a whole 256-thread block (the closing pass: one channel per block): thread t sums partial rows t, t + 256, ...
+// in fp64, then the block combines them in a fixed order, so that every block of a channel arrives at the same constants.
+struct CloseFin {
+    const float* partial;   // [rows][C][2] = (sum y, sum y^2), or null: no BatchNorm on this operand (identity shortcut)
+    int rows;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float momentum, eps;
+    float* table;
+};
+__device__ __forceinline__ void close_finalize(const CloseFin& f, int ch, int C, double count, bool owner, double* red /*[12]*/, float& sc, float& sh) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = threadIdx.x; r < f.rows; r += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(f.partial + ((size_t)r * C + ch) * 2);
+        s1 += v.x; s2 += v.y;
+    }
+    blk_sum3(s1, s2, s3, red);
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float fmean = (float)mean;
+    sc = invstd * f.gamma[ch];
+    sh = __fmaf_rn(-fmean, sc, f.beta[ch]);
+    if (owner && threadIdx.x == 0) {
+        float* t = f.table + (size_t)ch * FX_TAB;
+        t[0] = sc; t[1] = sh; t[2] = fmean; t[3] = invstd;
+        if (f.running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            f.running_mean[ch] = (float)((1.0 - f.momentum) * f.running_mean[ch] + f.momentum * mean);
+            f.running_var[ch] = (float)((1.0 - f.momentum) * f.running_var[ch] + f.momentum * unbiased);
+        }
+    }
+}
+
 // Closes the block in forward: out = act(c * sc + sh + shortcut), shortcut = res (identity) or rc * rsc + rsh (the downsample conv's raw output and its BN).
-// grid (C, split): block (c, s) owns images n = s, s + split, ...
-__global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __restrict__ c, const float* __restrict__ tab, const float* __restrict__ res,
-                                                              const float* __restrict__ rtab, float* __restrict__ out, int N, int C, int HW, int relu) {
+// The batch statistics of the closing BatchNorm (and of the downsample BatchNorm) are finalized here, from the partial sums their convolutions' epilogues left.
+// grid (C, split): block (c, s) owns images n = s, s + split, ...; block (c, 0) writes the channel's table entry and running statistics.
+__global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __restrict__ c, const CloseFin fin, const float* __restrict__ res, const CloseFin rfin,
+                                                              float* __restrict__ out, int N, int C, int HW, int relu, double count) {
     const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
-    const float sc = tab[ch * FX_TAB], sh = tab[ch * FX_TAB + 1];
-    const float rsc = rtab ? rtab[ch * FX_TAB] : 1.f, rsh = rtab ? rtab[ch * FX_TAB + 1] : 0.f;
+    __shared__ double red[12];
+    float sc, sh, rsc = 1.f, rsh = 0.f;
+    close_finalize(fin, ch, C, count, s == 0, red, sc, sh);
+    const bool ds = rfin.partial != nullptr;
+    if (ds) close_finalize(rfin, ch, C, count, s == 0, red, rsc, rsh);
     for (int n = s; n < N; n += split) {
         const size_t off = ((size_t)n * C + ch) * HW;
         const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
@@ -134,7 +175,7 @@ __global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __res
             const f32x4 r = rv[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = fmaf(q[e], sc, sh) + (rtab ? fmaf(r[e], rsc, rsh) : r[e]);
+                float v = fmaf(q[e], sc, sh) + (ds ? fmaf(r[e], rsc, rsh) : r[e]);
                 q[e] = relu ? fmaxf(v, 0.f) : v;
             }
             ov[i] = q;
@@ -295,7 +336,7 @@ int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, s
         const size_t slabs = (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
         if (slabs > sw) sw = slabs;
     }
-    if (main_bytes) *main_bytes = align256(mw) + align256(part);
+    if (main_bytes) *main_bytes = align256(mw) + 2 * align256(part);          // (two partial-sum regions: the closing conv's and the downsample conv's live side by side)
     if (side_bytes) *side_bytes = align256(sw);
     return P3D_OK;
 }
@@ -316,6 +357,14 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     }
     conv_ws = align256(conv_ws);
     float* partial = (float*)((char*)workspace + conv_ws);
+    size_t part_bytes = 0;
+    {
+        size_t need_main = 0;
+        p3d_block_workspace_bytes(b, &need_main, nullptr);
+        part_bytes = (need_main - conv_ws) / 2;
+    }
+    float* partial2 = (float*)((char*)partial + part_bytes);          // the downsample conv's partial sums
+    const int last = b->nconv - 1;
     for (int i = 0; i < 4; ++i) {
         const bool ds = i == 3;
         if (i >= b->nconv && !(ds && b->has_downsample)) continue;
@@ -325,27 +374,38 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         if (!from_x) P3D_REQUIRE(io->aimg[i - 1], "block_fwd: null activation image %d", i - 1);
         FxFuse f{};
         f.act_img = from_x ? nullptr : io->aimg[i - 1];
-        f.partial = partial;
+        f.partial = ds ? partial2 : partial;
         f.wimg = io->wimg[i];
         {
             ProfScope ps(0, d, st);
             fx_count(0, d);
             if (int32_t e = fx_conv_fwd(d, from_x ? io->x : nullptr, io->w[i], nullptr, io->c[i], workspace, conv_ws, &f, st)) return e;
         }
-        hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(fin_threads(fx_partial_rows_fwd(d))), 0, st, (const float*)partial, fx_partial_rows_fwd(d), d->K,
-                           (double)d->N * d->Ho * d->Wo, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
-        if (!ds && i < b->nconv - 1) {
-            // a_i = relu(bn_i(c_i)), written once, as the image the next convolution (and, in backward, its weight gradient) copies into LDS
-            P3D_REQUIRE(io->aimg[i], "block_fwd: null activation image %d", i);
+        if (ds || i == last) continue;               // the closing pass finalizes these two BatchNorm layers itself
+        // a_i = relu(bn_i(c_i)), written once, as the image the next convolution (and, in backward, its weight gradient) copies into LDS.  With few partial rows
+        // (the 32 x 32 and 16 x 16 stages, split-K launches) the statistics are finalized in that pass's prologue; otherwise by a launch of its own.
+        P3D_REQUIRE(io->aimg[i], "block_fwd: null activation image %d", i);
+        const int rows = fx_partial_rows_fwd(d);
+        const double cnt = (double)d->N * d->Ho * d->Wo;
+        if (rows <= FX_FIN_MAX_ROWS) {
+            FxFinalize fin{};
+            fin.kind = 1; fin.partial = partial; fin.rows = rows; fin.count = cnt; fin.gamma = io->gamma[i]; fin.beta = io->beta[i];
+            fin.running_mean = io->running_mean[i]; fin.running_var = io->running_var[i]; fin.momentum = b->momentum[i]; fin.eps = b->eps[i]; fin.table = io->table[i];
+            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st, &fin)) return e;
+        } else {
+            hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(fin_threads(rows)), 0, st, (const float*)partial, rows, d->K, cnt, io->gamma[i],
+                               io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
             if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st)) return e;
         }
     }
-    const int last = b->nconv - 1;
     const p3d_conv_desc* dl = &b->conv[last];
     const int HW = dl->Ho * dl->Wo;
-    hipLaunchKernelGGL(block_close_fwd_kernel, dim3(dl->K, close_split(dl->N, dl->K)), dim3(256), 0, st, (const float*)io->c[last], (const float*)io->table[last],
-                       b->has_downsample ? (const float*)io->c[3] : io->x, b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->out, dl->N, dl->K, HW,
-                       b->relu_out);
+    CloseFin cf{partial, fx_partial_rows_fwd(dl), io->gamma[last], io->beta[last], io->running_mean[last], io->running_var[last], b->momentum[last], b->eps[last], io->table[last]};
+    CloseFin rf{};
+    if (b->has_downsample)
+        rf = CloseFin{partial2, fx_partial_rows_fwd(&b->conv[3]), io->gamma[3], io->beta[3], io->running_mean[3], io->running_var[3], b->momentum[3], b->eps[3], io->table[3]};
+    hipLaunchKernelGGL(block_close_fwd_kernel, dim3(dl->K, close_split(dl->N, dl->K)), dim3(256), 0, st, (const float*)io->c[last], cf,
+                       b->has_downsample ? (const float*)io->c[3] : io->x, rf, io->out, dl->N, dl->K, HW, b->relu_out, (double)dl->N * HW);
     return check_launch("block_fwd");
 }
 
@@ -384,22 +444,25 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                        (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
                        b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->gbuf, (double*)partial, dl->N, dl->K, dl->Ho * dl->Wo, b->relu_out);
     const double cnt_last = (double)dl->N * dl->Ho * dl->Wo;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(fin_threads(split)), 0, st, (const void*)partial, split, dl->K, cnt_last, 0, io->gamma[last],
-                       io->dgamma[last], io->dbeta[last], acc, io->table[last]);
-    if (b->has_downsample)
-        hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(fin_threads(split)), 0, st, (const void*)partial, split, dl->K, cnt_last, 1, io->gamma[3],
-                           io->dgamma[3], io->dbeta[3], acc, io->table[3]);
     if (int32_t e = check_launch("block_bwd open")) return e;
 
-    // 2. the main chain, last conv first.  The gradient that enters conv i is the upstream gradient taken through BN i's backward map (masked by its
-    //    ReLU, except the closing BN whose ReLU went into g already): d c_i = A g + B c_i + K, written ONCE, as the image both the weight gradient and the
-    //    data gradient of conv i copy into LDS.  What leaves the data gradient is the gradient w.r.t. the previous ReLU's output (fp32, the next g).
+    // 2. The gradient that enters conv i is the upstream gradient taken through BN i's backward map (masked by its ReLU, except the closing BN whose ReLU went
+    //    into g already): d c_i = A g + B c_i + K, written ONCE, as the image both the weight gradient and the data gradient of conv i copy into LDS.  The
+    //    constants come from channel sums (the opening pass's for the closing and the downsample BatchNorm, the downstream data gradient's epilogue for the
+    //    others), finalized in the image pass's own prologue when the partial rows are few, by a launch of their own otherwise.
     //    Streams: a weight gradient runs on the second stream behind an event of the launch stream; it reads dcimg[i] and aimg[i - 1] / x, none of which the
     //    launch stream writes again inside this call, so the launch stream never waits for the second one here.
-    const float* gi = g;
-    auto bwd_map = [&](const float* gin, int slot, int masked) -> int32_t {
+    auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt) -> int32_t {
         const p3d_conv_desc* dc = &b->conv[slot];
         P3D_REQUIRE(io->dcimg[slot], "block_bwd: null gradient image %d", slot);
+        if (kind == 3 || rows <= FX_FIN_MAX_ROWS) {
+            FxFinalize fin{};
+            fin.kind = kind; fin.partial = partial; fin.rows = rows; fin.which = which; fin.count = cnt; fin.gamma = io->gamma[slot];
+            fin.dgamma = io->dgamma[slot]; fin.dbeta = io->dbeta[slot]; fin.accumulate = acc; fin.table = io->table[slot];
+            return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, &fin);
+        }
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dc->K, FIN_CH)), dim3(fin_threads(rows)), 0, st, (const void*)partial, rows, dc->K, cnt, 0,
+                           io->gamma[slot], io->dgamma[slot], io->dbeta[slot], acc, io->table[slot]);
         return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st);
     };
     auto launch_wgrad = [&](int slot, const float* xin, const void* ximg, bool tapm) -> int32_t {
@@ -415,9 +478,12 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         dw_desc.accumulate = acc;
         return wgrad_finish(&dw_desc, (float*)side_workspace, splits, tapm, io->dw[slot], ss);
     };
+    // the two maps fed by the opening pass's sums (its partial buffer is overwritten by the first data gradient below): closing BatchNorm, downsample BatchNorm
+    if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last)) return e;
+    if (b->has_downsample)
+        if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last)) return e;
     for (int i = last; i >= 0; --i) {
         const p3d_conv_desc* d = &b->conv[i];
-        if (int32_t e = bwd_map(gi, i, i != last)) return e;
         // weight gradient: x operand = the previous ReLU's output (an image written by forward), or the block input (fp32)
         if (i > 0) P3D_REQUIRE(io->aimg[i - 1], "block_bwd: null activation image %d", i - 1);
         if (int32_t e = launch_wgrad(i, i > 0 ? nullptr : io->x, i > 0 ? io->aimg[i - 1] : nullptr, d->R * d->S > 1)) return e;
@@ -439,16 +505,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             }
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
             if (epi) {
-                hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(fin_threads(fx_partial_rows_dgrad(d))), 0, st, (const void*)partial, fx_partial_rows_dgrad(d), dp->K,
-                                   cnt, 0, io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
+                if (int32_t e = bwd_map(io->da[i - 1], i - 1, 1, 2, fx_partial_rows_dgrad(d), 0, cnt)) return e;
             } else {
                 const int sp = close_split(dp->N, dp->K);
                 hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dp->K, sp), dim3(256), 0, st, (const float*)io->da[i - 1], (const float*)io->c[i - 1],
                                    (const float*)io->table[i - 1], (double*)partial, dp->N, dp->K, dp->Ho * dp->Wo);
-                hipLaunchKernelGGL(bn_finalize_bwd_kernel<true>, dim3((unsigned)ceil_div(dp->K, FIN_CH)), dim3(fin_threads(sp)), 0, st, (const void*)partial, sp, dp->K, cnt, 0,
-                                   io->gamma[i - 1], io->dgamma[i - 1], io->dbeta[i - 1], acc, io->table[i - 1]);
+                if (int32_t e = bwd_map(io->da[i - 1], i - 1, 1, 3, sp, 0, cnt)) return e;
             }
-            gi = io->da[i - 1];
         } else if (b->need_dx) {
             // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
             // the downsample conv's dgrad adds to it below.  No weight-gradient kernel reads g (they read the images), so the launch stream does not wait.
@@ -463,10 +526,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
         }
     }
-    // 3. downsample branch: its BN's backward map applied to g, weight gradient, data gradient added onto dx
+    // 3. downsample branch: weight gradient, data gradient added onto dx (its gradient image was written with the closing BatchNorm's)
     if (b->has_downsample) {
         const p3d_conv_desc* d = &b->conv[3];
-        if (int32_t e = bwd_map(g, 3, 0)) return e;
         if (int32_t e = launch_wgrad(3, io->x, nullptr, false)) return e;
         if (b->need_dx) {
             FxFuse f{};
@@ -600,6 +662,13 @@ int32_t p3d_stem_wgrad(const float* dy, const void* x_img, float* dw, int32_t N,
     ProfScope ps(2, &d, (hipStream_t)stream);
     fx_count(2, &d);
     return fx_stem_wgrad(dy, x_img, dw, N, Cin, H, W, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// All weight images of a network in one launch.  jobs: device array of njobs records {const float* w; void* img_fwd; void* img_bwd; int32 K, C, RS, pad} (40 bytes each;
+// a NULL image pointer skips that direction); blocks: grid width per job and direction (each block strides over the job's 16-B chunk positions).
+int32_t p3d_fx_weight_images_batched(const void* jobs, int32_t njobs, int32_t blocks, void* stream) {
+    P3D_REQUIRE(jobs && njobs > 0 && blocks > 0, "weight_images_batched: bad argument");
+    return fx_build_weight_images_batched(jobs, njobs, blocks, (hipStream_t)stream);
 }
 
 // ---- profile of the conv launches made by the executor (and by p3d_conv2d_* when enabled) ---------------------------------------------------------

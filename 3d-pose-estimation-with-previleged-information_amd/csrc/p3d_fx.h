@@ -97,12 +97,34 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
 int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm, float* dw, hipStream_t st);
 size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd);
 int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st);
+int32_t fx_build_weight_images_batched(const void* jobs, int njobs, int blocks, hipStream_t st);      // jobs: device array of {w, fwd, bwd, K, C, RS, pad} (40 B each)
 int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, const FxFuse* fuse, hipStream_t st);
 // Pre-split activation images: a fp32 NCHW tensor [N][C][HW] (C % 16 == 0, HW % 4 == 0) as three bf16 planes [N][C/16][HW][16] (hi + mid + lo == value exactly):
 // what the x3 kernels stage into LDS with plain 16-B copies.  mode 0: the tensor itself; 1: relu(x * sc + sh) with the table's constants per channel;
 // 2: A * (masked ? g * [c * sc + sh > 0] : g) + B * c + K (x = g, x2 = c): the BatchNorm-backward map.
+// `fin` (optional): the finalize step of the BatchNorm layer the pass belongs to, done in the pass's prologue instead of a launch of its own -- every block sums the
+// per-channel partial sums of its 16 channels (fp64, fixed order: all blocks get the same constants), block x == 0 also writes what a finalize kernel would
+// (table / running statistics, or d gamma / d beta).  For few partial rows only (each block re-reads rows * 16 channels); the caller decides.
+struct FxFinalize {
+    int kind;               // 1: MODE 1, batch statistics from fp32 partials [rows][C][2] = (sum y, sum y^2);  2: MODE 2, backward sums from fp32 partials [rows][C][2] =
+                            // (sum g, sum g (c - mean));  3: MODE 2, the same from fp64 partials [C][rows][3] (second sum at index 1 + which)
+    const void* partial;
+    int rows, which;
+    double count;           // N * H * W
+    const float* gamma;
+    const float* beta;      // kind 1
+    float* running_mean;    // kind 1, may be null
+    float* running_var;
+    float momentum, eps;    // kind 1
+    float* dgamma;          // kind 2 / 3
+    float* dbeta;
+    int accumulate;         // kind 2 / 3: add to d gamma / d beta instead of overwriting
+    float* table;           // the layer's [C][8] table: kind 1 writes {sc, sh, mean, invstd}; kind 2 / 3 read them
+};
+constexpr int FX_FIN_MAX_ROWS = 512;
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);
-int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st);
+int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
+                     const FxFinalize* fin = nullptr);
 
 // The 7x7 stride-2 stem (Cin = 1..4) as a 4x4 stride-1 convolution over a space-to-depth image of the input (p3d_fx.hip)
 bool fx_stem_applies(int N, int Cin, int H, int W, int K);

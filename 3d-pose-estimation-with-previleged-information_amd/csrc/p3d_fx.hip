@@ -746,11 +746,62 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 // ------------------------------------------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ tab,
-                                                           unsigned char* __restrict__ img, size_t plane_bytes, int N, int C, int HW, int masked) {
+                                                           unsigned char* __restrict__ img, size_t plane_bytes, int N, int C, int HW, int masked, const FxFinalize fin) {
     __shared__ float cst[16][FX_TAB];
+    __shared__ double fred[2][16][16];
     const int cg = blockIdx.y, t = threadIdx.x;
     if constexpr (MODE != 0) {
-        if (t < 16 * FX_TAB) cst[t >> 3][t & 7] = tab[(size_t)(cg * 16) * FX_TAB + t];
+        if (fin.kind == 0) {
+            if (t < 16 * FX_TAB) cst[t >> 3][t & 7] = tab[(size_t)(cg * 16) * FX_TAB + t];
+        } else {
+            // fused finalize: thread (cl, rl) sums rows rl, rl + 16, ... of channel cl in fp64, lane 0 of each channel adds the 16 lanes in order
+            const int cl = t & 15, rl = t >> 4, c = cg * 16 + cl;
+            double s1 = 0.0, s2 = 0.0;
+            if (fin.kind == 3) {
+                const double* pd = (const double*)fin.partial;
+                for (int r = rl; r < fin.rows; r += 16) { s1 += pd[((size_t)c * fin.rows + r) * 3]; s2 += pd[((size_t)c * fin.rows + r) * 3 + 1 + fin.which]; }
+            } else {
+                const float* pf = (const float*)fin.partial;
+                for (int r = rl; r < fin.rows; r += 16) { const f32x2 v = *reinterpret_cast<const f32x2*>(pf + ((size_t)r * C + c) * 2); s1 += v[0]; s2 += v[1]; }
+            }
+            fred[0][rl][cl] = s1; fred[1][rl][cl] = s2;
+            __syncthreads();
+            if (rl == 0) {
+                s1 = s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += fred[0][i][cl]; s2 += fred[1][i][cl]; }
+                const bool owner = blockIdx.x == 0;
+                if constexpr (MODE == 1) {          // as bn_finalize_fwd_kernel (p3d_block.hip)
+                    const double mean = s1 / fin.count;
+                    double var = s2 / fin.count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+                    const float fmean = (float)mean;
+                    const float sc = invstd * fin.gamma[c], sh = __fmaf_rn(-fmean, sc, fin.beta[c]);
+                    cst[cl][0] = sc; cst[cl][1] = sh;
+                    if (owner) {
+                        float* tt = fin.table + (size_t)c * FX_TAB;
+                        tt[0] = sc; tt[1] = sh; tt[2] = fmean; tt[3] = invstd;
+                        if (fin.running_mean) {
+                            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                            fin.running_mean[c] = (float)((1.0 - fin.momentum) * fin.running_mean[c] + fin.momentum * mean);
+                            fin.running_var[c] = (float)((1.0 - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased);
+                        }
+                    }
+                } else {                             // as bn_finalize_bwd_kernel
+                    const float* tt = fin.table + (size_t)c * FX_TAB;
+                    const float sc = tt[0], sh = tt[1], mean = tt[2], is = tt[3];
+                    const double dg = (double)is * s2;
+                    if (owner) {
+                        fin.dbeta[c] = fin.accumulate ? fin.dbeta[c] + (float)s1 : (float)s1;
+                        fin.dgamma[c] = fin.accumulate ? fin.dgamma[c] + (float)dg : (float)dg;
+                    }
+                    const float m1 = (float)(s1 / fin.count), m2 = (float)(dg / fin.count);
+                    const float A = fin.gamma[c] * is;
+                    cst[cl][0] = sc; cst[cl][1] = sh; cst[cl][4] = A; cst[cl][5] = -A * is * m2; cst[cl][6] = A * (mean * is * m2 - m1);
+                }
+            }
+        }
         __syncthreads();
     }
     const int ih = t & 1;
@@ -798,15 +849,23 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
 
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW) { return (size_t)(3 * N * C * HW * 2); }
 
-int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st) {
-    if (!x || !img || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3) || (mode != 0 && !table) || (mode == 2 && !x2) || mode < 0 || mode > 2) {
+int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
+                     const FxFinalize* fin) {
+    if (!x || !img || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3) || (mode != 0 && !table && !fin) || (mode == 2 && !x2) || mode < 0 || mode > 2) {
         set_error("fx_act_image: bad argument (N=%d C=%d HW=%d mode=%d; C %% 16 == 0 and HW %% 4 == 0 are required)", N, C, HW, mode); return P3D_EINVAL;
+    }
+    FxFinalize f{};
+    if (fin) {
+        f = *fin;
+        if (!((f.kind == 1 && mode == 1 && f.beta) || ((f.kind == 2 || f.kind == 3) && mode == 2 && f.dgamma && f.dbeta)) || !f.partial || f.rows <= 0 || !f.gamma || !f.table) {
+            set_error("fx_act_image: inconsistent fused-finalize request (kind %d, mode %d)", f.kind, mode); return P3D_EINVAL;
+        }
     }
     const size_t plane = (size_t)N * C * HW * 2;
     const dim3 grid((unsigned)ceil_div((int64_t)N * (HW >> 2) * 2, 256), (unsigned)(C >> 4));
-    if (mode == 0) hipLaunchKernelGGL(fx_act_image_kernel<0>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
-    else if (mode == 1) hipLaunchKernelGGL(fx_act_image_kernel<1>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
-    else hipLaunchKernelGGL(fx_act_image_kernel<2>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked);
+    if (mode == 0) hipLaunchKernelGGL(fx_act_image_kernel<0>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
+    else if (mode == 1) hipLaunchKernelGGL(fx_act_image_kernel<1>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
+    else hipLaunchKernelGGL(fx_act_image_kernel<2>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
     return check_launch("fx_act_image");
 }
 
@@ -914,15 +973,11 @@ int fx_partial_rows_dgrad(const p3d_conv_desc* d) {
 // 1 the data-gradient image (rows = input channels, reduction = output channels); a null image pointer skips that direction.  One thread per 16-B chunk
 // position (tap, row tile, K step, row, half): eight fp32 weights -> three bf16 pieces (here the truncating split: piece = the top 16 bits of what is left;
 // exact like the rounding one), written where fx_conv_kernel's linear 12 KB copy wants them.
-__global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __restrict__ w, unsigned char* __restrict__ img_fwd, unsigned char* __restrict__ img_bwd, int K,
-                                                               int C, int RS) {
-    const bool bwd = blockIdx.y == 1;
-    unsigned char* img = bwd ? img_bwd : img_fwd;
-    if (!img) return;
+__device__ __forceinline__ void fx_weight_image_chunks(const float* __restrict__ w, unsigned char* __restrict__ img, int K, int C, int RS, bool bwd, size_t first, size_t step) {
     const int rows = bwd ? C : K, red = bwd ? K : C;
     const int tiles = (rows + 127) / 128, ksteps = red / FX_BK;
     const size_t total = (size_t)RS * tiles * ksteps * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    for (size_t i = first; i < total; i += step) {
         const int half = (int)(i & 1), row = (int)((i >> 1) & 127);
         size_t j = i >> 8;
         const int ks = (int)(j % ksteps); j /= ksteps;
@@ -945,6 +1000,26 @@ __global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __re
         *reinterpret_cast<i32x4*>(dst + FX_PIECE) = i32x4{(int)((mid[0] >> 16) | mid[1]), (int)((mid[2] >> 16) | mid[3]), (int)((mid[4] >> 16) | mid[5]), (int)((mid[6] >> 16) | mid[7])};
         *reinterpret_cast<i32x4*>(dst + 2 * FX_PIECE) = i32x4{(int)((lo[0] >> 16) | lo[1]), (int)((lo[2] >> 16) | lo[3]), (int)((lo[4] >> 16) | lo[5]), (int)((lo[6] >> 16) | lo[7])};
     }
+}
+__global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __restrict__ w, unsigned char* __restrict__ img_fwd, unsigned char* __restrict__ img_bwd, int K,
+                                                               int C, int RS) {
+    const bool bwd = blockIdx.y == 1;
+    unsigned char* img = bwd ? img_bwd : img_fwd;
+    if (img) fx_weight_image_chunks(w, img, K, C, RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+// every convolution of a network in ONE launch (54 launches of a few microseconds each sat on the forward critical path of ResNet-50): grid (blocks, 2 * jobs)
+struct FxImageJob { const float* w; unsigned char* fwd; unsigned char* bwd; int K, C, RS, pad; };
+__global__ __launch_bounds__(256) void fx_weight_images_batched_kernel(const FxImageJob* __restrict__ jobs) {
+    const FxImageJob j = jobs[blockIdx.y >> 1];
+    const bool bwd = blockIdx.y & 1;
+    unsigned char* img = bwd ? j.bwd : j.fwd;
+    if (img) fx_weight_image_chunks(j.w, img, j.K, j.C, j.RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+int32_t fx_build_weight_images_batched(const void* jobs, int njobs, int blocks, hipStream_t st) {
+    static_assert(sizeof(FxImageJob) == 40, "job table layout (ops_block.py builds it)");
+    if (njobs <= 0) return P3D_OK;
+    hipLaunchKernelGGL(fx_weight_images_batched_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks), (unsigned)(2 * njobs)), dim3(256), 0, st, (const FxImageJob*)jobs);
+    return check_launch("fx_build_weight_images_batched");
 }
 
 int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st) {

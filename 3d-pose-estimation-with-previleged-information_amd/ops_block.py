@@ -80,25 +80,77 @@ class _Plan:
         self.table_rows = sum(ks)
 
 
+# Every convolution that has asked for weight images is registered here; when one of them finds its images stale (the optimizer stepped), ALL stale ones are
+# rebuilt by ONE launch (p3d_fx_weight_images_batched): 54 launches of a few microseconds each otherwise sit on the forward critical path of ResNet-50.
+_image_convs = []            # weak references, in order of first use
+_image_members = None        # WeakSet of the same modules (a deep copy of a registered module carries `_fx_images` along but is not a member)
+_image_tables = {}           # (conv ids) -> device job table
+
+
+def _image_key(w):
+    return (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+
+
+def _rebuild_stale_images(device):
+    import weakref
+    import numpy as np
+    live = []
+    for ref in _image_convs:
+        conv = ref()
+        if conv is not None and '_fx_images' in conv.__dict__:
+            live.append(conv)
+    _image_convs[:] = [weakref.ref(c) for c in live]
+    stale = [c for c in live if c.weight.device == device and c.__dict__['_fx_images'][0] != _image_key(c.weight)]
+    if not stale:
+        return
+    # the job table: its bytes are also the cache key (Python ids and device addresses are both re-used after a module dies, so only the full record identifies a job)
+    rows = np.zeros(len(stale), dtype=[('w', '<u8'), ('f', '<u8'), ('b', '<u8'), ('K', '<i4'), ('C', '<i4'), ('RS', '<i4'), ('pad', '<i4')])
+    most = 0
+    for i, c in enumerate(stale):
+        k, cc, r, s_ = c.weight.shape
+        _, fwd, bwd = c.__dict__['_fx_images']
+        rows[i] = (c.weight.data_ptr(), fwd.data_ptr(), bwd.data_ptr(), k, cc, r * s_, 0)
+        most = max(most, fwd.numel(), bwd.numel())
+    assert rows.dtype.itemsize == 40
+    ident = rows.tobytes()
+    entry = _image_tables.get(ident)
+    if entry is None:
+        table = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).to(device)
+        blocks = max(1, min(256, (most // 48 + 255) // 256))          # 16-B chunk positions of the largest image / 256 threads, capped: blocks stride
+        if len(_image_tables) > 16:
+            _image_tables.clear()
+        entry = _image_tables[ident] = (table, blocks)
+    table, blocks = entry
+    check(lib().p3d_fx_weight_images_batched(ops._p(table), len(stale), blocks, ops._stream()), 'p3d_fx_weight_images_batched')
+    for c in stale:
+        _, fwd, bwd = c.__dict__['_fx_images']
+        c.__dict__['_fx_images'] = (_image_key(c.weight), fwd, bwd)
+
+
 def weight_images(conv):
-    """(forward image, data-gradient image) of conv.weight as device byte tensors (p3d_fx_weight_images), rebuilt when the weight has changed:
-    in-place edits through torch bump weight._version; the optimizer kernels write through raw pointers, so FlatAdam bumps ops.WEIGHT_EPOCH."""
+    """(forward image, data-gradient image) of conv.weight as device byte tensors (p3d_fx_weight_images*), rebuilt when the weight has changed:
+    in-place edits through torch bump weight._version; writes behind torch's back (the optimizer kernels, broadcasts into the flat buffer) bump ops.WEIGHT_EPOCH."""
+    import weakref
     w = conv.weight
-    key = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
     cached = conv.__dict__.get('_fx_images')
-    if cached is not None and cached[0] == key:
+    if cached is not None and cached[0] == _image_key(w):
         return cached[1], cached[2]
-    k, c, r, s_ = w.shape
-    if cached is None:
+    global _image_members
+    if _image_members is None:
+        _image_members = weakref.WeakSet()
+    if cached is None or conv not in _image_members or cached[1].device != w.device:
+        k, c, r, s_ = w.shape
         fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
         check(lib().p3d_fx_weight_image_bytes(k, c, r * s_, ctypes.byref(fb), ctypes.byref(bb)), 'p3d_fx_weight_image_bytes')
         fwd = torch.empty(fb.value, dtype=torch.uint8, device=w.device)
         bwd = torch.empty(bb.value, dtype=torch.uint8, device=w.device)
-    else:
-        fwd, bwd = cached[1], cached[2]
-    check(lib().p3d_fx_weight_images(ops._p(w.detach()), k, c, r * s_, ops._p(fwd), ops._p(bwd), ops._stream()), 'p3d_fx_weight_images')
-    conv.__dict__['_fx_images'] = (key, fwd, bwd)
-    return fwd, bwd
+        conv.__dict__['_fx_images'] = (None, fwd, bwd)
+        if conv not in _image_members:
+            _image_members.add(conv)
+            _image_convs.append(weakref.ref(conv))
+    _rebuild_stale_images(w.device)
+    cached = conv.__dict__['_fx_images']
+    return cached[1], cached[2]
 
 
 USE_WEIGHT_IMAGES = os.environ.get('P3D_WEIGHT_IMAGES', '1') != '0'

@@ -177,6 +177,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
  * each (filter tap, 128-channel tile, 16-deep K step) of the conv kernels consumes, so the weight operand costs the kernels no arithmetic.  w [K][C][R*S]. */
 int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_bytes, size_t* bwd_bytes);
 int32_t p3d_fx_weight_images(const float* w, int32_t K, int32_t C, int32_t RS, void* img_fwd, void* img_bwd, void* stream);
+/* the same for many weights in ONE launch: jobs = device array of njobs records {const float* w; void* img_fwd; void* img_bwd; int32_t K, C, RS, pad;} (40 bytes each,
+ * NULL image = skip that direction), blocks = grid width per job and direction */
+int32_t p3d_fx_weight_images_batched(const void* jobs, int32_t njobs, int32_t blocks, void* stream);
 
 /* Pre-split activation images: a fp32 NCHW tensor [N][C][HW] (C % 16 == 0, HW % 4 == 0) as three bf16 planes [N][C/16][HW][16] with hi + mid + lo == the fp32
  * value exactly -- the form in which the x3 convolution kernels take an operand without splitting it (16-B copies into LDS whatever the filter tap).
