@@ -47,6 +47,9 @@ SIGNATURES = {
     'p3d_fx_weight_image_bytes': (_i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     'p3d_fx_weight_images': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     'p3d_fx_weight_images_batched': (_i32, [_ptr, _i32, _i32, _ptr]),
+    'p3d_hblock_workspace_bytes': (_i32, [_ptr, _ptr, _ptr]),
+    'p3d_hblock_fwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr]),
+    'p3d_hblock_bwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr, _sz, _ptr, _ptr]),
     'p3d_fx_act_image_bytes': (_sz, [_i32, _i32, _i32]),
     'p3d_fx_act_image': (_i32, [_i32, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i32, _i32, _ptr]),
     'p3d_fx_conv_img_workspace_bytes': (_sz, [_ptr, _i32]),

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 import os
 
-from . import ops, ops_block
+from . import ops, ops_block, ops_half
 from .nn import BatchNorm2d, Conv2d, MaxPool2d, Sequential
 from .partial_conv import PartialConv
 
@@ -73,6 +73,8 @@ class _ResidualBlock(nn.Module):
             return self._forward_inference(x)
         if FUSED_BLOCKS and ops_block.usable(self, x):          # training: the whole block is one C call per direction, BatchNorm inside the convolutions
             return ops_block.residual_block(self, x)
+        if FUSED_BLOCKS and x.dtype == torch.float16 and ops_half.block_usable(self, x):      # -half_acc: one C call per block and direction over the fp16 kernels
+            return ops_half.residual_block(self, x)
         join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1

@@ -276,6 +276,11 @@ static bool order_after(hipStream_t waiter, hipStream_t signaller) {
     hipEvent_t e = next_event();
     return e && hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess;
 }
+// the same in two halves: mark the signaller's position now, make the waiter wait for it later (after more work has been queued on the signaller)
+static hipEvent_t mark_position(hipStream_t signaller) {
+    hipEvent_t e = next_event();
+    return (e && hipEventRecord(e, signaller) == hipSuccess) ? e : nullptr;
+}
 
 // ---- conv launch profile (bench.py's roofline brackets): HIP events around every conv call of the executor, on the stream it runs on ----------
 struct ProfRec { int kind; double flops; hipEvent_t a, b; };
@@ -465,9 +470,11 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                            io->gamma[slot], io->dgamma[slot], io->dbeta[slot], acc, io->table[slot]);
         return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st);
     };
-    auto launch_wgrad = [&](int slot, const float* xin, const void* ximg, bool tapm) -> int32_t {
+    // `ready`: the launch stream's position when the gradient image of this convolution was complete (the data gradient of the same layer has been queued on
+    // the launch stream since: it is the critical path and gets to the GPU first; the weight gradient only feeds the optimizer)
+    auto launch_wgrad = [&](int slot, const float* xin, const void* ximg, bool tapm, hipEvent_t ready) -> int32_t {
         const p3d_conv_desc* d = &b->conv[slot];
-        if (two && !order_after(ss, st)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
+        if (two && (!ready || hipStreamWaitEvent(ss, ready, 0) != hipSuccess)) { set_error("block_bwd: event failure"); return P3D_ELAUNCH; }
         ProfScope ps(2, d, ss);
         fx_count(2, d);
         FxFuse fw{};
@@ -482,12 +489,12 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last)) return e;
     if (b->has_downsample)
         if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last)) return e;
+    hipEvent_t ready = two ? mark_position(st) : nullptr;           // d c_last (and the downsample branch's gradient image) are complete
+    const hipEvent_t ready_ds = ready;
     for (int i = last; i >= 0; --i) {
         const p3d_conv_desc* d = &b->conv[i];
-        // weight gradient: x operand = the previous ReLU's output (an image written by forward), or the block input (fp32)
         if (i > 0) P3D_REQUIRE(io->aimg[i - 1], "block_bwd: null activation image %d", i - 1);
-        if (int32_t e = launch_wgrad(i, i > 0 ? nullptr : io->x, i > 0 ? io->aimg[i - 1] : nullptr, d->R * d->S > 1)) return e;
-        // data gradient
+        // data gradient first (the chain the next layer waits for), then the weight gradient of the same layer on the second stream
         FxFuse f{};
         f.wimg = io->wimgT[i];
         f.act_img = io->dcimg[i];
@@ -503,6 +510,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                 fx_count(1, d);
                 if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[i], io->da[i - 1], workspace, conv_ws, &f, st)) return e;
             }
+            if (int32_t e = launch_wgrad(i, nullptr, io->aimg[i - 1], d->R * d->S > 1, ready)) return e;
             const double cnt = (double)dp->N * dp->Ho * dp->Wo;
             if (epi) {
                 if (int32_t e = bwd_map(io->da[i - 1], i - 1, 1, 2, fx_partial_rows_dgrad(d), 0, cnt)) return e;
@@ -512,7 +520,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                                    (const float*)io->table[i - 1], (double*)partial, dp->N, dp->K, dp->Ho * dp->Wo);
                 if (int32_t e = bwd_map(io->da[i - 1], i - 1, 1, 3, sp, 0, cnt)) return e;
             }
-        } else if (b->need_dx) {
+            ready = two ? mark_position(st) : nullptr;                      // d c_{i-1} is complete
+        } else {
+            if (b->need_dx) {
             // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
             // the downsample conv's dgrad adds to it below.  No weight-gradient kernel reads g (they read the images), so the launch stream does not wait.
             float* dx;
@@ -524,12 +534,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             ProfScope ps(1, d, st);
             fx_count(1, d);
             if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
+            }
+            if (int32_t e = launch_wgrad(0, io->x, nullptr, d->R * d->S > 1, ready)) return e;
         }
     }
-    // 3. downsample branch: weight gradient, data gradient added onto dx (its gradient image was written with the closing BatchNorm's)
+    // 3. downsample branch: data gradient added onto dx, weight gradient (its gradient image was written with the closing BatchNorm's)
     if (b->has_downsample) {
         const p3d_conv_desc* d = &b->conv[3];
-        if (int32_t e = launch_wgrad(3, io->x, nullptr, false)) return e;
         if (b->need_dx) {
             FxFuse f{};
             f.wimg = io->wimgT[3];
@@ -540,8 +551,112 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             fx_count(1, d);
             if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
         }
+        if (int32_t e = launch_wgrad(3, io->x, nullptr, false, ready_ds)) return e;
     }
     return check_launch("block_bwd");
+}
+
+// ---- the same block on the fp16 NHWC kernels (-half_acc): host-side fusion of the per-layer entry points into one call per block and direction -------------------
+static bool hblock_slot(const p3d_block_desc* b, int i) { return i < b->nconv || (i == 3 && b->has_downsample); }
+
+int32_t p3d_hblock_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes) {
+    P3D_REQUIRE(b && (b->nconv == 2 || b->nconv == 3), "hblock: nconv must be 2 or 3");
+    size_t mw = 0, sw = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!hblock_slot(b, i)) continue;
+        const size_t a = p3d_hbn_workspace_bytes(b->conv[i].K), w = p3d_hconv2d_wgrad_workspace_bytes(&b->conv[i]);
+        if (a > mw) mw = a;
+        if (w > sw) sw = w;
+    }
+    if (main_bytes) *main_bytes = align256(mw);
+    if (side_bytes) *side_bytes = align256(sw);
+    return P3D_OK;
+}
+
+int32_t p3d_hblock_fwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(b && io && io->x && io->out && (b->nconv == 2 || b->nconv == 3), "hblock_fwd: bad argument");
+    const int last = b->nconv - 1;
+    for (int i = 0; i < 4; ++i)
+        if (hblock_slot(b, i)) P3D_REQUIRE(io->w_krsc[i] && io->c[i] && io->coef[i] && io->gamma[i] && io->beta[i] && (i == last || io->a[i]), "hblock_fwd: null tensor of conv %d", i);
+    hipStream_t st = (hipStream_t)stream;
+    auto conv = [&](int i, const void* in) -> int32_t {
+        const p3d_conv_desc* d = &b->conv[i];
+        ProfScope ps(0, d, st);
+        return p3d_hconv2d_fwd(d, in, io->w_krsc[i], nullptr, nullptr, nullptr, io->c[i], stream);
+    };
+    auto bn = [&](int i, const void* res, void* y, int relu) -> int32_t {
+        const p3d_conv_desc* d = &b->conv[i];
+        return p3d_hbn_train_fwd(io->c[i], res, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], y, io->coef[i], d->N * d->Ho * d->Wo, d->K,
+                                 b->momentum[i], b->eps[i], relu, workspace, workspace_bytes, stream);
+    };
+    if (b->has_downsample) {
+        if (int32_t e = conv(3, io->x)) return e;
+        if (int32_t e = bn(3, nullptr, io->a[3], 0)) return e;
+    }
+    const void* in = io->x;
+    for (int i = 0; i <= last; ++i) {
+        if (int32_t e = conv(i, in)) return e;
+        if (i < last) { if (int32_t e = bn(i, nullptr, io->a[i], 1)) return e; in = io->a[i]; }
+        else if (int32_t e = bn(i, b->has_downsample ? (const void*)io->a[3] : io->x, io->out, b->relu_out)) return e;
+    }
+    return P3D_OK;
+}
+
+int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
+                       void* stream, void* side_stream) {
+    P3D_REQUIRE(b && io && io->x && io->out && io->dout && (b->nconv == 2 || b->nconv == 3), "hblock_bwd: bad argument");
+    P3D_REQUIRE(b->relu_out, "hblock_bwd: blocks without the closing ReLU stay on the per-layer path");
+    const int last = b->nconv - 1;
+    for (int i = 0; i < 4; ++i)
+        if (hblock_slot(b, i)) P3D_REQUIRE(io->c[i] && io->coef[i] && io->dc[i] && io->dw[i] && io->dgamma[i] && io->dbeta[i] && (i == 0 || i == 3 || io->w_crsk[i]) && (i == last || i == 3 || io->da[i]),
+                                           "hblock_bwd: null tensor of conv %d", i);
+    P3D_REQUIRE(io->da[3] && (!b->need_dx || !b->has_downsample || (io->dx && io->w_crsk[0] && io->w_crsk[3])) && (!b->need_dx || b->has_downsample || io->w_crsk[0]), "hblock_bwd: null gradient buffer");
+    hipStream_t st = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : st;
+    const bool two = ss != st;
+    const int acc = b->accumulate_grads;
+    auto bn_bwd = [&](int i, const void* dy, const void* y, void* dres, int relu) -> int32_t {
+        const p3d_conv_desc* d = &b->conv[i];
+        return p3d_hbn_train_bwd(dy, io->c[i], y, io->coef[i], io->dc[i], dres, io->dgamma[i], io->dbeta[i], d->N * d->Ho * d->Wo, d->K, relu, acc, workspace, workspace_bytes, stream);
+    };
+    auto wgrad = [&](int i, const void* xin, hipEvent_t ready) -> int32_t {        // `ready`: the launch stream's position when dc[i] was complete
+        p3d_conv_desc d = b->conv[i];
+        d.accumulate = acc;
+        if (two && (!ready || hipStreamWaitEvent(ss, ready, 0) != hipSuccess)) { set_error("hblock_bwd: event failure"); return P3D_ELAUNCH; }
+        ProfScope ps(2, &d, ss);
+        return p3d_hconv2d_wgrad(&d, io->dc[i], xin, nullptr, io->dw[i], io->c_real[i], 1.0f, two ? side_workspace : side_workspace, side_bytes, (void*)ss);
+    };
+    auto dgrad = [&](int i, void* dx, int accumulate) -> int32_t {
+        p3d_conv_desc d = b->conv[i];
+        d.accumulate = accumulate;
+        ProfScope ps(1, &d, st);
+        return p3d_hconv2d_dgrad(&d, io->dc[i], io->w_crsk[i], nullptr, dx, stream);
+    };
+    // closing BatchNorm: d c_last, and the gradient that enters the shortcut (dout masked by the block's output)
+    if (int32_t e = bn_bwd(last, io->dout, io->out, io->da[3], 1)) return e;
+    hipEvent_t ready = two ? mark_position(st) : nullptr;
+    // the downsample branch first (the order autograd runs the per-layer nodes in: dx = branch's data gradient, then the first conv's added onto it);
+    // per layer the data gradient is queued before the weight gradient: it is the chain the next layer waits for
+    if (b->has_downsample) {
+        if (int32_t e = bn_bwd(3, io->da[3], nullptr, nullptr, 0)) return e;
+        const hipEvent_t ready_ds = two ? mark_position(st) : nullptr;
+        if (b->need_dx)
+            if (int32_t e = dgrad(3, io->dx, 0)) return e;
+        if (int32_t e = wgrad(3, io->x, ready_ds)) return e;
+    }
+    for (int i = last; i >= 0; --i) {
+        if (i > 0) {
+            if (int32_t e = dgrad(i, io->da[i - 1], 0)) return e;
+            if (int32_t e = wgrad(i, io->a[i - 1], ready)) return e;
+            if (int32_t e = bn_bwd(i - 1, io->da[i - 1], nullptr, nullptr, 1)) return e;
+            ready = two ? mark_position(st) : nullptr;
+        } else {
+            // the first conv's data gradient joins what the shortcut already delivered: the branch's data gradient (dx), or with an identity shortcut da[3] itself
+            if (b->need_dx)
+                if (int32_t e = dgrad(0, b->has_downsample ? io->dx : io->da[3], 1)) return e;
+            if (int32_t e = wgrad(0, io->x, ready)) return e;
+        }
+    }
+    return P3D_OK;
 }
 
 // Pre-split weight images (csrc/p3d_fx.hip): three bf16 pieces of every weight, laid out as the conv kernels' LDS tiles, one image for the forward pass

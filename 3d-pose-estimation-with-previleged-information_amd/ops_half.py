@@ -387,3 +387,178 @@ class HReluFn(torch.autograd.Function):
 
 def relu(x):
     return HReluFn.apply(x)
+
+
+# ---- one autograd node per residual block on the fp16 kernels (p3d_hblock_fwd / p3d_hblock_bwd) -----------------------------------------------------------------------
+# The fp16 step is bound by the host: ~330 Python-level calls per direction for ResNet-50, 15 ms of enqueue work for 16.7 ms of step.  The block executor makes
+# one C call per block and direction over the same per-layer entry points (depthnet.py:40-56,96-116 under model.half(), depth_train.py:73-83).
+import os as _os
+
+HALF_BLOCKS = _os.environ.get('P3D_HALF_BLOCKS', '1') != '0'
+_vp = ctypes.c_void_p
+
+
+class HBlockIO(ctypes.Structure):
+    """struct p3d_hblock_io"""
+    _fields_ = [('x', _vp), ('out', _vp), ('w_krsc', _vp * 4), ('w_crsk', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('coef', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
+                ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('dc', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4), ('dgamma', _vp * 4),
+                ('dbeta', _vp * 4), ('c_real', ctypes.c_int32 * 4)]
+
+
+class _HPlan:
+    def __init__(self, block, x_shape):
+        from . import ops_block
+        d = ops_block.BlockDesc()
+        d.nconv = len(block._chain)
+        d.has_downsample = int(block.downsample is not None)
+        d.relu_out = 1
+        shape = tuple(x_shape)
+        self.shapes = {}
+        self.layers = ops_block._layers(block)
+        for slot, conv, bn in self.layers:
+            src = tuple(x_shape) if slot in (0, 3) else shape
+            k, _, r, s_ = conv.weight.shape
+            cd = _desc(src, (k, src[1], r, s_), ops_block._one(conv.stride), ops_block._one(conv.padding), ops_block._one(conv.dilation))
+            d.conv[slot] = cd
+            d.eps[slot] = bn.eps
+            d.momentum[slot] = 0.1 if bn.momentum is None else bn.momentum
+            self.shapes[slot] = (cd.N, cd.K, cd.Ho, cd.Wo)
+            if slot != 3:
+                shape = self.shapes[slot]
+        self.desc = d
+        self.out_shape = shape
+        self.ok = block.downsample is None or self.shapes[3] == shape
+        m, sd = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().p3d_hblock_workspace_bytes(ctypes.byref(d), ctypes.byref(m), ctypes.byref(sd)), 'p3d_hblock_workspace_bytes')
+        self.main_bytes, self.side_bytes = m.value, sd.value
+
+
+def block_usable(block, x):
+    """The fp16 block executor takes this call: dense block on fp16 NHWC tensors, every BatchNorm computing batch statistics, closing ReLU, weight images present."""
+    if not HALF_BLOCKS or block.partial or block.skip_relu or x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4:
+        return False
+    from . import ops_block
+    for _, conv, bn in ops_block._layers(block):
+        img = getattr(conv, '_h_images', None)
+        if (not bn.training or not (bn.affine and bn.track_running_stats) or conv.bias is not None or type(conv).__name__ != 'Conv2d' or img is None or img.crsk is None
+                or pad8(conv.out_channels) != conv.out_channels):
+            return False
+    cache = block.__dict__.setdefault('_hblk_plans', {})
+    plan = cache.get(tuple(x.shape))
+    if plan is None:
+        plan = cache[tuple(x.shape)] = _HPlan(block, x.shape)
+    return plan.ok and x.shape[1] == ops_block._layers(block)[0][1]._h_images.cpad
+
+
+class HResidualBlockFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, block, *params):
+        x = _cl(x)
+        plan = block.__dict__['_hblk_plans'][tuple(x.shape)]
+        dev = x.device
+        io = HBlockIO()
+        io.x = x.data_ptr()
+        out = _empty(*plan.out_shape, dev)
+        io.out = out.data_ptr()
+        cs, acts, coefs = {}, {}, {}
+        last = plan.desc.nconv - 1
+        for slot, conv, bn in plan.layers:
+            n, k, ho, wo = plan.shapes[slot]
+            cs[slot] = _empty(n, k, ho, wo, dev)
+            coefs[slot] = torch.empty((k, 4), dtype=torch.float32, device=dev)
+            io.c[slot], io.coef[slot] = cs[slot].data_ptr(), coefs[slot].data_ptr()
+            if slot != last:
+                acts[slot] = _empty(n, k, ho, wo, dev)
+                io.a[slot] = acts[slot].data_ptr()
+            io.w_krsc[slot] = conv._h_images.krsc.data_ptr()
+            io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
+            io.running_mean[slot], io.running_var[slot] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            if getattr(bn, '_ticked', False):
+                bn._ticked = False
+            else:
+                bn.num_batches_tracked.add_(1)
+        ws = workspace(dev, plan.main_bytes)
+        check(lib().p3d_hblock_fwd(ctypes.byref(plan.desc), ctypes.byref(io), _p(ws), ws.numel(), _stream()), 'p3d_hblock_fwd')
+        ctx.block, ctx.plan = block, plan
+        ctx.saved = (cs, acts, coefs)
+        ctx.save_for_backward(x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops_block
+        if ctx.saved is None:
+            raise P3DError('residual_block (fp16): backward called a second time on the same graph; run the forward again')
+        block, plan = ctx.block, ctx.plan
+        x, out = ctx.saved_tensors
+        cs, acts, coefs = ctx.saved
+        ctx.saved = None
+        dev = x.device
+        dout = _cl(dout)
+        d = plan.desc
+        last = d.nconv - 1
+        need_dx = bool(ctx.needs_input_grad[0])
+        params = []
+        for slot, conv, bn in plan.layers:
+            params += [(slot, 'dw', conv.weight), (slot, 'dgamma', bn.weight), (slot, 'dbeta', bn.bias)]
+        sinks = [_grad_sink(p) for _, _, p in params]
+        direct = all(s_ is not None for s_ in sinks)
+        grads = sinks if direct else [torch.empty(p.shape, dtype=torch.float32, device=dev) for _, _, p in params]
+        io = HBlockIO()
+        io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
+        keep = []
+        for slot, conv, bn in plan.layers:
+            n, k, ho, wo = plan.shapes[slot]
+            io.c[slot], io.coef[slot] = cs[slot].data_ptr(), coefs[slot].data_ptr()
+            if slot in acts:
+                io.a[slot] = acts[slot].data_ptr()
+            io.w_crsk[slot] = conv._h_images.crsk.data_ptr()
+            io.c_real[slot] = conv._h_images.c_real
+            dc = _empty(n, k, ho, wo, dev)
+            keep.append(dc)
+            io.dc[slot] = dc.data_ptr()
+            if slot < last:
+                da = _empty(n, k, ho, wo, dev)
+                keep.append(da)
+                io.da[slot] = da.data_ptr()
+        dres = _empty(*plan.out_shape, dev)                # the gradient that enters the shortcut; with an identity shortcut it becomes dx
+        io.da[3] = dres.data_ptr()
+        dx = None
+        if need_dx:
+            if d.has_downsample:
+                dx = _empty(*x.shape, dev)
+                io.dx = dx.data_ptr()
+            else:
+                dx = dres
+        for (slot, kind, _), g in zip(params, grads):
+            getattr(io, kind)[slot] = g.data_ptr()
+        desc = ops_block.BlockDesc.from_buffer_copy(d)
+        desc.need_dx, desc.accumulate_grads = int(need_dx), int(direct)
+        ws = workspace(dev, plan.main_bytes)
+        two = ops.WGRAD_STREAM and direct
+        if two:
+            side = ops._side_stream(dev)
+            ops._queue_join()
+            sws = ops._side_workspace(dev, plan.side_bytes)
+            side_handle = _vp(side.cuda_stream)
+        else:
+            sws = ops._second_workspace(dev, plan.side_bytes)
+            side_handle = None
+        check(lib().p3d_hblock_bwd(ctypes.byref(desc), ctypes.byref(io), _p(ws), ws.numel(), _p(sws), sws.numel(), _stream(), side_handle), 'p3d_hblock_bwd')
+        if two:
+            for t in [x, dout] + list(acts.values()) + keep:        # freed by autograd while the second stream may still read them
+                t.record_stream(side)
+        if direct:
+            for _, _, p in params:
+                _grad_done(p)
+            return (dx, None) + (None,) * len(params)
+        return (dx, None) + tuple(grads)
+
+
+def residual_block(block, x):
+    from . import ops_block
+    params = []
+    for _, conv, bn in ops_block._layers(block):
+        params += [conv.weight, bn.weight, bn.bias]
+    return HResidualBlockFn.apply(x, block, *params)

@@ -255,21 +255,18 @@ def main():
     trainer.train_step(*batches[0])
     sync()
     prof = None
-    if not opt.half:
-        ops.profile_convs(True)
-    else:
-        ops.PROFILE = [] if rank == 0 else None
+    ops.profile_convs(True)                      # brackets inside the library (the block executors launch their convolutions from C)
+    if opt.half:
+        ops.PROFILE = [] if rank == 0 else None      # + the fp16 per-layer calls (stem, regressor), bracketed in Python
     t1 = time.perf_counter()
     for i in range(ksteps):
         trainer.train_step(*batches[i % nbuf])
     sync()
     serial_elapsed = time.perf_counter() - t1
-    if not opt.half:
-        ops.profile_convs(False)
-        prof = ops.collect_conv_profile()
-    else:
+    ops.profile_convs(False)
+    prof = ops.collect_conv_profile()
+    if opt.half:
         recs, ops.PROFILE = ops.PROFILE or [], None
-        prof = {}
         for kind, fl, start, end in recs:
             ms, f0, n0 = prof.get(kind, (0.0, 0.0, 0))
             prof[kind] = (ms + start.elapsed_time(end), f0 + fl, n0 + 1)

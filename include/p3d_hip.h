@@ -173,6 +173,36 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
                       void* stream, void* side_stream);
 
+/* The same block on the fp16 NHWC kernels of -half_acc (depth_train.py:73-83,413-449): one call per block and direction over p3d_hconv2d_* / p3d_hbn_train_*,
+ * instead of one Python-level call per layer (the fp16 step is bound by the host's enqueue work).  Tensors are fp16 NHWC unless typed otherwise; the descriptor is the
+ * fp32 block's (channel counts of a convolution = the padded counts of its fp16 tensors). */
+typedef struct p3d_hblock_io {
+    const void* x;              /* block input */
+    void* out;                  /* block output */
+    const void* w_krsc[4];      /* fp16 forward weight images (p3d_weight_images_f16*) */
+    const void* w_crsk[4];      /* fp16 data-gradient weight images */
+    void* c[4];                 /* raw conv outputs */
+    void* a[4];                 /* a[i] = relu(bn_i(c[i])), i < nconv-1; a[3] = bn_ds(c[3]), the shortcut of a downsample branch */
+    float* coef[4];             /* [K_i][4] fp32 per BatchNorm: written by forward, read by backward */
+    const float* gamma[4];
+    const float* beta[4];
+    float* running_mean[4];
+    float* running_var[4];
+    /* backward only */
+    const void* dout;
+    void* dc[4];                /* scratch: gradient w.r.t. c[i] */
+    void* da[4];                /* scratch: gradient w.r.t. a[i], i < nconv-1; da[3]: the gradient that enters the shortcut (with an identity shortcut it becomes dx) */
+    void* dx;                   /* gradient w.r.t. x with a downsample branch (identity: da[3]) */
+    float* dw[4];               /* fp32 master gradients */
+    float* dgamma[4];
+    float* dbeta[4];
+    int32_t c_real[4];          /* real (unpadded) input channels of conv i */
+} p3d_hblock_io;
+int32_t p3d_hblock_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
+int32_t p3d_hblock_fwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* stream);
+int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
+                       void* stream, void* side_stream);
+
 /* Pre-split weight images for p3d_block_io.wimg / wimgT: every fp32 weight as three bf16 pieces (hi + mid + lo = w exactly), laid out as the 12 KB LDS tile
  * each (filter tap, 128-channel tile, 16-deep K step) of the conv kernels consumes, so the weight operand costs the kernels no arithmetic.  w [K][C][R*S]. */
 int32_t p3d_fx_weight_image_bytes(int32_t K, int32_t C, int32_t RS, size_t* fwd_bytes, size_t* bwd_bytes);

@@ -451,3 +451,43 @@ def test_half_frozen_distillation_step(pkg):
     assert stats[1] == 1
     assert records[1]['cam_train_loss'] == pytest.approx(records[0]['cam_train_loss'], rel=5e-3)
     assert records[1]['dist_train_loss'] == pytest.approx(records[0]['dist_train_loss'], rel=2e-2)
+
+
+@pytest.mark.parametrize('case', [('bottleneck', 256, 64, 1, 1, 4, 32, False), ('bottleneck', 256, 128, 2, 1, 4, 32, True), ('bottleneck', 512, 256, 1, 2, 2, 16, True),
+                                  ('basic', 64, 64, 1, 1, 4, 32, False), ('basic', 64, 128, 2, 1, 4, 32, True)],
+                         ids=lambda c: '%s_c%d_p%d_s%d_d%d%s' % (c[0], c[1], c[2], c[3], c[4], '_ds' if c[7] else ''))
+def test_half_block_executor_equals_the_per_layer_path(case, pkg):
+    """p3d_hblock_fwd / p3d_hblock_bwd (one C call per block and direction) run the same fp16 kernels in the same order as the per-layer autograd path
+    (depthnet.py:40-56,96-116 under model.half()): output, input gradient, every parameter gradient and the running statistics are bit-identical."""
+    import test_block_gpu as tb
+    kind, inplanes, planes, stride, dil, n, h, with_ds = case
+    oh = pkg.ops_half
+    block = tb.build(pkg, kind, inplanes, planes, stride, dil, with_ds, seed=5)
+    oh.refresh_weights(block)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    x0 = torch.randn(n, inplanes, h, h, device='cuda', generator=gen).relu_().half().contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (False, True):
+        oh.HALF_BLOCKS = fused
+        try:
+            state = {k: v.clone() for k, v in block.state_dict().items()}
+            block.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            assert oh.block_usable(block, x) == fused
+            y = block(x)
+            assert ('HResidualBlockFn' in type(y.grad_fn).__name__) == fused
+            dy = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4)).half().contiguous(memory_format=torch.channels_last)
+            y.backward(dy)
+            pkg.ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append(dict(y=y.detach().clone(), dx=x.grad.clone(), grads={k: p.grad.clone() for k, p in block.named_parameters()},
+                            buffers={k: v.clone() for k, v in block.state_dict().items() if 'running' in k}))
+            block.load_state_dict(state)
+        finally:
+            oh.HALF_BLOCKS = True
+    a, b = res
+    assert torch.equal(a['y'], b['y']) and torch.equal(a['dx'], b['dx'])
+    for k in a['grads']:
+        assert torch.equal(a['grads'][k], b['grads'][k]), k
+    for k in a['buffers']:
+        assert torch.equal(a['buffers'][k], b['buffers'][k]), k
