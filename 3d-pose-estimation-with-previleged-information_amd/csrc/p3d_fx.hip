@@ -76,8 +76,9 @@ __device__ __forceinline__ int fx_rc_off(int row, int half) { return 32 * row + 
 
 // NA x NB of the wave's 2 x 2 sub-tiles (32 x 32 each) are computed: a wave whose rows reach beyond the tensor (272 = 2 x 128 + 16 regressor channels,
 // 64-channel layers in a 128-row tile) issues no MFMAs for the sub-tiles that hold nothing
-#define P3D_FX_PRODUCTS_AB(ACC, PIX, CH, NA, NB)                                                                        \
-    _Pragma("unroll") for (int pa = 0; pa < 6; ++pa) {                                                                 \
+#define P3D_FX_PRODUCTS_AB(ACC, PIX, CH, NA, NB) P3D_FX_PRODUCTS_RANGE(ACC, PIX, CH, NA, NB, 0, 6)
+#define P3D_FX_PRODUCTS_RANGE(ACC, PIX, CH, NA, NB, P0, P1)                                                            \
+    _Pragma("unroll") for (int pa = P0; pa < P1; ++pa) {                                                               \
         constexpr int PP[6] = {2, 0, 1, 1, 0, 0}, PC[6] = {0, 2, 1, 0, 1, 0};                                           \
         _Pragma("unroll") for (int a = 0; a < NA; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                   \
             ACC[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIX[PP[pa]][a], CH[PC[pa]][b], ACC[a][b], 0, 0, 0);    \
@@ -302,29 +303,53 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
         rd_c[a] = fx_rc_off(wm * 64 + a * 32 + fr, fh);
     }
     const int live_b = fx_live_subtiles(m0 + wm * 64, p.M);       // channel sub-tiles of this wave that hold output channels
-    if (nk > 0) { fetch(); stage(0); }
+    // Software pipeline: the registers fetched during K step kt - 1 hold step kt + 1; they go to LDS at the HEAD of step kt (right behind the reads of the
+    // first product's fragments), then the fetch of step kt + 2 is issued, then the step's MFMAs run.  So a fetch has a whole step to arrive, and the LDS
+    // stores complete under the MFMAs instead of in front of the barrier.
+    if (nk > 0) { fetch(); stage(0); if (nk > 1) fetch(); }
     __syncthreads();
     // the K loop, once per count of live channel sub-tiles (a wave-uniform choice made outside the loop, so that each copy is the straight-line loop)
     auto kloop = [&](auto nbt) {
         constexpr int NB = decltype(nbt)::value;
-        for (int kt = 0; kt < nk; ++kt) {
+        auto step = [&](int kt, auto st, auto fe) {
             const int buf = kt & 1;
-            if (kt + 1 < nk) fetch();
+            bf8 pf[3][2], cf[3][2];
+            auto read_p = [&](int pc) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if constexpr (AMODE == 0) pf[pc][a] = fx_tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
+                    else pf[pc][a] = *reinterpret_cast<const bf8*>(Ps + (buf * 3 + pc) * FX_PIECE + rd_p[a][0]);
+                }
+            };
+            auto read_c = [&](int pc) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (a < NB) cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a]);
+            };
+            // Order of a step, pinned with scheduling barriers (left alone the scheduler sinks the loads to the end of the step to save registers, and a wave
+            // that issues its six LDS stores before its first MFMA leaves the matrix pipe idle for their issue time): fragments of the first two products,
+            // the first product's MFMAs, under them the LDS stores of step kt + 1 and the loads of step kt + 2, then the rest.
             if constexpr (NB > 0) {
-                bf8 pf[3][2], cf[3][2];
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if constexpr (AMODE == 0) pf[pc][a] = fx_tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
-                        else pf[pc][a] = *reinterpret_cast<const bf8*>(Ps + (buf * 3 + pc) * FX_PIECE + rd_p[a][0]);
-                        if (a < NB) cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a]);
-                    }
-                P3D_FX_PRODUCTS_AB(acc, pf, cf, 2, NB)
+                read_p(2); read_c(0); read_p(0); read_c(2);
+                __builtin_amdgcn_sched_barrier(0);
+                P3D_FX_PRODUCTS_RANGE(acc, pf, cf, 2, NB, 0, 1)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (kt + 1 < nk) stage(buf ^ 1);
+            if constexpr (decltype(st)::value) stage(buf ^ 1);
+            if constexpr (decltype(fe)::value) fetch();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NB > 0) {
+                read_p(1); read_c(1);
+                P3D_FX_PRODUCTS_RANGE(acc, pf, cf, 2, NB, 1, 6)
+            }
             __syncthreads();
-        }
+        };
+        // (the two last steps are peeled so that the body of the main loop has no branch around its LDS stores: the wait in front of the first MFMA can then
+        // count exactly the reads it needs instead of draining the stores too)
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) step(kt, std::false_type{}, std::false_type{});
     };
     if (live_b == 2) kloop(std::integral_constant<int, 2>{});
     else if (live_b == 1) kloop(std::integral_constant<int, 1>{});
@@ -533,7 +558,9 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // fp32 operands: rows row, row + 64 of the tile, pixels 4 kq .. 4 kq + 3 of the step.  Image operands: pixel ipix of the step, channel group icg of the
     // tile's eight, 16-B half ih of the group's 32-B row.
     const int row = t >> 2, kq = t & 3;
-    const int ih = t & 1, ipix = (t >> 1) & 15, icg = t >> 5;
+    // (the pixel's bits are permuted so that the eight lanes of a ds_write_b128 group hold pixels {p, p + 1, p + 8, p + 9}: with consecutive pixels two of
+    // the group's 16-B chunks share a bank quad of the "tr" image)
+    const int ih = t & 1, ipix = ((t >> 1) & 1) | (((t >> 3) & 3) << 1) | (((t >> 2) & 1) << 3), icg = t >> 5;
     const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
     const int KG = p.K >> 4, CG = TAPS ? 1 : p.C >> 4;
     const int a_cg = (m0 >> 4) + icg, b_cg = TAPS ? 0 : (n0 >> 4) + icg;
@@ -684,33 +711,49 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
         else rd_b[a][0] = rd_b[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
     }
     const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
-    if (nk > 0) { fetch(); stage(0); }
+    if (nk > 0) { fetch(); stage(0); if (nk > 1) fetch(); }       // software pipeline as in fx_conv_kernel: stage step kt + 1 at the head of step kt, fetch step kt + 2
     __syncthreads();
     auto kloop = [&](auto nat, auto nbt) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles
         constexpr int NA = decltype(nat)::value, NB = decltype(nbt)::value;
-        for (int kt = 0; kt < nk; ++kt) {
+        constexpr bool LIVE = NA > 0 && NB > 0;
+        auto step = [&](int kt, auto st, auto fe) {
             const int buf = kt & 1;
-            if (kt + 1 < nk) fetch();
-            if constexpr (NA > 0 && NB > 0) {
-                bf8 af[3][2], bf[3][2];
+            bf8 af[3][2], bf[3][2];
+            auto read_a = [&](int pc) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if (a < NA) {
-                            if constexpr (AIMG) af[pc][a] = fx_tr_read(As + (buf * 3 + pc) * FX_PIECE, rd_a[a]);
-                            else af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a][0]);
-                        }
-                        if (a < NB) {
-                            if constexpr (BIMG) bf[pc][a] = fx_tr_read(Bs + (buf * 3 + pc) * FX_PIECE, rd_b[a]);
-                            else bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a][0]);
-                        }
+                for (int a = 0; a < 2; ++a)
+                    if (a < NA) {
+                        if constexpr (AIMG) af[pc][a] = fx_tr_read(As + (buf * 3 + pc) * FX_PIECE, rd_a[a]);
+                        else af[pc][a] = *reinterpret_cast<const bf8*>(As + (buf * 3 + pc) * FX_PIECE + rd_a[a][0]);
                     }
-                P3D_FX_PRODUCTS_AB(acc, af, bf, NA, NB)
+            };
+            auto read_b = [&](int pc) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (a < NB) {
+                        if constexpr (BIMG) bf[pc][a] = fx_tr_read(Bs + (buf * 3 + pc) * FX_PIECE, rd_b[a]);
+                        else bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a][0]);
+                    }
+            };
+            if constexpr (LIVE) {                                   // order of a step: see fx_conv_kernel
+                read_a(2); read_b(0); read_a(0); read_b(2);
+                __builtin_amdgcn_sched_barrier(0);
+                P3D_FX_PRODUCTS_RANGE(acc, af, bf, NA, NB, 0, 1)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (kt + 1 < nk) stage(buf ^ 1);
+            if constexpr (decltype(st)::value) stage(buf ^ 1);
+            if constexpr (decltype(fe)::value) fetch();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LIVE) {
+                read_a(1); read_b(1);
+                P3D_FX_PRODUCTS_RANGE(acc, af, bf, NA, NB, 1, 6)
+            }
             __syncthreads();
-        }
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) step(kt, std::false_type{}, std::false_type{});
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
