@@ -99,6 +99,13 @@ constexpr int FX_OOB = (int)0x80000000;
 #else
 #define FX_SO(x) (x)
 #endif
+// further timing-only ablations of fx_conv_kernel's K loop (wrong results): P3D_FX_ABL_NOREAD reads the MFMA fragments from LDS in the first step only,
+// P3D_FX_ABL_NOSTAGE never stores a fetched step to LDS, P3D_FX_ABL_NOBAR drops the loop's barrier (tools/ablate.sh builds and times them)
+#ifdef P3D_FX_ABL_NOREAD
+#define FX_ABL_READ(kt) ((kt) == 0)
+#else
+#define FX_ABL_READ(kt) true
+#endif
 __device__ f32x4 fx_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ i32x4 fx_buffer_load_i32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 __device__ float fx_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
@@ -143,11 +150,12 @@ __device__ __forceinline__ void fx_tr_frag_off(int lane, int cb, int (&off)[2]) 
 template <int AMODE, int PRO, int EPI>
 __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     static_assert(AMODE == 0 || PRO == 0, "the partial-convolution factor is applied by the in-kernel split");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 3 * FX_PIECE];     // both operands, double buffered; after the K loop: the result tile on its way out
-    unsigned char* const Ps = lds;                                                     // pixel (activation) operand
-    unsigned char* const Cs = lds + 2 * 3 * FX_PIECE;                                  // channel (weight) operand
-    __shared__ float red[2][2][128];                                                   // EPI 1 / 2: [wave along pixels][sum kind][channel]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    // one shared array: two buffers of [3 pixel pieces][3 channel pieces]; after the K loop the result tile on its way out (33.8 KB) and, behind it, the
+    // per-channel sums of EPI 1 / 2
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 6 * FX_PIECE];
+    constexpr int BUFB = 6 * FX_PIECE, CH0 = 3 * FX_PIECE;                             // bytes per buffer; offset of the channel (weight) pieces in a buffer
+    float (*const red)[2][128] = reinterpret_cast<float (*)[2][128]>(lds + 40960);     // EPI 1 / 2: [wave along pixels][sum kind][channel]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
     // XCD-aware remap (bijective): blocks b, b+8, ... share an XCD; give each XCD a contiguous run of logical ids (pixel tile outer, channel tile inner)
     int bid;
     {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     // ---- activation operand: staging maps ----
     // AMODE 0: reduction rows trow, trow + 8; columns (pixels) 4 tp4 .. 4 tp4 + 3.  AMODE 1: pixel pp of the tile, 16-B half ph of its 32-B row.
     const int trow = t >> 5, tp4 = t & 31;
-    const int pp = t >> 1, ph = t & 1;
+    const int pp = t >> 1, ph = (t & 1) ^ ((t >> 4) & 1);       // (the half whose place in the "rc" image is byte 16 t: a wave's chunks are 1 KB contiguous, lane-linear)
     const int col = n0 + (AMODE == 0 ? 4 * tp4 : pp);
     const bool col_ok = col < p.NP;
     int hbase = 0, wbase = 0, img_off = 0, mimg_off = 0;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
         w_tapoff = (wtap * p.tiles_m + tile_m) * csteps * (3 * FX_PIECE);
         const int hi = hbase + ir * p.hstep, wshift = is * p.wstep, wi0 = wbase + wshift;
         const bool row_ok = col_ok && (unsigned)hi < (unsigned)p.Hi;
-        if constexpr (AMODE == 1) {
+        if constexpr (AMODE != 0) {
             x_voff[0] = (row_ok && (unsigned)wi0 < (unsigned)p.Wi) ? (img_off + hi * p.Wi + wi0) * 32 + 16 * ph : FX_OOB;
         } else {
             x_vec = p.wmul == 1 && ((p.woff + wshift) & 3) == 0;        // wave-uniform: the four pixels are one aligned 16-B group, in or out together
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], FX_SO(so), 0);
         }
-        if constexpr (AMODE == 1) {
+        if constexpr (AMODE != 0) {
             const int so = (f_k >> 4) * HWi * 32;                  // wave-uniform: the K step's channel group
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) rxi[pc] = fx_buffer_load_i32x4(rXi[pc], x_voff[0], FX_SO(so), 0);
@@ -266,11 +274,11 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     const int st_p[2] = {fx_tr_off(trow, tp4 >> 1) + 8 * (tp4 & 1), fx_tr_off(trow + 8, tp4 >> 1) + 8 * (tp4 & 1)};
     const int st_p1 = fx_rc_off(pp, ph);
     auto stage = [&](int buf) {
-        unsigned char* pb = Ps + buf * 3 * FX_PIECE;
-        unsigned char* cb = Cs + buf * 3 * FX_PIECE;
+        unsigned char* pb = lds + buf * BUFB;
+        unsigned char* cb = pb + CH0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) *reinterpret_cast<i32x4*>(cb + 16 * (t + 256 * j)) = rwi[j];
-        if constexpr (AMODE == 1) {
+        if constexpr (AMODE != 0) {
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(pb + pc * FX_PIECE + st_p1) = rxi[pc];
         } else {
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     for (int a = 0; a < 2; ++a) {
         if constexpr (AMODE == 0) fx_tr_frag_off(lane, wn * 64 + a * 32, rd_p[a]);
         else rd_p[a][0] = rd_p[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
-        rd_c[a] = fx_rc_off(wm * 64 + a * 32 + fr, fh);
+        rd_c[a] = CH0 + fx_rc_off(wm * 64 + a * 32 + fr, fh);
     }
     const int live_b = fx_live_subtiles(m0 + wm * 64, p.M);       // channel sub-tiles of this wave that hold output channels
     // Software pipeline: the registers fetched during K step kt - 1 hold step kt + 1; they go to LDS at the HEAD of step kt (right behind the reads of the
@@ -311,38 +319,43 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     // the K loop, once per count of live channel sub-tiles (a wave-uniform choice made outside the loop, so that each copy is the straight-line loop)
     auto kloop = [&](auto nbt) {
         constexpr int NB = decltype(nbt)::value;
+        bf8 pf[3][2], cf[3][2];
         auto step = [&](int kt, auto st, auto fe) {
             const int buf = kt & 1;
-            bf8 pf[3][2], cf[3][2];
+            const unsigned char* bb = lds + buf * BUFB;
             auto read_p = [&](int pc) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    if constexpr (AMODE == 0) pf[pc][a] = fx_tr_read(Ps + (buf * 3 + pc) * FX_PIECE, rd_p[a]);
-                    else pf[pc][a] = *reinterpret_cast<const bf8*>(Ps + (buf * 3 + pc) * FX_PIECE + rd_p[a][0]);
+                    if constexpr (AMODE == 0) pf[pc][a] = fx_tr_read(bb + pc * FX_PIECE, rd_p[a]);
+                    else pf[pc][a] = *reinterpret_cast<const bf8*>(bb + pc * FX_PIECE + rd_p[a][0]);
                 }
             };
             auto read_c = [&](int pc) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    if (a < NB) cf[pc][a] = *reinterpret_cast<const bf8*>(Cs + (buf * 3 + pc) * FX_PIECE + rd_c[a]);
+                    if (a < NB) cf[pc][a] = *reinterpret_cast<const bf8*>(bb + pc * FX_PIECE + rd_c[a]);
             };
             // Order of a step, pinned with scheduling barriers (left alone the scheduler sinks the loads to the end of the step to save registers, and a wave
             // that issues its six LDS stores before its first MFMA leaves the matrix pipe idle for their issue time): fragments of the first two products,
             // the first product's MFMAs, under them the LDS stores of step kt + 1 and the loads of step kt + 2, then the rest.
             if constexpr (NB > 0) {
-                read_p(2); read_c(0); read_p(0); read_c(2);
+                if (FX_ABL_READ(kt)) { read_p(2); read_c(0); read_p(0); read_c(2); }
                 __builtin_amdgcn_sched_barrier(0);
                 P3D_FX_PRODUCTS_RANGE(acc, pf, cf, 2, NB, 0, 1)
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef P3D_FX_ABL_NOSTAGE
             if constexpr (decltype(st)::value) stage(buf ^ 1);
+#endif
             if constexpr (decltype(fe)::value) fetch();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NB > 0) {
-                read_p(1); read_c(1);
+                if (FX_ABL_READ(kt)) { read_p(1); read_c(1); }
                 P3D_FX_PRODUCTS_RANGE(acc, pf, cf, 2, NB, 1, 6)
             }
+#ifndef P3D_FX_ABL_NOBAR
             __syncthreads();
+#endif
         };
         // (the two last steps are peeled so that the body of the main loop has no branch around its LDS stores: the wait in front of the first MFMA can then
         // count exactly the reads it needs instead of draining the stores too)
@@ -1075,7 +1088,8 @@ int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_f
 }
 
 static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, dim3 grid, hipStream_t st) {
-#define P3D_FX_CASE(AM, PRO, EPI) if ((int)img == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
+    const int am = img ? 1 : 0;
+#define P3D_FX_CASE(AM, PRO, EPI) if (am == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
     P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 4)
     P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2)
 #undef P3D_FX_CASE

@@ -805,13 +805,16 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
-def act_image(x, mode=0, x2=None, table=None, masked=False):
+def act_image(x, mode=0, x2=None, table=None, masked=False, out=None):
     """Pre-split activation image of a fp32 NCHW tensor (p3d_fx_act_image): uint8 tensor of 6 bytes per element = three bf16 planes [N][C/16][H*W][16].
     mode 0: x; 1: relu(x * sc + sh); 2: A * (masked ? x * [x2 * sc + sh > 0] : x) + B * x2 + K, constants per channel from `table` [C][8]."""
     _need_gpu(x)
     x = x.contiguous()
     n, c, h, w = x.shape
-    img = torch.empty(lib().p3d_fx_act_image_bytes(n, c, h * w), dtype=torch.uint8, device=x.device)
+    nbytes = lib().p3d_fx_act_image_bytes(n, c, h * w)
+    img = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if out is None else out
+    if img.numel() != nbytes or img.dtype != torch.uint8 or not img.is_contiguous():
+        raise P3DError('act_image: `out` must be a contiguous uint8 tensor of %d bytes' % nbytes)
     check(lib().p3d_fx_act_image(mode, _p(x), None if x2 is None else _p(x2.contiguous()), None if table is None else _p(table.contiguous()), int(bool(masked)),
                                  _p(img), n, c, h * w, _stream()), 'p3d_fx_act_image')
     return img

@@ -78,6 +78,103 @@ class _Plan:
             self.main_bytes, self.side_bytes = m.value, s.value
         ks = [self.shapes[slot][1] for slot, _, _ in _layers(block)]
         self.table_rows = sum(ks)
+        self.slots = [slot for slot, _, _ in _layers(block)]
+        self.sets = []                  # _Buffers owned by this plan (see there)
+
+    def acquire(self, device):
+        """A free buffer set (or a new one).  Two are kept per plan (a block that runs twice before its backward: labelled + unlabelled batch of semi_train);
+        a third concurrent execution gets a set that dies with its autograd node."""
+        for b in self.sets:
+            if not b.held and b.device == device:
+                break
+        else:
+            b = _Buffers(self, device)
+            if len(self.sets) < 2:
+                self.sets.append(b)
+        if b.side_done is not None:     # the previous backward's weight gradients (second stream) read these buffers: order this stream behind them
+            torch.cuda.current_stream(device).wait_event(b.side_done)
+        return b
+
+
+_spare_shapes = set()
+
+
+class _Buffers:
+    """The device memory of ONE execution of a block, owned by its plan and used again by the next step: the conv outputs c_i, the activation images a_i and the
+    BatchNorm tables (written by forward, read by backward), and the backward's own scratch (gradient images, the fp32 gradients between layers).  Taking these
+    from the caching allocator per call cost more than its bookkeeping: tensors the weight-gradient stream reads must be `record_stream`ed, which makes their
+    re-use depend on GPU timing, and every so often a step found no free block and sat in hipMalloc -- 2.4 - 2.8 s on some boxes of the pool, once per
+    process, in the middle of the timed region (profiles/r03_summary.md section 8)."""
+
+    def __init__(self, plan, device):
+        self.device, self.held, self.side_done, self.bwd = device, False, None, None
+        f32 = dict(dtype=torch.float32, device=device)
+        self.tables = torch.empty((plan.table_rows, 8), **f32)
+        self.c = {slot: torch.empty(plan.shapes[slot], **f32) for slot in plan.slots}
+        # a_slot = relu(bn(c_slot)) exists only as a pre-split image (three bf16 planes: 6 B per element)
+        self.act = {slot: torch.empty(6 * self.c[slot].numel(), dtype=torch.uint8, device=device) for slot in plan.slots if slot < plan.desc.nconv - 1}
+        # the block's output (= the next block's input) and its gradient stay with the caching allocator; a little slack per distinct shape keeps the few
+        # `record_stream`ed tensors that remain (the block input) from ever forcing a hipMalloc in steady state
+        key = (plan.out_shape, str(device))
+        if key not in _spare_shapes:
+            _spare_shapes.add(key)
+            spare = [torch.empty(plan.out_shape, **f32) for _ in range(3)]
+            del spare
+
+    def backward_scratch(self, plan):
+        if self.bwd is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            dcimg = {slot: torch.empty(6 * self.c[slot].numel(), dtype=torch.uint8, device=self.device) for slot in plan.slots}    # image of d c_slot: what conv slot's wgrad and dgrad read
+            da = {slot: torch.empty(plan.shapes[slot], **f32) for slot in plan.slots if slot < plan.desc.nconv - 1}
+            gbuf = torch.empty(plan.out_shape, **f32) if plan.desc.has_downsample else None      # (identity shortcut: the gradient buffer IS dx, a fresh tensor)
+            self.bwd = (dcimg, da, gbuf)
+        return self.bwd
+
+
+class _OwnedBuffers:
+    """Named byte buffers owned by one module for one execution in flight (the per-layer twins of _Buffers: the operand images of ConvImagesFn / StemConvFn)."""
+
+    def __init__(self, device):
+        self.device, self.held, self.side_done, self.t = device, False, None, {}
+
+    def tensor(self, name, nbytes):
+        t = self.t.get(name)
+        if t is None or t.numel() != nbytes:
+            t = self.t[name] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return t
+
+    def mark_side(self, side):
+        if self.side_done is None:
+            self.side_done = torch.cuda.Event()
+        self.side_done.record(side)
+
+
+def _owned(module, key, device):
+    cache = module.__dict__.get('_owned_bufs')
+    if cache is None:
+        cache = module.__dict__['_owned_bufs'] = _Transient()
+    sets = cache.setdefault(key, [])
+    for b in sets:
+        if not b.held and b.device == device:
+            break
+    else:
+        b = _OwnedBuffers(device)
+        if len(sets) < 2:
+            sets.append(b)
+    if b.side_done is not None:
+        torch.cuda.current_stream(device).wait_event(b.side_done)
+    return b
+
+
+class _Lease:
+    """Marks a buffer set as in use for the life of an autograd node (released when the node dies: after backward, or when the graph is dropped)."""
+
+    def __init__(self, bufs):
+        self.bufs = bufs
+        bufs.held = True
+
+    def __del__(self):
+        self.bufs.held = False
 
 
 # Every convolution that has asked for weight images is registered here; when one of them finds its images stale (the optimizer stepped), ALL stale ones are
@@ -156,8 +253,20 @@ def weight_images(conv):
 USE_WEIGHT_IMAGES = os.environ.get('P3D_WEIGHT_IMAGES', '1') != '0'
 
 
+class _Transient(dict):
+    """Per-module caches of plans and device buffers: never copied or pickled with the module (a deep copy starts with an empty cache)."""
+
+    def __deepcopy__(self, memo):
+        return _Transient()
+
+    def __reduce__(self):
+        return (_Transient, ())
+
+
 def plan_for(block, x):
-    cache = block.__dict__.setdefault('_blk_plans', {})
+    cache = block.__dict__.get('_blk_plans')
+    if cache is None:
+        cache = block.__dict__['_blk_plans'] = _Transient()
     key = (tuple(x.shape), ops.X3_EPOCH)
     plan = cache.get(key)
     if plan is None:
@@ -187,16 +296,14 @@ class ResidualBlockFn(torch.autograd.Function):
         io.x = x.data_ptr()
         out = torch.empty(plan.out_shape, dtype=torch.float32, device=x.device)
         io.out = out.data_ptr()
-        tables = torch.empty((plan.table_rows, 8), dtype=torch.float32, device=x.device)
-        cs, acts, row = {}, {}, 0
+        bufs = plan.acquire(x.device)
+        lease = _Lease(bufs)
+        tables, cs, acts, row = bufs.tables, bufs.c, bufs.act, 0
         for slot, conv, bn in layers:
-            c = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
-            cs[slot] = c
-            io.w[slot], io.c[slot] = conv.weight.data_ptr(), c.data_ptr()
+            io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
             if USE_WEIGHT_IMAGES:
                 io.wimg[slot] = weight_images(conv)[0].data_ptr()
-            if slot < plan.desc.nconv - 1:              # a_slot = relu(bn(c_slot)) exists only as a pre-split image (three bf16 planes: 6 B per element)
-                acts[slot] = torch.empty(6 * c.numel(), dtype=torch.uint8, device=x.device)
+            if slot in acts:
                 io.aimg[slot] = acts[slot].data_ptr()
             io.table[slot] = tables.data_ptr() + row * 32
             row += plan.shapes[slot][1]
@@ -209,7 +316,7 @@ class ResidualBlockFn(torch.autograd.Function):
         ws = ops.workspace(x.device, plan.main_bytes)
         check(L.p3d_block_fwd(ctypes.byref(plan.desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._stream()), 'p3d_block_fwd')
         ctx.block, ctx.plan = block, plan
-        ctx.saved = (x, out, cs, tables, acts)             # (plain attributes: these tensors are never inputs / outputs of another node, save for x and out)
+        ctx.saved = (lease, bufs)                          # (a plain attribute: the plan's buffers are never inputs / outputs of another node)
         ctx.save_for_backward(x, out)
         return out
 
@@ -220,8 +327,9 @@ class ResidualBlockFn(torch.autograd.Function):
         if ctx.saved is None:
             raise P3DError('residual_block: backward called a second time on the same graph (retain_graph / re-entrant checkpointing): the block executor '
                            'releases its saved activations after the first backward; run the forward again')
-        _, _, cs, tables, acts = ctx.saved
+        lease, bufs = ctx.saved
         ctx.saved = None
+        cs, tables, acts = bufs.c, bufs.tables, bufs.act
         layers = _layers(block)
         L = lib()
         dout = dout.contiguous()
@@ -247,17 +355,14 @@ class ResidualBlockFn(torch.autograd.Function):
             io.gamma[slot], io.beta[slot] = bn.weight.data_ptr(), bn.bias.data_ptr()
         for (slot, kind, _), g in zip(params, grads):
             getattr(io, kind)[slot] = g.data_ptr()
-        keep = []
-        gbuf = torch.empty_like(out)
+        dcimg, da, gbuf = bufs.backward_scratch(plan)
+        if gbuf is None:
+            gbuf = torch.empty_like(out)
         io.gbuf = gbuf.data_ptr()
         for slot, _, _ in layers:
-            dcimg = torch.empty(6 * cs[slot].numel(), dtype=torch.uint8, device=x.device)      # image of d c_slot: what conv slot's wgrad and dgrad read
-            keep.append(dcimg)
-            io.dcimg[slot] = dcimg.data_ptr()
-            if slot < d.nconv - 1:
-                da = torch.empty(plan.shapes[slot], dtype=torch.float32, device=x.device)
-                keep.append(da)
-                io.da[slot] = da.data_ptr()
+            io.dcimg[slot] = dcimg[slot].data_ptr()
+            if slot in da:
+                io.da[slot] = da[slot].data_ptr()
         dx = None
         if need_dx:
             if d.has_downsample:
@@ -279,8 +384,11 @@ class ResidualBlockFn(torch.autograd.Function):
             side_handle = None
         check(L.p3d_block_bwd(ctypes.byref(desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._p(sws), sws.numel(), ops._stream(), side_handle), 'p3d_block_bwd')
         if two:
-            for t in [x, dout, gbuf, tables] + list(cs.values()) + list(acts.values()) + keep:      # freed by autograd while the second stream may still read them
-                t.record_stream(side)
+            x.record_stream(side)          # the one allocator-owned tensor the second stream reads (first conv's and the downsample's weight gradients)
+            if bufs.side_done is None:
+                bufs.side_done = torch.cuda.Event()
+            bufs.side_done.record(side)    # the plan's buffers: their next user (plan.acquire) orders itself behind this
+        del lease
         if direct:
             for _, _, p in params:
                 ops._grad_done(p)
@@ -327,7 +435,9 @@ class ConvImagesFn(torch.autograd.Function):
         L = lib()
         stride, pad, dil = _one(conv.stride), _one(conv.padding), _one(conv.dilation)
         d = ops._desc(x.shape, w.shape, stride, pad, dil)
-        x_img = ops.act_image(x)
+        bufs = _owned(conv, ('images', tuple(x.shape)), x.device)
+        ctx.lease = _Lease(bufs)
+        x_img = ops.act_image(x, out=bufs.tensor('x', 6 * x.numel()))
         y = torch.empty((d.N, d.K, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
         wimg = weight_images(conv)[0] if USE_WEIGHT_IMAGES else None
         ws = ops.workspace(x.device, L.p3d_fx_conv_img_workspace_bytes(ctypes.byref(d), 0))
@@ -347,7 +457,11 @@ class ConvImagesFn(torch.autograd.Function):
         L, st = lib(), ops._stream()
         dy = dy.contiguous()
         d = ops._desc(ctx.x_shape, w.shape, stride, pad, dil)
-        dy_img = ops.act_image(dy)
+        lease, ctx.lease = ctx.lease, None
+        if lease is None:
+            raise P3DError('conv2d_images: backward called a second time on the same graph; run the forward again')
+        bufs = lease.bufs
+        dy_img = ops.act_image(dy, out=bufs.tensor('dy', 6 * dy.numel()))
         dy_ready = ops._mark_ready() if (ops.WGRAD_STREAM and ctx.needs_input_grad[2]) else None
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -370,8 +484,7 @@ class ConvImagesFn(torch.autograd.Function):
                     with ops._Timed('wgrad', d):
                         check(L.p3d_fx_conv_wgrad_img(ctypes.byref(d), ops._p(dy_img), None, ops._p(x_img), ops._p(dw), ops._p(sws), sws.numel(), ops._stream()),
                               'p3d_fx_conv_wgrad_img')
-                for t in (dy_img, x_img):                   # freed by autograd while the side stream may still read them
-                    t.record_stream(side)
+                bufs.mark_side(side)                        # both images are the module's own buffers: their next user orders itself behind this
             else:
                 sws = ops.workspace(dy.device, nbytes)
                 with ops._Timed('wgrad', d):
@@ -430,7 +543,9 @@ class StemConvFn(torch.autograd.Function):
         L = lib()
         n, c, h, wd = x.shape
         k = w.shape[0]
-        x_img = torch.empty(L.p3d_stem_image_bytes(n, h, wd), dtype=torch.uint8, device=x.device)
+        bufs = _owned(conv, ('stem', tuple(x.shape)), x.device)
+        ctx.lease = _Lease(bufs)
+        x_img = bufs.tensor('x', L.p3d_stem_image_bytes(n, h, wd))
         check(L.p3d_stem_image(ops._p(x), ops._p(x_img), n, c, h, wd, ops._stream()), 'p3d_stem_image')
         y = torch.empty((n, k, h // 2, wd // 2), dtype=torch.float32, device=x.device)
         check(L.p3d_stem_fwd(ops._p(x_img), ops._p(stem_weight_image(conv)), ops._p(y), n, c, h, wd, k, ops._stream()), 'p3d_stem_fwd')
@@ -446,6 +561,9 @@ class StemConvFn(torch.autograd.Function):
         L = lib()
         dy = dy.contiguous()
         dw = None
+        lease, ctx.lease = ctx.lease, None
+        if lease is None:
+            raise P3DError('stem_conv: backward called a second time on the same graph; run the forward again')
         if ctx.needs_input_grad[2]:
             sink = ops._grad_sink(w)
             dw = torch.empty_like(w) if sink is None else sink
@@ -458,8 +576,8 @@ class StemConvFn(torch.autograd.Function):
                 sws = ops._side_workspace(dy.device, nbytes)
                 with torch.cuda.stream(side):
                     check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
-                for t in (dy, x_img):
-                    t.record_stream(side)
+                dy.record_stream(side)                      # (allocator-owned: the stem BatchNorm's data gradient)
+                lease.bufs.mark_side(side)
             else:
                 sws = ops.workspace(dy.device, nbytes)
                 check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 0 if sink is None else 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')

@@ -199,10 +199,21 @@ def main():
     ops.conv_path_stats(reset=True)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(opt.steps + 1)] if opt.lean else None      # (lean runs only: per-step spread as a diagnostic)
     t0 = time.perf_counter()
+    host = []                                             # lean runs: what the host spent enqueueing each step
+    watchdog = bool(marks) and os.environ.get('P3D_BENCH_WATCHDOG', '0') != '0'       # diagnostic: Python stack of a step whose enqueue takes > 0.3 s
+    if watchdog:
+        import faulthandler
     for i in range(opt.steps):
         if marks:
             marks[i].record()
+            h0 = time.perf_counter()
+            if watchdog:
+                faulthandler.dump_traceback_later(0.3, repeat=False, file=sys.stderr)
         loss = trainer.train_step(*batches[i % nbuf])
+        if marks:
+            host.append((time.perf_counter() - h0) * 1e3)
+            if watchdog:
+                faulthandler.cancel_dump_traceback_later()
     if marks:
         marks[opt.steps].record()
     sync()
@@ -220,7 +231,10 @@ def main():
                               'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True,
                               'dist_backend': dist_backend, 'dist_world_size': dist_world,
                               'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank))),
-                              'step_ms_min_med_max': [round(v, 2) for v in (lambda d: (d[0], d[len(d) // 2], d[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps)))]}),
+                              'step_ms_min_med_max': [round(v, 2) for v in (lambda d: (d[0], d[len(d) // 2], d[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps)))],
+                              'slowest_step': (lambda d: {'index': d.index(max(d)), 'gpu_ms': round(max(d), 2), 'host_enqueue_ms': round(host[d.index(max(d))], 2),
+                                                          'host_enqueue_ms_max': round(max(host), 2), 'host_slowest_index': host.index(max(host))})(
+                                  [marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps)])}),
                   flush=True)
         if dist.is_initialized():
             dist.barrier()

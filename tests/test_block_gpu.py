@@ -262,3 +262,53 @@ def test_fused_block_writes_gradients_into_the_flat_buffer(pkg):
     want = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in ref.parameters()])
     for flat, dx in res:
         assert rel(flat, want) < 1e-4 and rel(dx, xr.grad) < 2e-5
+
+
+def test_block_buffers_two_executions_in_flight_and_deep_copies(pkg):
+    """The executor's activations live in buffer sets owned by the block's plan (ops_block._Buffers), not in per-call allocations.  A block that runs twice
+    before either backward (semi_train: labelled + unlabelled batch through one model) must keep both executions apart; a third concurrent execution gets a
+    temporary set; a deep copy of a block that has run starts with an empty cache and gives the same results."""
+    import copy
+    block = build(pkg, 'bottleneck', 256, 64, 1, 1, False, seed=5)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    xs = [torch.randn(4, 256, 16, 16, device='cuda', generator=gen).relu_() for _ in range(3)]
+    dys = [torch.randn(4, 256, 16, 16, device='cuda', generator=gen) for _ in range(3)]
+    state = {k: v.clone() for k, v in block.state_dict().items()}
+
+    def one(i):
+        block.load_state_dict(state)
+        block.zero_grad(set_to_none=True)
+        x = xs[i].clone().requires_grad_(True)
+        y = block(x)
+        y.backward(dys[i])
+        return y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in block.named_parameters()}
+
+    alone = [one(i) for i in range(3)]
+    # three forwards, then the three backwards in another order
+    block.load_state_dict(state)
+    block.zero_grad(set_to_none=True)
+    inputs = [xs[i].clone().requires_grad_(True) for i in range(3)]
+    outs = [block(x) for x in inputs]
+    plans = block.__dict__['_blk_plans']
+    assert len(plans) == 1 and len(next(iter(plans.values())).sets) == 2          # two cached sets; the third execution holds a temporary one
+    assert all(b.held for b in next(iter(plans.values())).sets)
+    grads = {}
+    for i in (1, 2, 0):
+        block.zero_grad(set_to_none=True)
+        outs[i].backward(dys[i])
+        grads[i] = {n: p.grad.clone() for n, p in block.named_parameters()}
+    torch.cuda.synchronize()
+    assert not any(b.held for b in next(iter(plans.values())).sets)
+    for i in range(3):
+        assert torch.equal(outs[i].detach(), alone[i][0]), i
+        assert torch.equal(inputs[i].grad, alone[i][1]), i
+        for n, g in grads[i].items():
+            assert torch.equal(g, alone[i][2][n]), (i, n)
+    # a deep copy carries no buffers over and computes the same
+    twin = copy.deepcopy(block)
+    assert len(twin.__dict__['_blk_plans']) == 0
+    twin.load_state_dict(state)
+    x = xs[0].clone().requires_grad_(True)
+    y = twin(x)
+    y.backward(dys[0])
+    assert torch.equal(y.detach(), alone[0][0]) and torch.equal(x.grad, alone[0][1])
