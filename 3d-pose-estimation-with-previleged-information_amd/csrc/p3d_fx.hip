@@ -559,8 +559,23 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * FX_BM, n0 = blockIdx.x * FX_BN;
-    const int tap = TAPS ? 0 : blockIdx.z / p.nsplit, split = blockIdx.z - tap * p.nsplit;
+    // XCD-aware block order (the bijective remap of fx_conv_kernel): consecutive linear block ids go to different XCDs, so in grid order the blocks that share
+    // a dy tile or an x tile would each fetch it into a different L2.  Logical order: channel tile fastest, then output-channel tile, then filter tap, the
+    // pixel slab slowest -- every XCD works through a contiguous run of it, i.e. the tiles of one or two slabs, whose operands its L2 then holds once.
+    int bx, by, bz;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bx = bid % gx;
+        const int rest = bid / gx;
+        by = rest % gy;
+        bz = rest / gy;
+    }
+    const int m0 = by * FX_BM, n0 = bx * FX_BN;
+    const int ntaps = TAPS ? 1 : p.R * p.S;
+    const int split = bz / ntaps, tap = bz - split * ntaps;
     const int tr = tap / p.S, ts = tap - tr * p.S;
     const int dh = tr * p.dil - p.pad, dw = ts * p.dil - p.pad;             // input coordinate = output coordinate * stride + (dh, dw)
     const int OHW = p.OH * p.OW, HWi = p.Hi * p.Wi;
