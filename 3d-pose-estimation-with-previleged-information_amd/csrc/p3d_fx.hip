@@ -1249,13 +1249,13 @@ int fx_wgrad_splits(const p3d_conv_desc* d) {
     if (g_wgrad_target > 0) target = g_wgrad_target;          // (tuning aid: p3d_fx_tune, tools/split_sweep.py)
     else if (tiles >= 256) target = 1536;
     else switch ((int)tiles) {
-        case 4: target = 384; break;
-        case 8: case 36: target = 512; break;
-        case 9: target = d->stride > 1 ? 576 : (d->C <= 64 ? 720 : 768); break;
-        case 16: target = 896; break;
-        case 32: target = d->stride > 1 ? 720 : 512; break;
+        case 2: target = 384; break;
+        case 4: target = 640; break;
+        case 8: case 32: case 36: target = 512; break;
+        case 16: target = 256; break;
+        case 128: target = 1024; break;
         case 144: target = 720; break;
-        default: target = 768;
+        default: target = 768;              // (1, 9, 64 tiles; anything the sweep has not seen)
     }
     int64_t splits = (2 * target + tiles) / (2 * tiles);                 // nearest
     if (splits > total / 32) splits = total / 32;                        // at least 32 K steps per block
