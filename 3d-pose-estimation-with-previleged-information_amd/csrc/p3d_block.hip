@@ -158,7 +158,7 @@ __device__ __forceinline__ void close_finalize(const CloseFin& f, int ch, int C,
 // The batch statistics of the closing BatchNorm (and of the downsample BatchNorm) are finalized here, from the partial sums their convolutions' epilogues left.
 // grid (C, split): block (c, s) owns images n = s, s + split, ...; block (c, 0) writes the channel's table entry and running statistics.
 __global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __restrict__ c, const CloseFin fin, const float* __restrict__ res, const CloseFin rfin,
-                                                              float* __restrict__ out, int N, int C, int HW, int relu, double count) {
+                                                              float* __restrict__ out, unsigned char* __restrict__ omask, int N, int C, int HW, int relu, double count) {
     const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     __shared__ double red[12];
     float sc, sh, rsc = 1.f, rsh = 0.f;
@@ -170,24 +170,30 @@ __global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __res
         const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
         const f32x4* rv = reinterpret_cast<const f32x4*>(res + off);
         f32x4* ov = reinterpret_cast<f32x4*>(out + off);
+        unsigned char* mv = omask ? omask + off / 4 : nullptr;
         for (int i = threadIdx.x; i < HW / 4; i += 256) {
             f32x4 q = cv[i];
             const f32x4 r = rv[i];
+            unsigned m = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = fmaf(q[e], sc, sh) + (ds ? fmaf(r[e], rsc, rsh) : r[e]);
+                m |= (v > 0.f ? 1u : 0u) << e;
                 q[e] = relu ? fmaxf(v, 0.f) : v;
             }
             ov[i] = q;
+            if (mv) mv[i] = (unsigned char)m;             // which of the four outputs are positive: what the backward pass needs of `out` (1 byte instead of 16)
         }
     }
 }
 
 // Opens the block in backward: g = relu ? dout * [out > 0] : dout (written to gbuf when relu), and per channel the sums of g, g * (c - mean) and, with a
-// downsample branch, g * (rc - rmean).  partial [C][split][3] fp64.
+// downsample branch, g * (rc - rmean).  partial [C][split][3] fp64.  [out > 0] comes from the forward pass's mask bytes when the caller keeps them (omask),
+// else from `out` itself.
 __global__ __launch_bounds__(256) void block_open_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ c,
                                                              const float* __restrict__ tab, const float* __restrict__ rc, const float* __restrict__ rtab,
-                                                             float* __restrict__ gbuf, double* __restrict__ partial, int N, int C, int HW, int relu) {
+                                                             float* __restrict__ gbuf, double* __restrict__ partial, const unsigned char* __restrict__ omask, int N, int C,
+                                                             int HW, int relu) {
     const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     const float mean = tab[ch * FX_TAB + 2], rmean = rtab ? rtab[ch * FX_TAB + 2] : 0.f;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -198,13 +204,20 @@ __global__ __launch_bounds__(256) void block_open_bwd_kernel(const float* __rest
         const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
         const f32x4* rv = rc ? reinterpret_cast<const f32x4*>(rc + off) : nullptr;
         f32x4* gv = reinterpret_cast<f32x4*>(gbuf + off);
+        const unsigned char* mv = omask ? omask + off / 4 : nullptr;
         for (int i = threadIdx.x; i < HW / 4; i += 256) {
             f32x4 g = dv[i];
             const f32x4 q = cv[i];
             if (relu) {
-                const f32x4 o = ov[i];
+                if (mv) {
+                    const unsigned m = mv[i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+                } else {
+                    const f32x4 o = ov[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                }
                 gv[i] = g;
             }
             float a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -410,7 +423,8 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     if (b->has_downsample)
         rf = CloseFin{partial2, fx_partial_rows_fwd(&b->conv[3]), io->gamma[3], io->beta[3], io->running_mean[3], io->running_var[3], b->momentum[3], b->eps[3], io->table[3]};
     hipLaunchKernelGGL(block_close_fwd_kernel, dim3(dl->K, close_split(dl->N, dl->K)), dim3(256), 0, st, (const float*)io->c[last], cf,
-                       b->has_downsample ? (const float*)io->c[3] : io->x, rf, io->out, dl->N, dl->K, HW, b->relu_out, (double)dl->N * HW);
+                       b->has_downsample ? (const float*)io->c[3] : io->x, rf, io->out, b->relu_out ? io->out_mask : (unsigned char*)nullptr, dl->N, dl->K, HW, b->relu_out,
+                       (double)dl->N * HW);
     return check_launch("block_fwd");
 }
 
@@ -447,7 +461,8 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     const float* g = b->relu_out ? io->gbuf : io->dout;
     hipLaunchKernelGGL(block_open_bwd_kernel, dim3(dl->K, split), dim3(256), 0, st, io->dout, (const float*)io->out, (const float*)io->c[last],
                        (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
-                       b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->gbuf, (double*)partial, dl->N, dl->K, dl->Ho * dl->Wo, b->relu_out);
+                       b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->gbuf, (double*)partial, (const unsigned char*)io->out_mask, dl->N, dl->K,
+                       dl->Ho * dl->Wo, b->relu_out);
     const double cnt_last = (double)dl->N * dl->Ho * dl->Wo;
     if (int32_t e = check_launch("block_bwd open")) return e;
 

@@ -32,7 +32,7 @@ class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
     _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('aimg', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcimg', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
-                ('dgamma', _vp * 4), ('dbeta', _vp * 4)]
+                ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('out_mask', _vp)]
 
 
 def _one(v):
@@ -113,6 +113,9 @@ class _Buffers:
         self.c = {slot: torch.empty(plan.shapes[slot], **f32) for slot in plan.slots}
         # a_slot = relu(bn(c_slot)) exists only as a pre-split image (three bf16 planes: 6 B per element)
         self.act = {slot: torch.empty(6 * self.c[slot].numel(), dtype=torch.uint8, device=device) for slot in plan.slots if slot < plan.desc.nconv - 1}
+        # which outputs the closing ReLU let through: one byte per four elements, all the backward pass needs of `out`
+        n_out = plan.out_shape[0] * plan.out_shape[1] * plan.out_shape[2] * plan.out_shape[3]
+        self.mask = torch.empty(n_out // 4, dtype=torch.uint8, device=device) if plan.desc.relu_out else None
         # the block's output (= the next block's input) and its gradient stay with the caching allocator; a little slack per distinct shape keeps the few
         # `record_stream`ed tensors that remain (the block input) from ever forcing a hipMalloc in steady state
         key = (plan.out_shape, str(device))
@@ -299,6 +302,8 @@ class ResidualBlockFn(torch.autograd.Function):
         bufs = plan.acquire(x.device)
         lease = _Lease(bufs)
         tables, cs, acts, row = bufs.tables, bufs.c, bufs.act, 0
+        if bufs.mask is not None:
+            io.out_mask = bufs.mask.data_ptr()
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
             if USE_WEIGHT_IMAGES:
@@ -343,6 +348,8 @@ class ResidualBlockFn(torch.autograd.Function):
         grads = sinks if direct else [torch.empty_like(p) for _, _, p in params]
         io = BlockIO()
         io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
+        if bufs.mask is not None:
+            io.out_mask = bufs.mask.data_ptr()
         row = 0
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()

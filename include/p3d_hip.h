@@ -162,6 +162,9 @@ typedef struct p3d_block_io {
     float* dw[4];
     float* dgamma[4];
     float* dbeta[4];
+    /* forward + backward, optional (NULL: backward reads `out`): one byte per four consecutive output elements, bit e = [out[4 i + e] > 0]; written by
+       p3d_block_fwd of a block that ends in a ReLU, read by p3d_block_bwd instead of `out` (N * K_last * Ho * Wo / 4 bytes) */
+    unsigned char* out_mask;
 } p3d_block_io;
 
 /* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 64, four-pixel-aligned rows, maps of a
