@@ -1341,12 +1341,19 @@ __global__ __launch_bounds__(256) void fx_stem_weights_kernel(const float* __res
 
 // slabs [split][K][256 = tap * 16 + c'] -> dw [K][Cin][7][7] (=|+=).  One thread per (k, column): consecutive threads sum consecutive columns over the splits
 // (coalesced), then the columns that are a weight (c < Cin, the tap inside the 7x7 window) are scattered to it.
-__global__ __launch_bounds__(256) void fx_stem_dw_kernel(const float* __restrict__ slabs, int nsplit, float* __restrict__ dw, int K, int Cin, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K * 256) return;
+__global__ __launch_bounds__(1024) void fx_stem_dw_kernel(const float* __restrict__ slabs, int nsplit, float* __restrict__ dw, int K, int Cin, int accumulate) {
+    // grid (K, 4): block = output channel k, 64 of its 256 restated columns; 16 groups of 64 threads sum every 16th slab, group 0 adds the 16 partial sums in order
+    __shared__ float part[16][64];
+    const int k = blockIdx.x, t = threadIdx.x, g = t >> 6, cl = t & 63, col = blockIdx.y * 64 + cl;
     float acc = 0.f;
-    for (int z = 0; z < nsplit; ++z) acc += slabs[(size_t)z * K * 256 + i];
-    const int k = i >> 8, col = i & 255, tp = col >> 4, c2 = col & 15;
+    for (int z = g; z < nsplit; z += 16) acc += slabs[((size_t)z * K + k) * 256 + col];
+    part[g][cl] = acc;
+    __syncthreads();
+    if (g != 0) return;
+    acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += part[j][cl];
+    const int tp = col >> 4, c2 = col & 15;
     const int c = c2 >> 2, pi = (c2 >> 1) & 1, pj = c2 & 1;
     const int r = 2 * (tp >> 2) - 1 + pi, q = 2 * (tp & 3) - 1 + pj;
     if (c < Cin && r >= 0 && r < 7 && q >= 0 && q < 7) {
@@ -1419,7 +1426,7 @@ int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int 
     p.nsplit = fx_stem_splits(N, H, W);
     p.spb = (int)ceil_div((int64_t)N * (H2 * W2 / FX_BK), p.nsplit);
     hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K), dim3(256), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
+    hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K, 4), dim3(1024), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
     return check_launch("fx_stem_wgrad");
 }
 
