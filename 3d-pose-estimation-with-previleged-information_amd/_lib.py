@@ -78,6 +78,9 @@ SIGNATURES = {
     'p3d_relu_bwd': (_i32, [_ptr, _ptr, _ptr, _i64, _ptr]),
     'p3d_maxpool3x3s2_fwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
     'p3d_maxpool3x3s2_bwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    'p3d_stem_tail_supported': (_i32, [_i32, _i32, _i32, _i32]),
+    'p3d_stem_tail_fwd': (_i32, [_ptr] * 9 + [_i32, _i32, _i32, _i32, _f32, _f32, _ptr, _sz, _ptr]),
+    'p3d_stem_tail_bwd': (_i32, [_ptr] * 10 + [_i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_softargmax3d_fwd': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_softargmax3d_bwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr]),
     'p3d_pose_loss_fwd_bwd': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _f32, _i32, _f32, _ptr, _ptr]),

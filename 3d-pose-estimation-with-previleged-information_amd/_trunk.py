@@ -199,4 +199,7 @@ def stem(conv, bn, pool, x):
     """conv -> BN+ReLU (one kernel) -> maxpool; at inference conv + BN + ReLU are one kernel."""
     if ops.can_fuse_eval(x, conv, bn):
         return pool(ops.conv_bn_eval(x, conv, bn, relu=True))
-    return pool(bn(conv(x), relu=True))
+    c = conv(x)
+    if ops.stem_tail_usable(c, bn, pool):              # training, fp32: BatchNorm + ReLU + max pool as one node that never writes the BatchNorm output
+        return ops.stem_tail(c, bn)
+    return pool(bn(c, relu=True))

@@ -544,6 +544,72 @@ def maxpool3x3s2(x):
     return MaxPool3x3S2Fn.apply(x)
 
 
+class StemTailFn(torch.autograd.Function):
+    """maxpool(relu(bn(x))) of the stem in training mode as ONE node (p3d_stem_tail_fwd / bwd): the BatchNorm output (268 MB at batch 64) is neither written nor
+    read; bit-identical to BatchNormActFn + MaxPool3x3S2Fn (depthnet.py:139-140)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        _need_gpu(x, gamma, beta, running_mean, running_var)
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        L, st = lib(), _stream()
+        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=x.device)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
+        check(L.p3d_stem_tail_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(idx), _p(mean), _p(invstd), n, c, h, w, momentum, eps,
+                                  _p(ws), ws.numel(), st), 'p3d_stem_tail_fwd')
+        ctx.save_for_backward(x, idx, gamma, beta, mean, invstd)
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, idx, gamma, beta, mean, invstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = dy.contiguous()
+        L, st = lib(), _stream()
+        dx = torch.empty_like(x)
+        g_param, b_param = ctx.params
+        g_sink, b_sink = _grad_sink(g_param), _grad_sink(b_param)
+        direct = g_sink is not None and b_sink is not None
+        dgamma = g_sink if direct else torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = b_sink if direct else torch.empty_like(dgamma)
+        ws = workspace(x.device, L.p3d_bn_workspace_bytes(n, c, h * w))
+        check(L.p3d_stem_tail_bwd(_p(dy), _p(idx), _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dgamma), _p(dbeta), n, c, h, w, int(direct),
+                                  _p(ws), ws.numel(), st), 'p3d_stem_tail_bwd')
+        if direct:
+            dgamma = dbeta = None
+            _grad_done(g_param)
+            _grad_done(b_param)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+STEM_TAIL = os.environ.get('P3D_STEM_TAIL', '1') != '0'        # A/B switch: 0 = BatchNorm + ReLU and the max pool of the stem as two nodes
+
+
+def stem_tail_usable(x, bn, pool):
+    if not (STEM_TAIL and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.training and bn.affine and bn.track_running_stats and torch.is_grad_enabled()):
+        return False
+    one = lambda v: v[0] if isinstance(v, (tuple, list)) else v
+    if (one(pool.kernel_size), one(pool.stride), one(pool.padding), one(pool.dilation)) != (3, 2, 1, 1) or pool.ceil_mode:
+        return False
+    n, c, h, w = x.shape
+    return bool(lib().p3d_stem_tail_supported(n, c, h, w))
+
+
+def stem_tail(x, bn):
+    """maxpool(relu(bn(x))) with bn's running statistics and batch counter updated as nn.BatchNorm2d.forward does (nn.py)."""
+    if getattr(bn, '_ticked', False):
+        bn._ticked = False
+    else:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return StemTailFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps)
+
+
 # --------------------------------------------------------------------------------------------
 class SoftArgmax3dFn(torch.autograd.Function):
     """utils.to_heatmap followed by utils.decode (utils.py:154-194), fused."""

@@ -19,6 +19,8 @@ _vp = ctypes.c_void_p
 # (p3d_block_bwd orders them with events), as in the per-layer path; the step is bitwise reproducible either way
 # (tests/test_step_gpu.py::test_training_is_bitwise_reproducible).
 BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '1') != '0'
+# P3D_OUT_MASK=0: the backward pass reads the block's fp32 output for the closing ReLU's mask instead of the mask bytes forward leaves (p3d_block_io.out_mask = NULL)
+USE_OUT_MASK = os.environ.get('P3D_OUT_MASK', '1') != '0'
 
 
 class BlockDesc(ctypes.Structure):
@@ -115,7 +117,7 @@ class _Buffers:
         self.act = {slot: torch.empty(6 * self.c[slot].numel(), dtype=torch.uint8, device=device) for slot in plan.slots if slot < plan.desc.nconv - 1}
         # which outputs the closing ReLU let through: one byte per four elements, all the backward pass needs of `out`
         n_out = plan.out_shape[0] * plan.out_shape[1] * plan.out_shape[2] * plan.out_shape[3]
-        self.mask = torch.empty(n_out // 4, dtype=torch.uint8, device=device) if plan.desc.relu_out else None
+        self.mask = torch.empty(n_out // 4, dtype=torch.uint8, device=device) if (plan.desc.relu_out and USE_OUT_MASK) else None
         # the block's output (= the next block's input) and its gradient stay with the caching allocator; a little slack per distinct shape keeps the few
         # `record_stream`ed tensors that remain (the block input) from ever forcing a hipMalloc in steady state
         key = (plan.out_shape, str(device))

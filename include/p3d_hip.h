@@ -292,6 +292,21 @@ int32_t p3d_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int32_t NC,
 int32_t p3d_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int32_t NC, int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The stem's tail in training mode: maxpool(relu(bn1(x)))  (depthnet.py:139-140, resnet.py / fusionnet.py twins) as one node.
+ * The BatchNorm output is never written: forward = statistics pass + one pass that applies relu(bn(.)) inside the pooling windows; backward = two passes that
+ * route the pooled gradient through the argmax bytes on the fly.  Bit-identical to p3d_bn_train_fwd + p3d_maxpool3x3s2_fwd and their backward calls.
+ * x [N,C,H,W] (H, W even, W % 4 == 0) -> y [N,C,H/2,W/2], idx [N,C,H/2,W/2] bytes; save_mean / save_invstd [C] feed backward.
+ * workspace: p3d_bn_workspace_bytes(N, C, H * W).
+ * ------------------------------------------------------------------------------------------ */
+int32_t p3d_stem_tail_supported(int32_t N, int32_t C, int32_t H, int32_t W);
+int32_t p3d_stem_tail_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y, uint8_t* idx,
+                          float* save_mean, float* save_invstd, int32_t N, int32_t C, int32_t H, int32_t W, float momentum, float eps, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int32_t p3d_stem_tail_bwd(const float* dy, const uint8_t* idx, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                          const float* save_invstd, float* dx, float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t H, int32_t W, int32_t accumulate,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Volumetric soft-argmax head: utils.to_heatmap + utils.decode  (utils.py:154-194)
  * z [B, D*J, H, W] (channel = d*J + j) -> coords [B, J, 3] = (x, y, z) * depth_range.
  * ------------------------------------------------------------------------------------------ */

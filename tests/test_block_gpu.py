@@ -312,3 +312,26 @@ def test_block_buffers_two_executions_in_flight_and_deep_copies(pkg):
     y = twin(x)
     y.backward(dys[0])
     assert torch.equal(y.detach(), alone[0][0]) and torch.equal(x.grad, alone[0][1])
+
+
+def test_out_mask_bytes_equal_reading_the_output(pkg):
+    """p3d_block_io.out_mask is optional: with the mask bytes forward leaves, and with NULL (backward reads `out`), every result is bit-identical."""
+    ob = pkg.ops_block
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    x0 = torch.randn(4, 256, 32, 32, device='cuda', generator=gen).relu_()
+    dy = torch.randn(4, 512, 16, 16, device='cuda', generator=gen)
+    res = {}
+    before = ob.USE_OUT_MASK
+    try:
+        for use in (True, False):
+            ob.USE_OUT_MASK = use
+            torch.manual_seed(77)                                                  # (build() seeds after it has made the downsample pair)
+            block = build(pkg, 'bottleneck', 256, 128, 2, 1, True, seed=9)         # (a fresh module: buffer sets are created per plan)
+            res[use] = run(pkg, block, x0, dy, fused=True)
+            bufs = next(iter(block.__dict__['_blk_plans'].values())).sets[0]
+            assert (bufs.mask is not None) == use
+    finally:
+        ob.USE_OUT_MASK = before
+    assert torch.equal(res[True]['y'], res[False]['y']) and torch.equal(res[True]['dx'], res[False]['dx'])
+    for n, g in res[True]['grads'].items():
+        assert torch.equal(g, res[False]['grads'][n]), n

@@ -729,3 +729,33 @@ def test_multi_tap_conv_outside_a_block_takes_image_operands(pkg):
     assert np.abs(host(conv.weight.grad) - want).max() < 5e-5 * np.abs(want).max()
     want = dyh.astype(np.float64).sum((0, 2, 3))
     assert np.abs(host(conv.bias.grad) - want).max() < 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64), (3, 16, 32, 20), (2, 8, 6, 4)])
+def test_stem_tail_is_bit_identical_to_batchnorm_relu_maxpool(pkg, shape):
+    """maxpool(relu(bn1(x))) as one node (p3d_stem_tail_fwd / bwd, depthnet.py:139-140) computes every value with the expressions and in the order of the
+    three-node path: output, input gradient, parameter gradients and running statistics are compared bit for bit (odd window rows / columns at the borders,
+    negative gamma, ties between equal maxima included)."""
+    ops = pkg.ops
+    n, c, h, w = shape
+    gen = torch.Generator(device='cuda').manual_seed(h * 7 + w)
+    x0 = torch.randn(n, c, h, w, device='cuda', generator=gen)
+    x0 = (x0 * 2).round() / 2                                 # values on a coarse grid: plenty of exact ties inside the pooling windows
+    dy = torch.randn(n, c, h // 2, w // 2, device='cuda', generator=gen)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(1)
+        bn = pkg.nn.BatchNorm2d(c).cuda().train()
+        pool = pkg.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        with torch.no_grad():
+            bn.weight.uniform_(-1.0, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        x = x0.clone().requires_grad_(True)
+        assert ops.stem_tail_usable(x, bn, pool)
+        y = ops.stem_tail(x, bn) if fused else pool(bn(x, relu=True))
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[fused] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone(),
+                      bn.num_batches_tracked.clone())
+    for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var', 'num_batches_tracked')):
+        assert torch.equal(a, b), name
