@@ -218,7 +218,7 @@ def _rebuild_stale_images(device):
     entry = _image_tables.get(ident)
     if entry is None:
         table = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).to(device)
-        blocks = max(1, min(256, (most // 48 + 255) // 256))          # 16-B chunk positions of the largest image / 256 threads, capped: blocks stride
+        blocks = max(1, min(1024, (most // 48 + 255) // 256))         # 16-B chunk positions of the largest image / 256 threads, capped (blocks stride; measured: 256 -> 195 us, 1024 -> 168, 4096 -> 202 per ResNet-50 rebuild)
         if len(_image_tables) > 16:
             _image_tables.clear()
         entry = _image_tables[ident] = (table, blocks)
