@@ -792,6 +792,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tapm_kernel(const float* __r
     for (int e = threadIdx.x; e < n; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
 }
 
+// Deep splits (more than 16 slabs) in ONE launch: 16 thread groups each sum every 16th slab of their outputs (slab g, g + 16, ...), group 0 then adds the 16 partial
+// sums in order -- the additions, and their order, of slab_fold_kernel (G = 16) followed by the plain reduce, without the pass that wrote the folded slabs back.
+// contiguous destination only (ldw == Ncols, woff == 0, total % 4 == 0, 16-B aligned); grid: blocks of 16 outputs (float4) each
+__global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __restrict__ slab, float* __restrict__ dw, size_t n4, int splits, int accumulate) {
+    __shared__ float4 part[16][16];
+    const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const float4* s4 = reinterpret_cast<const float4*>(slab);
+    float4* d4 = reinterpret_cast<float4*>(dw);
+    for (size_t base = (size_t)blockIdx.x * 16; base < n4; base += (size_t)gridDim.x * 16) {
+        const size_t i = base + j;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4 && g < splits) {
+            a = s4[(size_t)g * n4 + i];
+            for (int z = g + 16; z < splits; z += 16) { const float4 b = s4[(size_t)z * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        }
+        part[g][j] = a;
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            a = part[0][j];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) { const float4 b = part[q][j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (accumulate) { const float4 o = d4[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+            d4[i] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// the same for tap-major slabs: one block per (filter k, 16-channel chunk); thread (g, cl) sums slabs g, g + 16, ... of channel c0 + cl for every tap, group 0
+// combines, transposes (rs, c) -> (c, rs) through LDS and writes the 16 * RS contiguous floats of dw[k][c0 : c0 + 16][:][:]
+__global__ __launch_bounds__(256) void wgrad_reduce16_tapm_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int C, int RS, int splits, int ldw,
+                                                                  int woff, int accumulate) {
+    extern __shared__ float sm[];                        // part[16 groups][RS][16 channels], then tile[16 channels][RS]
+    float* tile = sm + 16 * RS * 16;
+    const int k = blockIdx.x, c0 = blockIdx.y * 16, g = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const size_t total = (size_t)M * RS * C;
+    for (int rs = 0; rs < RS; ++rs) {
+        const size_t src = (size_t)k * RS * C + (size_t)rs * C + c0 + cl;
+        float s = 0.f;
+        if (g < splits) {
+            s = slab[(size_t)g * total + src];
+            for (int z = g + 16; z < splits; z += 16) s += slab[(size_t)z * total + src];
+        }
+        sm[(g * RS + rs) * 16 + cl] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RS * 16; e += 256) {
+        const int rs = e >> 4, c = e & 15;
+        float s = sm[rs * 16 + c];
+        for (int q = 1; q < 16; ++q) s += sm[(q * RS + rs) * 16 + c];
+        tile[c * RS + rs] = s;
+    }
+    __syncthreads();
+    float* dst = dw + (size_t)k * ldw + woff + (size_t)c0 * RS;
+    for (int e = threadIdx.x; e < RS * 16; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
+}
+
 // db[k] = sum over n, hw of dy[n][k][hw] (* mask_out[n][hw] of a partial conv, mask_out == (mult > 0): partial_conv.py:48-51); one block per channel
 __global__ __launch_bounds__(256) void bgrad_kernel(const float* __restrict__ dy, const float* __restrict__ mult, float* __restrict__ db, int N, int K, int HW,
                                                     int accumulate) {
@@ -1032,6 +1089,20 @@ int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm,
     const int M = d->K, Ncols = d->C * d->R * d->S;
     const int ldw = d->c_total * d->R * d->S, woff = d->c_offset * d->R * d->S;
     if (nslab > 16) {
+        // one launch where the destination allows it (every weight of a ResNet): same additions in the same order as fold + reduce
+        const size_t tot = (size_t)M * Ncols;
+        if (tapm && d->R * d->S > 1 && d->C % 16 == 0) {
+            const int RS = d->R * d->S;
+            hipLaunchKernelGGL(wgrad_reduce16_tapm_kernel, dim3(d->K, d->C / 16), dim3(256), (size_t)(17 * RS * 16) * sizeof(float), st, (const float*)slabs, dw, M, d->C, RS,
+                               nslab, ldw, woff, d->accumulate);
+            return check_launch("conv2d_wgrad reduce16 tapm");
+        }
+        if (!(tapm && d->R * d->S > 1) && ldw == Ncols && woff == 0 && (tot & 3) == 0 && ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0) {
+            const size_t n4 = tot >> 2;
+            const int64_t nb = ceil_div((int64_t)n4, 16);
+            hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, st, (const float*)slabs, dw, n4, nslab, d->accumulate);
+            return check_launch("conv2d_wgrad reduce16");
+        }
         const size_t total = (size_t)M * Ncols;
         const int G = 16;
         const int64_t bx = ceil_div((int64_t)ceil_div((int64_t)total, 4), 256);
