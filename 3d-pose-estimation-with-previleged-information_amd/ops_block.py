@@ -158,7 +158,15 @@ def _owned(module, key, device):
     cache = module.__dict__.get('_owned_bufs')
     if cache is None:
         cache = module.__dict__['_owned_bufs'] = _Transient()
-    sets = cache.setdefault(key, [])
+    sets = cache.pop(key, None)
+    if sets is None:
+        if len(cache) >= PLAN_LIMIT:
+            for old in list(cache):
+                if not any(b.held for b in cache[old]):
+                    del cache[old]
+                    break
+        sets = []
+    cache[key] = sets
     for b in sets:
         if not b.held and b.device == device:
             break
@@ -258,6 +266,9 @@ def weight_images(conv):
 USE_WEIGHT_IMAGES = os.environ.get('P3D_WEIGHT_IMAGES', '1') != '0'
 
 
+PLAN_LIMIT = 3
+
+
 class _Transient(dict):
     """Per-module caches of plans and device buffers: never copied or pickled with the module (a deep copy starts with an empty cache)."""
 
@@ -273,9 +284,17 @@ def plan_for(block, x):
     if cache is None:
         cache = block.__dict__['_blk_plans'] = _Transient()
     key = (tuple(x.shape), ops.X3_EPOCH)
-    plan = cache.get(key)
+    plan = cache.pop(key, None)
     if plan is None:
-        plan = cache[key] = _Plan(block, x.shape)
+        # a plan owns device buffers: keep those of the PLAN_LIMIT most recently used input shapes (a training loop has one or two: the batch and the epoch's
+        # last, smaller one), drop the oldest idle one beyond that
+        if len(cache) >= PLAN_LIMIT:
+            for old in list(cache):
+                if not any(b.held for b in cache[old].sets):
+                    del cache[old]
+                    break
+        plan = _Plan(block, x.shape)
+    cache[key] = plan               # (re-inserted: the dict's order is the order of last use)
     return plan
 
 

@@ -335,3 +335,19 @@ def test_out_mask_bytes_equal_reading_the_output(pkg):
     assert torch.equal(res[True]['y'], res[False]['y']) and torch.equal(res[True]['dx'], res[False]['dx'])
     for n, g in res[True]['grads'].items():
         assert torch.equal(g, res[False]['grads'][n]), n
+
+
+def test_plans_of_old_input_shapes_are_dropped(pkg):
+    """A plan owns device buffers, so a block keeps the plans of its PLAN_LIMIT most recently used input shapes only (batch sizes that come and go must not
+    accumulate memory); a plan whose buffers are held by a live graph is never the one dropped."""
+    ob = pkg.ops_block
+    block = build(pkg, 'basic', 64, 64, 1, 1, False, seed=2)
+    held = block(torch.randn(7, 64, 16, 16, device='cuda').relu_().requires_grad_(True))          # its graph stays alive: the plan for batch 7 is in use
+    for n in (1, 2, 3, 4, 5):
+        x = torch.randn(n, 64, 16, 16, device='cuda').relu_().requires_grad_(True)
+        block(x).sum().backward()
+    plans = block.__dict__['_blk_plans']
+    shapes = [k[0][0] for k in plans]
+    assert len(plans) <= ob.PLAN_LIMIT + 1 and 7 in shapes and shapes[-1] == 5, shapes
+    held.sum().backward()                                                                          # still intact
+    torch.cuda.synchronize()
