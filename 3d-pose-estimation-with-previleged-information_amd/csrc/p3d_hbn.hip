@@ -65,11 +65,21 @@ __device__ __forceinline__ void hbn_sum_partials(const float* __restrict__ parti
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int blk = sl; blk < nblk; blk += 16) {
-            const float* q = partial + ((size_t)blk * G + (c >> 3)) * 16 + (c & 7);
-            a += q[0]; b += q[8];
+    if (c < C) {
+        // four rows per trip, their loads independent of each other (one row per trip left 32 dependent round trips in a launch that does nothing else)
+        const float* q0 = partial + (size_t)(c >> 3) * 16 + (c & 7);
+        const size_t row = (size_t)G * 16;
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int blk = sl;
+        for (; blk + 48 < nblk; blk += 64) {
+            const float* q = q0 + blk * row;
+            const float v0 = q[0], w0 = q[8], v1 = q[16 * row], w1 = q[16 * row + 8], v2 = q[32 * row], w2 = q[32 * row + 8], v3 = q[48 * row], w3 = q[48 * row + 8];
+            a += v0; b += w0; a1 += v1; b1 += w1; a2 += v2; b2 += w2; a3 += v3; b3 += w3;
         }
+        for (; blk < nblk; blk += 16) { const float* q = q0 + blk * row; a += q[0]; b += q[8]; }
+        a = (a + a1) + (a2 + a3);
+        b = (b + b1) + (b2 + b3);
+    }
     red[sl][cl][0] = a; red[sl][cl][1] = b;
     __syncthreads();
     s1 = 0.0; s2 = 0.0;
