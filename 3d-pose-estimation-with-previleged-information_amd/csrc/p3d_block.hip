@@ -54,11 +54,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __re
                                                               float* __restrict__ table) {
     const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl, FIN_LANES = blockDim.x / FIN_CH;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rl; r < rows; r += FIN_LANES) {
+    if (c < C) {
+        // two rows per trip with independent loads (a launch that does nothing else should not chain its round trips)
+        double u1 = 0.0, u2 = 0.0;
+        int r = rl;
+        for (; r + FIN_LANES < rows; r += 2 * FIN_LANES) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
+            const float2 w = *reinterpret_cast<const float2*>(partial + ((size_t)(r + FIN_LANES) * C + c) * 2);
+            s1 += v.x; s2 += v.y; u1 += w.x; u2 += w.y;
+        }
+        if (r < rows) {
             const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
             s1 += v.x; s2 += v.y;
         }
+        s1 += u1; s2 += u2;
+    }
     __shared__ double red[2][FIN_MAX_LANES][FIN_CH];
     red[0][rl][cl] = s1; red[1][rl][cl] = s2;
     __syncthreads();

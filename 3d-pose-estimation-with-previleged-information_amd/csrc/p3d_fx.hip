@@ -827,14 +827,30 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
         } else {
             // fused finalize: thread (cl, rl) sums rows rl, rl + 16, ... of channel cl in fp64, lane 0 of each channel adds the 16 lanes in order
             const int cl = t & 15, rl = t >> 4, c = cg * 16 + cl;
-            double s1 = 0.0, s2 = 0.0;
+            // (four rows per trip with independent loads: up to 32 dependent round trips otherwise, in the prologue of EVERY block of the pass)
+            double s1 = 0.0, s2 = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0, w1 = 0.0, w2 = 0.0;
+            int r = rl;
             if (fin.kind == 3) {
-                const double* pd = (const double*)fin.partial;
-                for (int r = rl; r < fin.rows; r += 16) { s1 += pd[((size_t)c * fin.rows + r) * 3]; s2 += pd[((size_t)c * fin.rows + r) * 3 + 1 + fin.which]; }
+                const double* pd = (const double*)fin.partial + (size_t)c * fin.rows * 3;
+                const int o = 1 + fin.which;
+                for (; r + 48 < fin.rows; r += 64) {
+                    const double a0 = pd[r * 3], b0 = pd[r * 3 + o], a1 = pd[(r + 16) * 3], b1 = pd[(r + 16) * 3 + o];
+                    const double a2 = pd[(r + 32) * 3], b2 = pd[(r + 32) * 3 + o], a3 = pd[(r + 48) * 3], b3 = pd[(r + 48) * 3 + o];
+                    s1 += a0; s2 += b0; u1 += a1; u2 += b1; v1 += a2; v2 += b2; w1 += a3; w2 += b3;
+                }
+                for (; r < fin.rows; r += 16) { s1 += pd[r * 3]; s2 += pd[r * 3 + o]; }
             } else {
-                const float* pf = (const float*)fin.partial;
-                for (int r = rl; r < fin.rows; r += 16) { const f32x2 v = *reinterpret_cast<const f32x2*>(pf + ((size_t)r * C + c) * 2); s1 += v[0]; s2 += v[1]; }
+                const float* pf = (const float*)fin.partial + (size_t)c * 2;
+                const size_t row = (size_t)C * 2;
+                for (; r + 48 < fin.rows; r += 64) {
+                    const f32x2 a0 = *reinterpret_cast<const f32x2*>(pf + r * row), a1 = *reinterpret_cast<const f32x2*>(pf + (r + 16) * row);
+                    const f32x2 a2 = *reinterpret_cast<const f32x2*>(pf + (r + 32) * row), a3 = *reinterpret_cast<const f32x2*>(pf + (r + 48) * row);
+                    s1 += a0[0]; s2 += a0[1]; u1 += a1[0]; u2 += a1[1]; v1 += a2[0]; v2 += a2[1]; w1 += a3[0]; w2 += a3[1];
+                }
+                for (; r < fin.rows; r += 16) { const f32x2 v = *reinterpret_cast<const f32x2*>(pf + r * row); s1 += v[0]; s2 += v[1]; }
             }
+            s1 = (s1 + u1) + (v1 + w1);
+            s2 = (s2 + u2) + (v2 + w2);
             fred[0][rl][cl] = s1; fred[1][rl][cl] = s2;
             __syncthreads();
             if (rl == 0) {
