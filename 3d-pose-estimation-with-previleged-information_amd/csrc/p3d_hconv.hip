@@ -365,8 +365,17 @@ __global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restr
     for (size_t base = (size_t)blockIdx.x * 32; base < per; base += (size_t)gridDim.x * 32) {
         const size_t i = base + el;
         float s = 0.f;
-        if (i < per)
-            for (int sp = sl; sp < nsplit; sp += 8) s += slab[sp * per + i];
+        if (i < per) {
+            // four slabs per trip, their loads independent (a serial sum leaves up to nsplit / 8 dependent round trips per thread)
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = sl;
+            for (; sp + 24 < nsplit; sp += 32) {
+                const float a0 = slab[sp * per + i], a1 = slab[(sp + 8) * per + i], a2 = slab[(sp + 16) * per + i], a3 = slab[(sp + 24) * per + i];
+                s += a0; s1 += a1; s2 += a2; s3 += a3;
+            }
+            for (; sp < nsplit; sp += 8) s += slab[sp * per + i];
+            s = (s + s1) + (s2 + s3);
+        }
         red[sl][el] = s;
         __syncthreads();
         if (sl == 0 && i < per) {
