@@ -99,16 +99,29 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const void* __res
     const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH, c = blockIdx.x * FIN_CH + cl, FIN_LANES = blockDim.x / FIN_CH;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
+        double u1 = 0.0, u2 = 0.0;            // (two rows per trip with independent loads, as in bn_finalize_fwd_kernel)
+        int r = rl;
         if constexpr (F64) {
-            const double* partial = (const double*)partial_;
-            for (int r = rl; r < rows; r += FIN_LANES) { s1 += partial[((size_t)c * rows + r) * 3]; s2 += partial[((size_t)c * rows + r) * 3 + 1 + which]; }
+            const double* partial = (const double*)partial_ + (size_t)c * rows * 3;
+            const int o = 1 + which;
+            for (; r + FIN_LANES < rows; r += 2 * FIN_LANES) {
+                const double a0 = partial[r * 3], b0 = partial[r * 3 + o], a1 = partial[(r + FIN_LANES) * 3], b1 = partial[(r + FIN_LANES) * 3 + o];
+                s1 += a0; s2 += b0; u1 += a1; u2 += b1;
+            }
+            if (r < rows) { s1 += partial[r * 3]; s2 += partial[r * 3 + o]; }
         } else {
             const float* partial = (const float*)partial_;
-            for (int r = rl; r < rows; r += FIN_LANES) {
+            for (; r + FIN_LANES < rows; r += 2 * FIN_LANES) {
+                const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
+                const float2 w = *reinterpret_cast<const float2*>(partial + ((size_t)(r + FIN_LANES) * C + c) * 2);
+                s1 += v.x; s2 += v.y; u1 += w.x; u2 += w.y;
+            }
+            if (r < rows) {
                 const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
                 s1 += v.x; s2 += v.y;
             }
         }
+        s1 += u1; s2 += u2;
     }
     __shared__ double red[2][FIN_MAX_LANES][FIN_CH];
     red[0][rl][cl] = s1; red[1][rl][cl] = s2;
