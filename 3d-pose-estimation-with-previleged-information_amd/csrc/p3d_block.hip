@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void block_open_bwd_kernel(const float* __rest
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
                 }
-                gv[i] = g;
+                if (gbuf) gv[i] = g;           // (null: a block with a downsample branch and mask bytes -- nobody reads g as a tensor, the image passes mask dout themselves)
             }
             float a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -457,7 +457,10 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
                       void* stream, void* side_stream) {
     if (int32_t e = check_block(b)) return e;
-    P3D_REQUIRE(io && io->x && io->out && io->dout && io->gbuf, "block_bwd: null tensor");
+    P3D_REQUIRE(io && io->x && io->out && io->dout, "block_bwd: null tensor");
+    // g = dout * [out > 0] as a tensor is only needed where it becomes dx (identity shortcut) or where forward left no mask bytes
+    const bool g_in_memory = !(b->relu_out && b->has_downsample && io->out_mask);
+    P3D_REQUIRE(!g_in_memory || !b->relu_out || io->gbuf, "block_bwd: null gradient buffer");
     size_t need = 0, need_side = 0;
     p3d_block_workspace_bytes(b, &need, &need_side);
     if (!workspace || workspace_bytes < need || !side_workspace || side_bytes < need_side) {
@@ -481,10 +484,12 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 
     // 1. open: g = dout * [out > 0]; channel sums of the closing BN (and of the downsample BN)
     const int split = close_split(dl->N, dl->K);
-    const float* g = b->relu_out ? io->gbuf : io->dout;
+    const float* g = (b->relu_out && g_in_memory) ? io->gbuf : io->dout;
+    const unsigned char* gmask = g_in_memory ? nullptr : io->out_mask;
     hipLaunchKernelGGL(block_open_bwd_kernel, dim3(dl->K, split), dim3(256), 0, st, io->dout, (const float*)io->out, (const float*)io->c[last],
                        (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
-                       b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, io->gbuf, (double*)partial, (const unsigned char*)io->out_mask, dl->N, dl->K,
+                       b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, g_in_memory ? io->gbuf : (float*)nullptr, (double*)partial,
+                       (const unsigned char*)io->out_mask, dl->N, dl->K,
                        dl->Ho * dl->Wo, b->relu_out);
     const double cnt_last = (double)dl->N * dl->Ho * dl->Wo;
     if (int32_t e = check_launch("block_bwd open")) return e;
@@ -495,13 +500,14 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     //    others), finalized in the image pass's own prologue when the partial rows are few, by a launch of their own otherwise.
     //    Streams: a weight gradient runs on the second stream behind an event of the launch stream; it reads dcimg[i] and aimg[i - 1] / x, none of which the
     //    launch stream writes again inside this call, so the launch stream never waits for the second one here.
-    auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt) -> int32_t {
+    auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt, const unsigned char* front_mask = nullptr) -> int32_t {
         const p3d_conv_desc* dc = &b->conv[slot];
         P3D_REQUIRE(io->dcimg[slot], "block_bwd: null gradient image %d", slot);
         if (kind == 3 || rows <= FX_FIN_MAX_ROWS) {
             FxFinalize fin{};
             fin.kind = kind; fin.partial = partial; fin.rows = rows; fin.which = which; fin.count = cnt; fin.gamma = io->gamma[slot];
             fin.dgamma = io->dgamma[slot]; fin.dbeta = io->dbeta[slot]; fin.accumulate = acc; fin.table = io->table[slot];
+            fin.gmask = front_mask;
             return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, &fin);
         }
         hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dc->K, FIN_CH)), dim3(fin_threads(rows)), 0, st, (const void*)partial, rows, dc->K, cnt, 0,
@@ -524,9 +530,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         return wgrad_finish(&dw_desc, (float*)side_workspace, splits, tapm, io->dw[slot], ss);
     };
     // the two maps fed by the opening pass's sums (its partial buffer is overwritten by the first data gradient below): closing BatchNorm, downsample BatchNorm
-    if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last)) return e;
+    if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask)) return e;
     if (b->has_downsample)
-        if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last)) return e;
+        if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last, gmask)) return e;
     hipEvent_t ready = two ? mark_position(st) : nullptr;           // d c_last (and the downsample branch's gradient image) are complete
     const hipEvent_t ready_ds = ready;
     for (int i = last; i >= 0; --i) {

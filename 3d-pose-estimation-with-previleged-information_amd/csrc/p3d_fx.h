@@ -120,6 +120,8 @@ struct FxFinalize {
     float* dbeta;
     int accumulate;         // kind 2 / 3: add to d gamma / d beta instead of overwriting
     float* table;           // the layer's [C][8] table: kind 1 writes {sc, sh, mean, invstd}; kind 2 / 3 read them
+    const unsigned char* gmask;   // kind 3, optional: x is the gradient in FRONT of a ReLU whose mask bytes these are (bit e of byte i: element 4 i + e passes); the pass
+                                  // applies the mask itself, so the masked gradient never has to exist in memory (p3d_block_io.out_mask)
 };
 constexpr int FX_FIN_MAX_ROWS = 512;
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);

@@ -903,6 +903,16 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
         v[j] = *reinterpret_cast<const f32x4*>(X + in0 + (size_t)j * HW);
         if constexpr (MODE == 2) c2[j] = *reinterpret_cast<const f32x4*>(X2 + in0 + (size_t)j * HW);
     }
+    if constexpr (MODE == 2) {
+        if (fin.gmask) {                 // x = the gradient in front of the block's closing ReLU: apply that ReLU's mask bytes here
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned m = fin.gmask[(in0 + (size_t)j * HW) >> 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j][e] = (m >> e) & 1u ? v[j][e] : 0.f;
+            }
+        }
+    }
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

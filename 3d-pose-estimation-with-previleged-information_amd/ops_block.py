@@ -131,7 +131,8 @@ class _Buffers:
             f32 = dict(dtype=torch.float32, device=self.device)
             dcimg = {slot: torch.empty(6 * self.c[slot].numel(), dtype=torch.uint8, device=self.device) for slot in plan.slots}    # image of d c_slot: what conv slot's wgrad and dgrad read
             da = {slot: torch.empty(plan.shapes[slot], **f32) for slot in plan.slots if slot < plan.desc.nconv - 1}
-            gbuf = torch.empty(plan.out_shape, **f32) if plan.desc.has_downsample else None      # (identity shortcut: the gradient buffer IS dx, a fresh tensor)
+            # g = dout * [out > 0]: with an identity shortcut it IS dx (a fresh tensor per call); with a downsample branch and mask bytes nobody needs it as a tensor
+            gbuf = torch.empty(plan.out_shape, **f32) if (plan.desc.has_downsample and self.mask is None) else None
             self.bwd = (dcimg, da, gbuf)
         return self.bwd
 
@@ -384,9 +385,10 @@ class ResidualBlockFn(torch.autograd.Function):
         for (slot, kind, _), g in zip(params, grads):
             getattr(io, kind)[slot] = g.data_ptr()
         dcimg, da, gbuf = bufs.backward_scratch(plan)
-        if gbuf is None:
+        if gbuf is None and not (d.has_downsample and bufs.mask is not None):
             gbuf = torch.empty_like(out)
-        io.gbuf = gbuf.data_ptr()
+        if gbuf is not None:
+            io.gbuf = gbuf.data_ptr()
         for slot, _, _ in layers:
             io.dcimg[slot] = dcimg[slot].data_ptr()
             if slot in da:

@@ -154,7 +154,7 @@ typedef struct p3d_block_io {
     float* running_var[4];
     /* backward only */
     const float* dout;
-    float* gbuf;
+    float* gbuf;                /* may be NULL when the block has a downsample branch and out_mask is given (g is then never needed as a tensor) */
     void* dcimg[4];             /* scratch, one per convolution (slot 3: the downsample branch): image of d c_i, the gradient w.r.t. conv i's raw output
                                    (p3d_fx_act_image_bytes(N, K_i, Ho_i * Wo_i) bytes); read by conv i's weight gradient and data gradient */
     float* da[4];
