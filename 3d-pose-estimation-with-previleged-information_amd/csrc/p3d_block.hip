@@ -458,8 +458,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                       void* stream, void* side_stream) {
     if (int32_t e = check_block(b)) return e;
     P3D_REQUIRE(io && io->x && io->out && io->dout, "block_bwd: null tensor");
-    // g = dout * [out > 0] as a tensor is only needed where it becomes dx (identity shortcut) or where forward left no mask bytes
-    const bool g_in_memory = !(b->relu_out && b->has_downsample && io->out_mask);
+    // g = dout * [out > 0] never exists as a tensor when forward left mask bytes: the two opening image passes mask dout themselves, and with an identity
+    // shortcut the first convolution's data gradient adds the masked dout in its epilogue (dx = dgrad + dout * mask) instead of accumulating into a copy of g
+    const bool g_in_memory = !(b->relu_out && io->out_mask && (b->has_downsample || !b->need_dx || fx_dgrad_accumulates_from_source(&b->conv[0])));
     P3D_REQUIRE(!g_in_memory || !b->relu_out || io->gbuf, "block_bwd: null gradient buffer");
     size_t need = 0, need_side = 0;
     p3d_block_workspace_bytes(b, &need, &need_side);
@@ -573,7 +574,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");
+                P3D_REQUIRE(io->gbuf, "block_bwd: null gradient buffer (dx of an identity shortcut)");
                 dx = io->gbuf; dd.accumulate = 1;
+                if (!g_in_memory) { f.acc_src = io->dout; f.acc_mask = io->out_mask; }      // gbuf is written here for the first time
             }
             ProfScope ps(1, d, st);
             fx_count(1, d);

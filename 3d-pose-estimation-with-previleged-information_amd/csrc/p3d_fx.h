@@ -20,6 +20,8 @@ struct FxConvParams {
     float* partial;         // EPI 1 / 2: [rows][M][2] partial sums
     const float* pmask;     // PRO 4 (partial convolution): per-pixel factor of the activation operand, [N][1][Hi][Wi]
     const float* emask;     // EPI 4: per-pixel factor of the result, [N][1][YH][YW]
+    const float* acc_src;   // dense unsplit launches with `accumulate`: what is added to the result instead of Y's own content (laid out like Y), after
+    const unsigned char* acc_mask;   //   masking by these bytes when given (bit e of byte i: element 4 i + e passes): Y = result + src * mask, Y itself is only written
     size_t slab_stride;     // elements between two split-K slabs
     int N, Cred, Hi, Wi;
     int M, OH, OW, NP;      // the GEMM's pixel grid (for strided dgrad: one parity class of the input) and its size N * OH * OW
@@ -59,6 +61,8 @@ struct FxFuse {
     const float* pmask;     // partial convolution (partial_conv.py:32-57): factor of the activation operand per pixel (FWD: mask_in, DGRAD: mult; WGRAD: mult for dy)
     const float* emask;     //   and of the result per pixel (FWD: mult, DGRAD: mask_in; WGRAD: mask_in for x).  Both or neither.
     const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: built into the workspace by the call
+    const float* acc_src;   // DGRAD with d->accumulate, stride 1, unsplit (fx_dgrad_accumulates_from_source): dx = dgrad + acc_src * [acc_mask bit] instead of dx += dgrad
+    const unsigned char* acc_mask;
 };
 constexpr int FX_TAB = 8;   // floats per channel of a table
 
@@ -81,6 +85,7 @@ bool fx_fwd_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d);
+bool fx_dgrad_accumulates_from_source(const p3d_conv_desc* d);      // stride 1 and no split-K: FxFuse::acc_src is honoured
 bool fx_fwd_masked_applies(const p3d_conv_desc* d);          // partial convolutions: the masked instances exist for unsplit launches without bias
 bool fx_dgrad_masked_applies(const p3d_conv_desc* d);
 bool fx_wgrad_masked_applies(const p3d_conv_desc* d);

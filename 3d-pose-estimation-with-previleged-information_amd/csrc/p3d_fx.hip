@@ -467,8 +467,20 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
                 if (m >= p.M || c4 >= p.NP) continue;
                 const int n = c4 / OHW, rem = c4 - n * OHW;
                 f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * EROW + q * 16);
-                f32x4* dst = reinterpret_cast<f32x4*>(yout + ((size_t)n * p.M + m) * OHW + rem);
-                if (accum) { const f32x4 o4 = *dst; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                const size_t at = ((size_t)n * p.M + m) * OHW + rem;
+                f32x4* dst = reinterpret_cast<f32x4*>(yout + at);
+                if (accum) {
+                    f32x4 o4;
+                    if (p.acc_src) {              // the summand comes from another tensor (through a ReLU's mask bytes): Y is written, never read
+                        o4 = *reinterpret_cast<const f32x4*>(p.acc_src + at);
+                        if (p.acc_mask) {
+                            const unsigned mk = p.acc_mask[at >> 2];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[e] = (mk >> e) & 1u ? o4[e] : 0.f;
+                        }
+                    } else o4 = *dst;
+                    v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3];
+                }
                 *dst = v;
             }
         }
@@ -1200,6 +1212,9 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     }
     const size_t need = fx_dgrad_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    if (fuse && fuse->acc_src && !(d->accumulate && fx_dgrad_accumulates_from_source(d))) {
+        set_error("fx_conv_dgrad: an accumulation source needs accumulate = 1, stride 1 and an unsplit launch"); return P3D_EINVAL;
+    }
     FxConvParams p{};
     p.X = dy; p.Y = dx;
     if (img) { p.Ximg = (const unsigned char*)fuse->act_img; p.plane_bytes = (size_t)d->N * d->K * d->Ho * d->Wo * 2; }
@@ -1233,6 +1248,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
             fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
                              d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
         } else {
+            if (fuse && fuse->acc_src && d->accumulate) { p.acc_src = fuse->acc_src; p.acc_mask = fuse->acc_mask; }
             fx_launch_conv(p, img, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         }
         return check_launch("fx_conv_dgrad");
@@ -1262,6 +1278,8 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
 
 // input pixels of a strided 1x1 that no tap reaches: fx_conv_dgrad leaves them untouched, so a caller that does not accumulate zero-fills dx first
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d) { return d->stride > 1 && d->R == 1; }
+// the dense unsplit launch can take its summand from another tensor (FxFuse::acc_src / acc_mask)
+bool fx_dgrad_accumulates_from_source(const p3d_conv_desc* d) { return d->stride == 1 && fx_dgrad_split(d).splits == 1 && (d->H * d->W) % 4 == 0; }
 
 // How many slabs (splits of the pixel reduction) a weight gradient is cut into.  Measured on MI355X over the ResNet layer classes at batch 64 with
 // image operands (tools/split_sweep.py, profiles/r03_split_sweep.txt): the best block count depends on the tile count more than on anything else -- all
