@@ -314,19 +314,24 @@ def test_block_buffers_two_executions_in_flight_and_deep_copies(pkg):
     assert torch.equal(y.detach(), alone[0][0]) and torch.equal(x.grad, alone[0][1])
 
 
-def test_out_mask_bytes_equal_reading_the_output(pkg):
-    """p3d_block_io.out_mask is optional: with the mask bytes forward leaves, and with NULL (backward reads `out`), every result is bit-identical."""
+@pytest.mark.parametrize('geom', [('bottleneck', 256, 128, 2, True, (4, 256, 32, 32), (4, 512, 16, 16)),      # downsample branch: g is never written at all
+                                  ('bottleneck', 512, 128, 1, False, (4, 512, 16, 16), (4, 512, 16, 16)),     # identity: dx = dgrad + dout * mask in the dgrad epilogue
+                                  ('basic', 128, 128, 1, False, (4, 128, 16, 16), (4, 128, 16, 16))], ids=['downsample', 'identity', 'basic_identity'])
+def test_out_mask_bytes_equal_reading_the_output(pkg, geom):
+    """p3d_block_io.out_mask is optional: with the mask bytes forward leaves (the masked upstream gradient then never exists as a tensor), and with NULL (backward
+    reads `out` and writes g), every result is bit-identical."""
     ob = pkg.ops_block
+    kind, inpl, planes, stride, with_ds, xs, ys = geom
     gen = torch.Generator(device='cuda').manual_seed(3)
-    x0 = torch.randn(4, 256, 32, 32, device='cuda', generator=gen).relu_()
-    dy = torch.randn(4, 512, 16, 16, device='cuda', generator=gen)
+    x0 = torch.randn(*xs, device='cuda', generator=gen).relu_()
+    dy = torch.randn(*ys, device='cuda', generator=gen)
     res = {}
     before = ob.USE_OUT_MASK
     try:
         for use in (True, False):
             ob.USE_OUT_MASK = use
             torch.manual_seed(77)                                                  # (build() seeds after it has made the downsample pair)
-            block = build(pkg, 'bottleneck', 256, 128, 2, 1, True, seed=9)         # (a fresh module: buffer sets are created per plan)
+            block = build(pkg, kind, inpl, planes, stride, 1, with_ds, seed=9)     # (a fresh module: buffer sets are created per plan)
             res[use] = run(pkg, block, x0, dy, fused=True)
             bufs = next(iter(block.__dict__['_blk_plans'].values())).sets[0]
             assert (bufs.mask is not None) == use
