@@ -531,9 +531,19 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         return wgrad_finish(&dw_desc, (float*)side_workspace, splits, tapm, io->dw[slot], ss);
     };
     // the two maps fed by the opening pass's sums (its partial buffer is overwritten by the first data gradient below): closing BatchNorm, downsample BatchNorm
-    if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask)) return e;
-    if (b->has_downsample)
-        if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last, gmask)) return e;
+    if (b->has_downsample && fx_pair_map_enabled()) {
+        // both images in one pass: g (dout and the mask bytes) is read once
+        P3D_REQUIRE(io->dcimg[last] && io->dcimg[3], "block_bwd: null gradient image");
+        FxFinalize fa{}, fb{};
+        fa.kind = 3; fa.partial = partial; fa.rows = split; fa.which = 0; fa.count = cnt_last; fa.gamma = io->gamma[last]; fa.dgamma = io->dgamma[last];
+        fa.dbeta = io->dbeta[last]; fa.accumulate = acc; fa.table = io->table[last];
+        fb = fa; fb.which = 1; fb.gamma = io->gamma[3]; fb.dgamma = io->dgamma[3]; fb.dbeta = io->dbeta[3]; fb.table = io->table[3];
+        if (int32_t e = fx_act_image_pair(g, gmask, io->c[last], io->c[3], io->dcimg[last], io->dcimg[3], &fa, &fb, dl->N, dl->K, dl->Ho * dl->Wo, st)) return e;
+    } else {
+        if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask)) return e;
+        if (b->has_downsample)
+            if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last, gmask)) return e;
+    }
     hipEvent_t ready = two ? mark_position(st) : nullptr;           // d c_last (and the downsample branch's gradient image) are complete
     const hipEvent_t ready_ds = ready;
     for (int i = last; i >= 0; --i) {

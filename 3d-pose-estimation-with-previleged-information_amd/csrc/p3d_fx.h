@@ -130,6 +130,9 @@ struct FxFinalize {
 };
 constexpr int FX_FIN_MAX_ROWS = 512;
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);
+bool fx_pair_map_enabled();
+int32_t fx_act_image_pair(const float* x, const unsigned char* gmask, const float* c_a, const float* c_b, void* img_a, void* img_b, const FxFinalize* fa, const FxFinalize* fb,
+                          int N, int C, int HW, hipStream_t st);
 int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
                      const FxFinalize* fin = nullptr);
 

@@ -956,6 +956,114 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
     }
 }
 
+// The two gradient images a block with a downsample branch opens its backward pass with -- d c_last and d c_ds, both = (BatchNorm-backward map)(g, c), g the block's
+// upstream gradient -- in ONE pass: g (and the closing ReLU's mask bytes) are read once instead of twice.  MODE 2 with kind-3 finalize on both outputs (the fp64
+// partials [C][rows][3] of block_open_bwd: sum g, sum g (c_last - mean), sum g (c_ds - mean_ds)); every value by the expressions, and the partial rows in the order, of
+// fx_act_image_kernel<2>, so the images are bit-identical to two separate passes (p3d_fx_tune(3, 0) switches back: tests/test_block_gpu.py).
+struct FxPairSide { const float* c; unsigned char* img; const float* gamma; float* dgamma; float* dbeta; const float* table; };
+__global__ __launch_bounds__(256) void fx_act_image_pair_kernel(const float* __restrict__ X, const unsigned char* __restrict__ gmask, const FxPairSide a, const FxPairSide b,
+                                                                const double* __restrict__ partial, int rows, double count, int accumulate, size_t plane_bytes,
+                                                                int N, int C, int HW) {
+    __shared__ float cst[2][16][4];          // per side and channel: A, B, K
+    __shared__ double fred[3][16][16];
+    const int cg = blockIdx.y, t = threadIdx.x;
+    {
+        const int cl = t & 15, rl = t >> 4, c = cg * 16 + cl;
+        const double* pd = partial + (size_t)c * rows * 3;
+        double s[3] = {0.0, 0.0, 0.0}, u[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 0.0}, w[3] = {0.0, 0.0, 0.0};
+        int r = rl;
+        for (; r + 48 < rows; r += 64) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double a0 = pd[r * 3 + k], a1 = pd[(r + 16) * 3 + k], a2 = pd[(r + 32) * 3 + k], a3 = pd[(r + 48) * 3 + k];
+                s[k] += a0; u[k] += a1; v[k] += a2; w[k] += a3;
+            }
+        }
+        for (; r < rows; r += 16) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += pd[r * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fred[k][rl][cl] = (s[k] + u[k]) + (v[k] + w[k]);
+        __syncthreads();
+        if (rl == 0) {
+            double tot[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot[0] += fred[0][i][cl]; tot[1] += fred[1][i][cl]; tot[2] += fred[2][i][cl]; }
+            const bool owner = blockIdx.x == 0;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const FxPairSide& q = side == 0 ? a : b;
+                const float* tt = q.table + (size_t)c * FX_TAB;
+                const float mean = tt[2], is = tt[3];
+                const double s1 = tot[0], dg = (double)is * tot[1 + side];
+                if (owner) {
+                    q.dbeta[c] = accumulate ? q.dbeta[c] + (float)s1 : (float)s1;
+                    q.dgamma[c] = accumulate ? q.dgamma[c] + (float)dg : (float)dg;
+                }
+                const float m1 = (float)(s1 / count), m2 = (float)(dg / count);
+                const float A = q.gamma[c] * is;
+                cst[side][cl][0] = A; cst[side][cl][1] = -A * is * m2; cst[side][cl][2] = A * (mean * is * m2 - m1);
+            }
+        }
+        __syncthreads();
+    }
+    const int ih = t & 1;
+    const int q4 = HW >> 2;
+    const long long quad = ((long long)blockIdx.x * 256 + t) >> 1;
+    if (quad >= (long long)N * q4) return;
+    const int n = (int)(quad / q4), pq = (int)(quad - (long long)n * q4);
+    const size_t in0 = ((size_t)n * C + cg * 16 + 8 * ih) * HW + 4 * pq;
+    f32x4 g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const f32x4*>(X + in0 + (size_t)j * HW);
+    if (gmask) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned m = gmask[(in0 + (size_t)j * HW) >> 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[j][e] = (m >> e) & 1u ? g[j][e] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const FxPairSide& q = side == 0 ? a : b;
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 c2 = *reinterpret_cast<const f32x4*>(q.c + in0 + (size_t)j * HW);
+            const float A = cst[side][8 * ih + j][0], B = cst[side][8 * ih + j][1], K = cst[side][8 * ih + j][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = fmaf(A, g[j][e], fmaf(B, c2[e], K));
+        }
+        unsigned char* dst = q.img + (((size_t)n * (C >> 4) + cg) * HW + 4 * pq) * 32 + 16 * ih;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned hp[4], mp[4], lp[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fx_split2(v[2 * jj][e], v[2 * jj + 1][e], hp[jj], mp[jj], lp[jj]);
+            *reinterpret_cast<i32x4*>(dst + 32 * e) = i32x4{(int)hp[0], (int)hp[1], (int)hp[2], (int)hp[3]};
+            *reinterpret_cast<i32x4*>(dst + plane_bytes + 32 * e) = i32x4{(int)mp[0], (int)mp[1], (int)mp[2], (int)mp[3]};
+            *reinterpret_cast<i32x4*>(dst + 2 * plane_bytes + 32 * e) = i32x4{(int)lp[0], (int)lp[1], (int)lp[2], (int)lp[3]};
+        }
+    }
+}
+
+static int g_pair_map = 1;
+bool fx_pair_map_enabled() { return g_pair_map != 0; }
+int32_t fx_act_image_pair(const float* x, const unsigned char* gmask, const float* c_a, const float* c_b, void* img_a, void* img_b, const FxFinalize* fa, const FxFinalize* fb,
+                          int N, int C, int HW, hipStream_t st) {
+    if (!x || !c_a || !c_b || !img_a || !img_b || !fa || !fb || fa->kind != 3 || fb->kind != 3 || fa->partial != fb->partial || fa->rows != fb->rows || fa->which != 0 ||
+        fb->which != 1 || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3)) {
+        set_error("fx_act_image_pair: bad argument"); return P3D_EINVAL;
+    }
+    const FxPairSide a{c_a, (unsigned char*)img_a, fa->gamma, fa->dgamma, fa->dbeta, fa->table}, b{c_b, (unsigned char*)img_b, fb->gamma, fb->dgamma, fb->dbeta, fb->table};
+    const dim3 grid((unsigned)ceil_div((int64_t)N * (HW >> 2) * 2, 256), (unsigned)(C >> 4));
+    hipLaunchKernelGGL(fx_act_image_pair_kernel, grid, dim3(256), 0, st, x, gmask, a, b, (const double*)fa->partial, fa->rows, fa->count, fa->accumulate,
+                       (size_t)N * C * HW * 2, N, C, HW);
+    return check_launch("fx_act_image_pair");
+}
+
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW) { return (size_t)(3 * N * C * HW * 2); }
 
 int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
@@ -1022,7 +1130,10 @@ bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
 
 // tuning aid (p3d_fx_tune): forced split counts, 0 = the built-in plan
 static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0;
-void fx_tune(int what, int value) { (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value; }
+void fx_tune(int what, int value) {
+    if (what == 3) { g_pair_map = value; return; }      // 0: the two opening image passes of a downsample block as two launches (A/B, tests)
+    (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value;
+}
 
 struct FxSplit { int splits, kchunk; };
 static FxSplit fx_plan_split(int64_t tiles, int nk) {

@@ -356,3 +356,24 @@ def test_plans_of_old_input_shapes_are_dropped(pkg):
     assert len(plans) <= ob.PLAN_LIMIT + 1 and 7 in shapes and shapes[-1] == 5, shapes
     held.sum().backward()                                                                          # still intact
     torch.cuda.synchronize()
+
+
+def test_pair_image_pass_equals_two_passes(pkg):
+    """A block with a downsample branch writes its two opening gradient images (closing BatchNorm, downsample BatchNorm) in one pass that reads the upstream gradient
+    once (fx_act_image_pair); p3d_fx_tune(3, 0) switches back to two passes: every result is bit-identical."""
+    L = pkg._lib.lib()
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    x0 = torch.randn(4, 128, 32, 32, device='cuda', generator=gen).relu_()
+    dy = torch.randn(4, 512, 32, 32, device='cuda', generator=gen)
+    res = {}
+    try:
+        for pair in (1, 0):
+            L.p3d_fx_tune(3, pair)
+            torch.manual_seed(78)
+            block = build(pkg, 'bottleneck', 128, 128, 1, 1, True, seed=4)
+            res[pair] = run(pkg, block, x0, dy, fused=True)
+    finally:
+        L.p3d_fx_tune(3, 1)
+    assert torch.equal(res[1]['y'], res[0]['y']) and torch.equal(res[1]['dx'], res[0]['dx'])
+    for n, g in res[1]['grads'].items():
+        assert torch.equal(g, res[0]['grads'][n]), n
