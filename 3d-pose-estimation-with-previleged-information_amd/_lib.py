@@ -98,6 +98,8 @@ SIGNATURES = {
     'p3d_warp_crops': (_i32, [_ptr, _i32, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_stream_create': (_i32, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
     'p3d_stream_create_beside': (_i32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_i32)]),
+    'p3d_stream_create_cumask': (_i32, [ctypes.POINTER(ctypes.c_uint32), _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    'p3d_probe_hw_ids': (_i32, [ctypes.c_void_p, ctypes.c_void_p, _i32, _i32]),
     'p3d_stream_destroy': (_i32, [ctypes.c_void_p]),
     'p3d_x3_enable': (_i32, [_i32]),
     'p3d_fx_tune': (None, [_i32, _i32]),

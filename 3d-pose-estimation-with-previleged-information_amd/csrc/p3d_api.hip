@@ -73,5 +73,33 @@ int32_t p3d_stream_create_beside(void* main_stream, void** stream, int32_t* over
     if (overlaps) *overlaps = ok;
     return P3D_OK;
 }
+// A stream whose kernels may only run on the compute units whose bit is set in `mask` (bit i of word i / 32; 256 CUs = 8 words on MI355X).  A CU mask is a property
+// of the hardware queue, so such a stream has a queue of its own.  Used to give the weight-gradient stream a fixed share of the chip (ops._side_stream,
+// P3D_SIDE_CUS) so that the launch stream's short memory-bound passes always find free CUs instead of waiting for long weight-gradient blocks to retire.
+int32_t p3d_stream_create_cumask(const uint32_t* mask, int32_t words, void** stream) {
+    using namespace p3d;
+    P3D_REQUIRE(stream != nullptr && mask != nullptr && words > 0, "stream_create_cumask: bad argument");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) { set_error("stream_create_cumask: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e)); return P3D_ELAUNCH; }
+    *stream = s;
+    return P3D_OK;
+}
+// Where do the blocks of a launch on `stream` run?  out[b] = (XCC_ID << 16) | (HW_ID & 0xffff) of block b's wave: HW_ID holds the CU (bits 11:8), shader array
+// (12) and shader engine (15:13) inside the XCC.  Every block spins `spin_us` so that the launch spreads over all the CUs the stream may use.
+__global__ void hw_id_kernel(int32_t* out, long long ticks) {
+    const long long t0 = wall_clock64();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(((xcc & 0xf) << 16) | (hw & 0xffff));
+    while (wall_clock64() - t0 < ticks) {}
+}
+int32_t p3d_probe_hw_ids(void* stream, int32_t* out_device, int32_t nblocks, int32_t spin_us) {
+    using namespace p3d;
+    P3D_REQUIRE(out_device != nullptr && nblocks > 0, "probe_hw_ids: bad argument");
+    int rate_khz = 100000;
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0);
+    hipLaunchKernelGGL(hw_id_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, out_device, (long long)rate_khz * spin_us / 1000);
+    return hipGetLastError() == hipSuccess ? P3D_OK : P3D_ELAUNCH;
+}
 int32_t p3d_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? P3D_OK : P3D_ELAUNCH; }
 }

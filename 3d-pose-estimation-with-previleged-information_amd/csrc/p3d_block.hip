@@ -15,6 +15,7 @@
 #include "p3d_common.h"
 #include "p3d_fx.h"
 #include <vector>
+#include <mutex>
 
 namespace p3d {
 
@@ -297,9 +298,12 @@ static int close_split(int N, int C) {
 }
 
 // ---- events for the second stream -------------------------------------------------------------------------------------------------------
+// (library-global pools are guarded: two host threads may drive two streams through the executor at once -- "thread-safe for distinct streams")
+static std::mutex g_events_mu;
 static std::vector<hipEvent_t> g_events;
 static size_t g_event_next = 0;
 static hipEvent_t next_event() {
+    std::lock_guard<std::mutex> lock(g_events_mu);
     if (g_events.size() < 128) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -320,13 +324,20 @@ static hipEvent_t mark_position(hipStream_t signaller) {
 
 // ---- conv launch profile (bench.py's roofline brackets): HIP events around every conv call of the executor, on the stream it runs on ----------
 struct ProfRec { int kind; double flops; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
 ProfScope::ProfScope(int kind_, const p3d_conv_desc* d, hipStream_t st_) : st(st_), kind(kind_) {
     flops = 2.0 * d->N * d->K * d->Ho * d->Wo * (double)d->C * d->R * d->S;
     if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
 }
-ProfScope::~ProfScope() { if (a && b) { (void)hipEventRecord(b, st); g_prof.push_back({kind, flops, a, b}); } }
+ProfScope::~ProfScope() {
+    if (a && b) {
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        g_prof.push_back({kind, flops, a, b});
+    }
+}
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -853,7 +864,9 @@ int32_t p3d_profile_enable(int32_t on) {
 // Synchronises, sums the bracketed time per kind (0 forward, 1 data gradient, 2 weight gradient) and clears the records.
 int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind) {
     for (int k = 0; k < 3; ++k) { if (ms_by_kind) ms_by_kind[k] = 0; if (flops_by_kind) flops_by_kind[k] = 0; if (launches_by_kind) launches_by_kind[k] = 0; }
-    for (ProfRec& r : g_prof) {
+    std::vector<ProfRec> recs;
+    { std::lock_guard<std::mutex> lock(g_prof_mu); recs.swap(g_prof); }
+    for (ProfRec& r : recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             if (ms_by_kind) ms_by_kind[r.kind] += ms;
@@ -862,7 +875,6 @@ int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* 
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
-    g_prof.clear();
     return P3D_OK;
 }
 

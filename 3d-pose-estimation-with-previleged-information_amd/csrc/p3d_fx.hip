@@ -23,6 +23,7 @@
 // channel -- bias, the BatchNorm batch statistics of the result (EPI 1), the sums of the BatchNorm backward (EPI 2) -- is per lane, i.e. plain register
 // adds followed by one cross-lane step, not a 32-lane reduction per row.
 #include <type_traits>
+#include <mutex>
 #include "p3d_common.h"
 #include "p3d_fx.h"
 
@@ -94,6 +95,9 @@ __device__ __forceinline__ int fx_live_subtiles(int first, int limit) {
 // address is a wave-uniform scalar offset.  So a K step's fetch is loads only: no branches, no per-step address arithmetic.
 constexpr int FX_OOB = (int)0x80000000;
 // tuning ablation (wrong results, timing only): P3D_FX_ABL_NOLOAD fetches every K step from the first step's addresses (cache-hot operands)
+#if (defined(P3D_FX_ABL_NOLOAD) || defined(P3D_FX_ABL_NOREAD) || defined(P3D_FX_ABL_NOSTAGE) || defined(P3D_FX_ABL_NOBAR)) && !defined(P3D_TIMING_ONLY_BUILD)
+#error "P3D_FX_ABL_* builds compute wrong results: define P3D_TIMING_ONLY_BUILD as well (tools/ablate.sh does) and never ship the library"
+#endif
 #ifdef P3D_FX_ABL_NOLOAD
 #define FX_SO(x) 0
 #else
@@ -496,6 +500,306 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             }
             __syncthreads();
             if (t < 128 && m0 + t < p.M) {
+                float* dst = p.partial + ((size_t)tile_n * p.M + m0 + t) * 2;
+                dst[0] = red[0][0][t] + red[1][0][t];
+                dst[1] = red[0][1][t] + red[1][1][t];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// FWD / DGRAD on v_mfma_f32_16x16x32_bf16 ("fx16"): image-fed launches only (AMODE 1, PRO 0).
+// The instruction reduces over 32 k; a K step here is still 16 channels, and the two halves of the instruction's k range carry two DIFFERENT piece products of the
+// same 16 channels: lanes 0-31 hold piece X of the pixel operand against piece X' of the channel operand, lanes 32-63 piece Y against Y', so that one instruction
+// adds P_X C_X' + P_Y C_Y' into the accumulator.  The six products of a step are three such pairs, smallest first:
+//     (P_hi | P_lo) x (C_lo | C_hi)      (P_hi | P_mid) x (C_mid | C_mid)      (P_hi | P_mid) x (C_hi | C_hi)
+// = 3 x 16 instructions of 16 passes per wave and step instead of 6 x 4 of 32 passes: the same matrix-pipe cycles, 20 fragment reads per wave instead of 12, and a
+// shape on which the chip holds a higher clock (MI355X_MICROARCH.md, DVFS item 7).  16 x 16 sub-tiles also make the channel tile a template parameter: BM = 128
+// (wave 64 channels x 64 pixels) or 96 (wave 48 x 64: the 272-channel regressor is 96 + 96 + 80 instead of 128 + 128 + 16).
+// LDS images: "rc" rows of 32 B (row = pixel or channel, 16 k), NOT swizzled: a 16-lane group of the fragment read takes rows r .. r+3 / r+12 .. r+15 of one half
+// and rows r+4 .. r+11 of the other, which are 16 different bank quads as they lie.  The weight image keeps the swizzle of fx_rc_off; the staging copy undoes it
+// by fetching, for LDS position 16 t, the chunk that belongs there.
+// In the accumulator a lane is output channel (lane & 15) of a 16-channel group and holds four consecutive pixels 4 (lane >> 4) .. + 3 of a 16-pixel group.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+template <int BM, int EPI>
+__global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p) {
+    static_assert(BM == 128 || BM == 96 || BM == 64, "channel tile");
+    constexpr int GA = 4, GB = BM / 32;                 // 16-pixel / 16-channel groups of a wave (2 x 2 waves; a wave: 64 pixels x BM / 2 channels)
+    constexpr int WCH = BM / 2;
+    constexpr int PIECE_P = 128 * 32, PIECE_C = BM * 32;
+    constexpr int BUFB = 3 * PIECE_P + 3 * PIECE_C, CH0 = 3 * PIECE_P;
+    constexpr int LDSB = 2 * BUFB > 43008 ? 2 * BUFB : 43008;        // after the K loop: the result tile on its way out (33.8 KB) and the per-channel sums behind it
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+    float (*const red)[2][128] = reinterpret_cast<float (*)[2][128]>(lds + 40960);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * FX_BN;
+    const int OHW = p.OH * p.OW;
+    const int HWi = p.Hi * p.Wi;
+    const int nfirst = n0 / OHW;
+    const int csteps = p.Cred / FX_BK;
+    const int tiles128 = (p.M + 127) >> 7;             // row tiles of the weight image
+    int nk = p.ntap * csteps, kt0 = 0;
+    if (p.kchunk > 0) {
+        kt0 = blockIdx.y * p.kchunk;
+        nk = min(nk - kt0, p.kchunk);
+    }
+    int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
+
+    // weight operand: chunk id (piece, row of the tile, half) -> where it lies in the weight image (per 128-row tile and K step: 12 KB, fx_rc_off inside a piece)
+    const i32x4 rW = fx_rsrc(p.Wimg, (size_t)p.R * p.S * tiles128 * csteps * (3 * FX_PIECE));
+    int w_voff[3], w_lds[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int id = t + 256 * j, pc = id / (2 * BM), i = id - pc * (2 * BM), row = i >> 1, half = i & 1;
+        const int grow = m0 + row, tl = grow >> 7;
+        const bool ok = pc < 3 && tl < tiles128;
+        w_voff[j] = ok ? tl * csteps * (3 * FX_PIECE) + pc * FX_PIECE + fx_rc_off(grow & 127, half) : FX_OOB;
+        w_lds[j] = CH0 + (pc < 3 ? pc : 0) * PIECE_C + 16 * i;
+    }
+    constexpr int WCHUNKS = (3 * 2 * BM + 255) / 256;       // 16-B weight chunks per thread and K step (3, or 2 with BM = 64)
+    const bool w_last = (3 * 2 * BM) % 256 == 0 || t + 256 * (WCHUNKS - 1) < 3 * 2 * BM;       // (BM = 128: every thread has all three chunks)
+
+    // activation operand: pixel pp of the tile, 16-B half ph of its 32-B row, at LDS byte 16 t of each piece
+    const int pp = t >> 1, ph = t & 1;
+    const int col = n0 + pp;
+    const bool col_ok = col < p.NP;
+    int hbase = 0, wbase = 0, img_off = 0;
+    {
+        const int cc = col_ok ? col : 0;
+        const int pn = cc / OHW;
+        const int rem = cc - pn * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+        hbase = oh * p.hmul + p.hoff;
+        wbase = ow * p.wmul + p.woff;
+        img_off = (pn - nfirst) * csteps * HWi;
+    }
+    i32x4 rXi[3];
+    {
+        const size_t left = (size_t)(p.N - nfirst) * p.Cred * HWi * 2;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rXi[pc] = fx_rsrc(p.Ximg + pc * p.plane_bytes + (size_t)nfirst * p.Cred * HWi * 2, left);
+    }
+    int x_voff = FX_OOB, w_tapoff = 0, cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        cur_tap = tap;
+        const int ir = tap / p.nS, is = tap - ir * p.nS;
+        const int wtap = (p.r0 + p.rstep * ir) * p.S + p.s0 + p.sstep * is;
+        w_tapoff = wtap * tiles128 * csteps * (3 * FX_PIECE);
+        const int hi = hbase + ir * p.hstep, wi0 = wbase + is * p.wstep;
+        const bool ok = col_ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi0 < (unsigned)p.Wi;
+        x_voff = ok ? (img_off + hi * p.Wi + wi0) * 32 + 16 * ph : FX_OOB;
+    };
+    i32x4 rwi[3], rxi[3];
+    auto fetch = [&]() {
+        if (f_tap != cur_tap) { asm volatile("" ::: "memory"); set_tap(f_tap); }
+        {
+            const int so = w_tapoff + (f_k >> 4) * (3 * FX_PIECE);
+#pragma unroll
+            for (int j = 0; j < WCHUNKS; ++j) rwi[j] = fx_buffer_load_i32x4(rW, w_voff[j], so, 0);
+        }
+        {
+            const int so = (f_k >> 4) * HWi * 32;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) rxi[pc] = fx_buffer_load_i32x4(rXi[pc], x_voff, so, 0);
+        }
+        f_k += FX_BK;
+        if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+    };
+    auto stage = [&](int buf) {
+        unsigned char* pb = lds + buf * BUFB;
+#pragma unroll
+        for (int j = 0; j < WCHUNKS; ++j)
+            if (j + 1 < WCHUNKS || w_last) *reinterpret_cast<i32x4*>(pb + w_lds[j]) = rwi[j];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(pb + pc * PIECE_P + 16 * t) = rxi[pc];
+    };
+
+    f32x4 acc[GA][GB];
+#pragma unroll
+    for (int a = 0; a < GA; ++a)
+#pragma unroll
+        for (int b = 0; b < GB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lc = lane & 15, lq = lane >> 4, up = lane >> 5;
+    // fragment read offsets of the three pairings: lanes 0-31 read the first piece of a pair, lanes 32-63 the second
+    const int frow_p = 32 * (wn * 64 + lc) + 16 * (lq & 1), frow_c = CH0 + 32 * (wm * WCH + lc) + 16 * (lq & 1);
+    const int rdP_hl = frow_p + (up ? 2 : 0) * PIECE_P, rdP_hm = frow_p + (up ? 1 : 0) * PIECE_P;
+    const int rdC_lh = frow_c + (up ? 0 : 2) * PIECE_C, rdC_mm = frow_c + PIECE_C, rdC_hh = frow_c;
+    // 16-channel groups of this wave that hold output channels (wave-uniform)
+    int live_b;
+    {
+        const int n = (p.M - (m0 + wm * WCH) + 15) >> 4;
+        live_b = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > GB ? GB : n));
+    }
+    if (nk > 0) { fetch(); stage(0); if (nk > 1) fetch(); }
+    __syncthreads();
+    auto kloop = [&](auto nbt) {
+        constexpr int NB = decltype(nbt)::value;
+        auto step = [&](int kt, auto st, auto fe) {
+            const unsigned char* bb = lds + (kt & 1) * BUFB;
+            bf8 pf[GA], cf[GB > 0 ? GB : 1], pg[GA], cg[GB > 0 ? GB : 1], ch[GB > 0 ? GB : 1];
+            if constexpr (NB > 0) {
+#pragma unroll
+                for (int a = 0; a < GA; ++a) pf[a] = *reinterpret_cast<const bf8*>(bb + rdP_hl + 512 * a);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) cf[b] = *reinterpret_cast<const bf8*>(bb + rdC_lh + 512 * b);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < GA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[a], cf[b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (decltype(st)::value) stage((kt & 1) ^ 1);
+            if constexpr (decltype(fe)::value) fetch();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NB > 0) {
+#pragma unroll
+                for (int a = 0; a < GA; ++a) pg[a] = *reinterpret_cast<const bf8*>(bb + rdP_hm + 512 * a);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) cg[b] = *reinterpret_cast<const bf8*>(bb + rdC_mm + 512 * b);
+#pragma unroll
+                for (int a = 0; a < GA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pg[a], cg[b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) ch[b] = *reinterpret_cast<const bf8*>(bb + rdC_hh + 512 * b);
+#pragma unroll
+                for (int a = 0; a < GA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pg[a], ch[b], acc[a][b], 0, 0, 0);
+            }
+            __syncthreads();
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) step(kt, std::false_type{}, std::false_type{});
+    };
+    if (live_b == GB) kloop(std::integral_constant<int, GB>{});
+    else if (live_b == 0) kloop(std::integral_constant<int, 0>{});
+    else if (GB > 1 && live_b == 1) kloop(std::integral_constant<int, 1>{});
+    else if (GB > 2 && live_b == 2) kloop(std::integral_constant<int, (GB > 2 ? 2 : 0)>{});
+    else if (GB > 3 && live_b == 3) kloop(std::integral_constant<int, (GB > 3 ? 3 : 0)>{});
+
+    // ---- epilogue: lane = output channel (16 b + lc of the wave's), acc[a][b][e] = pixel 16 a + 4 lq + e of the wave's 64 ----
+    const bool split = p.kchunk > 0;
+    float* yout = p.Y + (split ? (size_t)blockIdx.y * p.slab_stride : 0);
+    const bool dense = split || (p.oxs == 1 && p.oys == 1 && p.oy0 == 0 && p.ox0 == 0 && p.YW == p.OW && p.YH == p.OH);
+    float ssum[GB], ssq[GB], esc[GB], esh[GB], emean[GB];
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+        ssum[b] = ssq[b] = esc[b] = esh[b] = emean[b] = 0.f;
+        if constexpr (EPI == 2) {
+            const int m = m0 + wm * WCH + b * 16 + lc;
+            if (m < p.M) { esc[b] = p.ep_tab[8 * m]; esh[b] = p.ep_tab[8 * m + 1]; emean[b] = p.ep_tab[8 * m + 2]; }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < GA; ++a) {
+        const int c4 = n0 + wn * 64 + a * 16 + 4 * lq;
+        if (c4 >= p.NP) continue;
+        const int n = c4 / OHW, rem = c4 - n * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+        for (int b = 0; b < GB; ++b) {
+            const int m = m0 + wm * WCH + b * 16 + lc;
+            if (m >= p.M) continue;
+            f32x4 v = acc[a][b];
+            if (!split) {
+                if (p.bias) { const float bb = p.bias[m]; v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb; }
+            }
+            if (dense) acc[a][b] = v;
+            else {
+                float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+                if (p.oxs == 1) {
+                    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+                    if (p.accumulate) { const f32x4 o4 = *d4; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                    *d4 = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e * p.oxs] = p.accumulate ? dst[e * p.oxs] + v[e] : v[e];
+                }
+            }
+            if constexpr (EPI == 1) {
+                if (!split) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[b] += v[e]; ssq[b] = fmaf(v[e], v[e], ssq[b]); }
+                }
+            }
+            if constexpr (EPI == 2) {
+                if (!split) {
+                    const f32x4 c2 = *reinterpret_cast<const f32x4*>(p.ep_c + ((size_t)n * p.M + m) * OHW + rem);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gg = fmaf(c2[e], esc[b], esh[b]) > 0.f ? v[e] : 0.f;
+                        ssum[b] += gg; ssq[b] = fmaf(gg, c2[e] - emean[b], ssq[b]);
+                    }
+                }
+            }
+        }
+    }
+    if (dense) {
+        // through a [64 channels][128 pixels] staging tile, 32 channels of each wave row per round (see fx_conv_kernel)
+        constexpr int EROW = 512 + 16;
+        constexpr int ROUNDS = (GB + 1) / 2;
+        const bool accum = !split && p.accumulate;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r > 0) __syncthreads();
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int b = 2 * r + b2;
+                if (b < GB) {
+#pragma unroll
+                    for (int a = 0; a < GA; ++a)
+                        *reinterpret_cast<f32x4*>(lds + (wm * 32 + b2 * 16 + lc) * EROW + (wn * 64 + a * 16 + 4 * lq) * 4) = acc[a][b < GB ? b : 0];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = t + 256 * i, row = id >> 5, q = id & 31;
+                const int within = r * 32 + (row & 31);
+                const int m = m0 + (row >> 5) * WCH + within;
+                const int c4 = n0 + 4 * q;
+                if (within >= WCH || m >= p.M || c4 >= p.NP) continue;
+                const int n = c4 / OHW, rem = c4 - n * OHW;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * EROW + q * 16);
+                const size_t at = ((size_t)n * p.M + m) * OHW + rem;
+                f32x4* dst = reinterpret_cast<f32x4*>(yout + at);
+                if (accum) {
+                    f32x4 o4;
+                    if (p.acc_src) {
+                        o4 = *reinterpret_cast<const f32x4*>(p.acc_src + at);
+                        if (p.acc_mask) {
+                            const unsigned mk = p.acc_mask[at >> 2];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[e] = (mk >> e) & 1u ? o4[e] : 0.f;
+                        }
+                    } else o4 = *dst;
+                    v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3];
+                }
+                *dst = v;
+            }
+        }
+    }
+    if constexpr (EPI == 1 || EPI == 2) {
+        if (!split) {
+            // the four 16-lane groups hold different pixels of the same channels; then the two waves along the pixel axis
+#pragma unroll
+            for (int b = 0; b < GB; ++b) {
+                ssum[b] += __shfl_xor(ssum[b], 16, 64); ssq[b] += __shfl_xor(ssq[b], 16, 64);
+                ssum[b] += __shfl_xor(ssum[b], 32, 64); ssq[b] += __shfl_xor(ssq[b], 32, 64);
+                if (lq == 0) { red[wn][0][wm * WCH + b * 16 + lc] = ssum[b]; red[wn][1][wm * WCH + b * 16 + lc] = ssq[b]; }
+            }
+            __syncthreads();
+            if (t < BM && m0 + t < p.M) {
                 float* dst = p.partial + ((size_t)tile_n * p.M + m0 + t) * 2;
                 dst[0] = red[0][0][t] + red[1][0][t];
                 dst[1] = red[0][1][t] + red[1][1][t];
@@ -1097,13 +1401,16 @@ bool fx_enabled() {
 int fx_set_enabled(int on) { const int before = fx_enabled() ? 1 : 0; g_fx = on ? 1 : 0; return before; }
 
 // coverage counters (launches routed here vs to the fp32-MFMA kernel), read by bench.py so that no fallback goes uncounted
+static std::mutex g_fx_count_mu;
 static unsigned long long g_fx_count[6];      // fwd / dgrad / wgrad on this path, then fwd / dgrad / wgrad on the fp32-MFMA path
 static double g_fx_flops[6];
 void fx_count(int kind, const p3d_conv_desc* d) {
+    std::lock_guard<std::mutex> lock(g_fx_count_mu);
     g_fx_count[kind] += 1;
     g_fx_flops[kind] += 2.0 * d->N * d->K * d->Ho * d->Wo * (double)d->C * d->R * d->S;
 }
 void fx_stats(unsigned long long* counts, double* flops, int reset) {
+    std::lock_guard<std::mutex> lock(g_fx_count_mu);
     for (int i = 0; i < 6; ++i) { if (counts) counts[i] = g_fx_count[i]; if (flops) flops[i] = g_fx_flops[i]; }
     if (reset) for (int i = 0; i < 6; ++i) { g_fx_count[i] = 0; g_fx_flops[i] = 0.0; }
 }
@@ -1130,8 +1437,26 @@ bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m) {
 
 // tuning aid (p3d_fx_tune): forced split counts, 0 = the built-in plan
 static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0;
+// image-fed forward / data gradient on v_mfma_f32_16x16x32_bf16 (fx16_conv_kernel): -1 = environment (P3D_FX16), 0 never, 1 (default) where its 64- and 96-row
+// channel tiles fit the layer better than 128 rows, 2 everywhere (the A/B of the two MFMA shapes: profiles/r04_fx16.md -- at 128 rows the 16x16x32 form is 1-3 %
+// SLOWER on the large layers, 20 fragment reads per step against 12, and the chip holds no higher clock on it in these kernels)
+static int g_fx16 = -1;
+static int fx16_mode() {
+    if (g_fx16 < 0) { const char* e = getenv("P3D_FX16"); g_fx16 = e ? atoi(e) : 1; if (g_fx16 < 0 || g_fx16 > 2) g_fx16 = 1; }
+    return g_fx16;
+}
+// channel tile of the fx16 kernel for a launch (0: the launch stays on fx_conv_kernel): 16 x 16 sub-tiles allow 96- and 64-row tiles where 128 rows would be
+// mostly padding (the 272-channel regressor: 3 x 96 = 288 rows instead of 384; 64-channel layers: all four waves live)
+static int fx16_bm(int M, bool img, int pro, int epi) {
+    const int mode = fx16_mode();
+    if (!img || pro != 0 || (epi != 0 && epi != 1 && epi != 2) || mode == 0) return 0;
+    if (M <= 64) return 64;
+    if (ceil_div(M, 96) * 96 < ceil_div(M, 128) * 128) return 96;
+    return mode == 2 ? 128 : 0;
+}
 void fx_tune(int what, int value) {
     if (what == 3) { g_pair_map = value; return; }      // 0: the two opening image passes of a downsample block as two launches (A/B, tests)
+    if (what == 4) { g_fx16 = value < 0 || value > 2 ? 1 : value; return; }  // A/B of the two MFMA shapes in one process
     (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value;
 }
 
@@ -1251,8 +1576,13 @@ int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_f
     return check_launch("fx_build_weight_images");
 }
 
-static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, dim3 grid, hipStream_t st) {
+static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, int bm, dim3 grid, hipStream_t st) {
     const int am = img ? 1 : 0;
+#define P3D_FX16_CASE(BM, EPI) if (bm == BM && epi == EPI) { hipLaunchKernelGGL((fx16_conv_kernel<BM, EPI>), grid, dim3(256), 0, st, p); return; }
+    P3D_FX16_CASE(128, 0) P3D_FX16_CASE(128, 1) P3D_FX16_CASE(128, 2)
+    P3D_FX16_CASE(96, 0) P3D_FX16_CASE(96, 1) P3D_FX16_CASE(96, 2)
+    P3D_FX16_CASE(64, 0) P3D_FX16_CASE(64, 1) P3D_FX16_CASE(64, 2)
+#undef P3D_FX16_CASE
 #define P3D_FX_CASE(AM, PRO, EPI) if (am == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
     P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 4)
     P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2)
@@ -1298,16 +1628,17 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
         if (fuse->partial) { epi = 1; p.partial = fuse->partial; }
         if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
-    p.tiles_m = (int)ceil_div(d->K, FX_BM);
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
     const FxSplit sp = fx_fwd_split(d);
+    const int bm = fx16_bm(d->K, img, sp.splits > 1 ? 0 : pro, sp.splits > 1 ? 0 : epi);
+    p.tiles_m = (int)ceil_div(d->K, bm ? bm : FX_BM);
     if (sp.splits > 1) {
         p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
-        fx_launch_conv(p, img, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        fx_launch_conv(p, img, 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
         fx_launch_reduce(epi, dim3((unsigned)d->K, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, y, bias, sp.splits, p.slab_stride, d->N, d->K,
                          d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial);
     } else {
-        fx_launch_conv(p, img, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+        fx_launch_conv(p, img, pro, epi, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     }
     return check_launch("fx_conv_fwd");
 }
@@ -1346,7 +1677,9 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         if (fuse->partial) { epi = 2; p.partial = fuse->partial; p.ep_c = fuse->ep_c; p.ep_tab = fuse->ep_tab; }
         if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
-    p.tiles_m = (int)ceil_div(d->C, FX_BM);
+    const bool dsplit = d->stride == 1 && fx_dgrad_split(d).splits > 1;
+    const int bm = fx16_bm(d->C, img, dsplit ? 0 : pro, dsplit ? 0 : epi);
+    p.tiles_m = (int)ceil_div(d->C, bm ? bm : FX_BM);
     if (d->stride == 1) {
         p.OH = d->H; p.OW = d->W; p.NP = d->N * d->H * d->W; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
         p.nR = d->R; p.nS = d->S; p.ntap = RS; p.r0 = 0; p.rstep = 1; p.s0 = 0; p.sstep = 1;
@@ -1355,12 +1688,12 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         const FxSplit sp = fx_dgrad_split(d);
         if (sp.splits > 1) {
             p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
-            fx_launch_conv(p, img, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            fx_launch_conv(p, img, 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
             fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
                              d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
         } else {
             if (fuse && fuse->acc_src && d->accumulate) { p.acc_src = fuse->acc_src; p.acc_mask = fuse->acc_mask; }
-            fx_launch_conv(p, img, pro, epi, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+            fx_launch_conv(p, img, pro, epi, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
         }
         return check_launch("fx_conv_dgrad");
     }
@@ -1382,7 +1715,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
             c.hoff = th >= 0 ? th / st2 : -((-th) / st2); c.hstep = -(c.rstep * d->dil) / st2;
             c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
             c.oy0 = ph; c.ox0 = pw;
-            fx_launch_conv(c, img, pro, epi, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            fx_launch_conv(c, img, pro, epi, bm, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
         }
     return check_launch("fx_conv_dgrad");
 }
@@ -1566,7 +1899,9 @@ int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H,
     p.Ximg = (const unsigned char*)x_img; p.plane_bytes = (size_t)N * (H / 2) * (W / 2) * 32;
     p.Wimg = (const unsigned char*)wimg; p.Y = y;
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
-    fx_launch_conv(p, true, 0, 0, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
+    const int bm = fx16_bm(K, true, 0, 0);
+    if (bm) p.tiles_m = (int)ceil_div(K, bm);
+    fx_launch_conv(p, true, 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     return check_launch("fx_stem_fwd");
 }
 

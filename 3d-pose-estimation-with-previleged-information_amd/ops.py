@@ -94,6 +94,32 @@ SIDE_STREAM_KIND = os.environ.get('P3D_SIDE_STREAM', 'probe')       # probe | to
 SIDE_STREAM_OVERLAPS = {}                                              # device -> what the probe found (None: not probed)
 
 
+def cu_mask_words(spec, total=256):
+    """'N' -> the first N of `total` compute units, 'N:hi' -> the last N, '0x...' -> the mask itself, as little-endian 32-bit words.  (KFD deals the bits of a
+    queue's mask round-robin over the eight XCDs: a contiguous run of N bits is N / 8 CUs on each.)"""
+    spec = str(spec)
+    if spec.lower().startswith('0x'):
+        value = int(spec, 16)
+    else:
+        n, _, where = spec.partition(':')
+        n = max(1, min(int(n), total))
+        value = ((1 << n) - 1) << (total - n if where == 'hi' else 0)
+    return [(value >> (32 * i)) & 0xFFFFFFFF for i in range(total // 32)]
+
+
+def masked_stream(device, spec):
+    """A HIP stream whose kernels run only on the compute units `spec` names (cu_mask_words), as a torch ExternalStream."""
+    words = cu_mask_words(spec)
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(lib().p3d_stream_create_cumask(arr, len(words), ctypes.byref(handle)), 'stream_create_cumask')
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
+SIDE_STREAM_CUS = os.environ.get('P3D_SIDE_CUS', '')                  # e.g. '192': the weight-gradient stream may use 192 of the 256 compute units
+
+
 def _side_stream(device):
     """The weight-gradient stream.  HIP multiplexes the streams of one priority onto four hardware queues: a stream taken from PyTorch's pool landed on
     the launch stream's own queue whenever an RCCL communicator had been created first (rocprofv3: every kernel of the step on one queue), which costs
@@ -101,7 +127,10 @@ def _side_stream(device):
     p3d_stream_create_beside creates candidates until two spin kernels, one per stream, demonstrably run side by side."""
     st = _side_streams.get(device)
     if st is None:
-        if SIDE_STREAM_KIND == 'torch':
+        if SIDE_STREAM_CUS:
+            st = masked_stream(device, SIDE_STREAM_CUS)
+            SIDE_STREAM_OVERLAPS[device] = None
+        elif SIDE_STREAM_KIND == 'torch':
             st = torch.cuda.Stream(device=device)
             SIDE_STREAM_OVERLAPS[device] = None
         else:

@@ -143,6 +143,8 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (a launcher set a different world size)' % (opt.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    if os.environ.get('P3D_MAIN_CUS'):             # experiment (tools/cumask_sweep.sh): the launch stream restricted to a share of the compute units
+        torch.cuda.set_stream(pkg.ops.masked_stream(device, os.environ['P3D_MAIN_CUS']))
     join_first = bool(os.environ.get('P3D_BENCH_JOIN_FIRST')) and (world > 1 or pkg.dist.FORCE_GROUP)       # experiment (tools/rccl_order.sh): the other order
     if join_first:
         pkg.dist.init_from_env()

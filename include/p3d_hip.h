@@ -40,6 +40,10 @@ int32_t p3d_stream_create(int32_t priority_class, void** stream);
 /* A second stream that is PROVEN to run beside `main_stream` (two 200-us spin kernels, one per stream, must take ~200 us, not ~400): see csrc/p3d_api.hip.
  * *overlaps = 1 if a candidate passed the probe, 0 if the returned stream shares the main stream's hardware queue after all. */
 int32_t p3d_stream_create_beside(void* main_stream, void** stream, int32_t* overlaps);
+/* a stream restricted to the compute units whose bit is set in mask[0 .. words) (hipExtStreamCreateWithCUMask); p3d_probe_hw_ids launches nblocks spinning blocks
+   on a stream and reports where each ran: out[b] = (XCC_ID << 16) | HW_ID[15:0] */
+int32_t p3d_stream_create_cumask(const uint32_t* mask, int32_t words, void** stream);
+int32_t p3d_probe_hw_ids(void* stream, int32_t* out_device, int32_t nblocks, int32_t spin_us);
 int32_t p3d_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -680,7 +680,7 @@ def test_image_fed_kernels_match_the_oracle(case, pkg):
     assert (acc - 1 - dx).abs().max() <= 4e-6 * dx.abs().max()
 
 
-@pytest.mark.parametrize('case', [(2, 3, 64, 64, 64), (3, 1, 48, 64, 64), (2, 3, 32, 32, 96), (5, 3, 128, 128, 64)], ids=lambda c: 'n%d_c%d_%dx%d_k%d' % c)
+@pytest.mark.parametrize('case', [(2, 3, 64, 64, 64), (3, 1, 48, 64, 64), (2, 3, 32, 32, 96), (5, 3, 128, 128, 64), (2, 4, 64, 64, 64)], ids=lambda c: 'n%d_c%d_%dx%d_k%d' % c)
 def test_stem_on_the_x3_kernels(case, pkg):
     """conv1 = Conv2d(Cin, K, 7, stride 2, padding 3) (depthnet.py:138) restated as a 4x4 stride-1 convolution over a space-to-depth image of the input
     (p3d_stem_*): forward and weight gradient against the float64 oracle's plain 7x7 stride-2 convolution."""
@@ -759,3 +759,37 @@ def test_stem_tail_is_bit_identical_to_batchnorm_relu_maxpool(pkg, shape):
                       bn.num_batches_tracked.clone())
     for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var', 'num_batches_tracked')):
         assert torch.equal(a, b), name
+
+
+def test_extra_channel_stem_forward_backward(pkg):
+    """`-extra_channel` (resnet.py:142): the legacy network's stem takes 4 input channels.  conv1 -> bn1 -> ReLU -> max pool of that network, forward and backward
+    (weight gradient of the 4-channel conv1, d gamma / d beta of bn1), against the float64 oracle's chain of the same four operators."""
+    args = pkg.opts.parse(['-model', 'resnet18', '-suffix', 't', '-data_name', 'h36m', '-save_path', '/tmp/p3d', '-criterion', 'SmoothL1', '-num_joints', '17',
+                           '-side_in', '64', '-extra_channel'])
+    torch.manual_seed(3)
+    model = pkg.resnet.resnet18(args).cuda().train()
+    assert tuple(model.conv1.weight.shape) == (64, 4, 7, 7)
+    with torch.no_grad():
+        model.bn1.weight.uniform_(0.5, 1.5)
+        model.bn1.bias.uniform_(-0.3, 0.3)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(3, 4, 64, 64, device='cuda', generator=gen)
+    stem = __import__('importlib').import_module(pkg.__name__ + '._trunk').stem
+    out = stem(model.conv1, model.bn1, model.maxpool, x)
+    dout = torch.randn(out.shape, device='cuda', generator=gen)
+    out.backward(dout)
+    pkg.ops.join_side_stream()
+    torch.cuda.synchronize()
+    xh, wh, gh, bh, dh = host(x), host(model.conv1.weight), host(model.bn1.weight), host(model.bn1.bias), host(dout)
+    c = ref.conv2d_fwd(xh, wh, None, 2, 3, 1)
+    y, mean, invstd, _, _ = ref.bn_train_fwd(c, gh, bh)
+    a = ref.relu_fwd(y)
+    want, idx = ref.maxpool3x3s2_fwd(a)
+    assert np.abs(host(out) - want).max() < 2e-5 * np.abs(want).max()
+    da = ref.maxpool3x3s2_bwd(dh, idx, a.shape)
+    dy = ref.relu_bwd(da, a)
+    dc, dgamma, dbeta = ref.bn_train_bwd(dy, c, mean, invstd, gh)
+    dw = ref.conv2d_wgrad(dc, xh, wh.shape, 2, 3, 1)
+    assert np.abs(host(model.bn1.weight.grad) - dgamma).max() < 5e-5 * np.abs(dgamma).max()
+    assert np.abs(host(model.bn1.bias.grad) - dbeta).max() < 5e-5 * np.abs(dbeta).max()
+    assert np.abs(host(model.conv1.weight.grad) - dw).max() < 1e-4 * np.abs(dw).max()

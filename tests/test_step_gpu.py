@@ -170,23 +170,28 @@ def test_training_reduces_the_loss_on_a_fixed_batch(extra, pkg):
     assert max(losses[-5:]) < 0.5 * losses[0], losses
 
 
-def test_contract_batch_step_matches_oracle(pkg):
-    """The workload bench.py times -- ResNet-50, 256 x 256, batch 64, one full step (depth_train.py:393-405,452-456) -- against the oracle's
-    PyTorch-CPU port from the same deterministic weights on the same batch: loss and 3-D joints within the north_star's 1e-3 relative, the
-    global gradient norm and the post-Adam regressor weights beside them.  (The reference goldens stop at batch 2; at batch 64 every conv,
-    BatchNorm and reduction kernel picks the plan the bench runs: split counts, slab folds, partial-sum rows.)  Slow: ~1 min of CPU."""
+@pytest.mark.parametrize('family,batch,flags', [('depthnet', 64, []), ('partial_depthnet', 64, ['-depth_only', '-partial_conv']), ('fusionnet', 32, ['-do_fusion'])],
+                         ids=['depthnet_b64', 'partial_depthnet_b64', 'fusionnet_b32'])
+def test_contract_batch_step_matches_oracle(family, batch, flags, pkg):
+    """The workloads BASELINE.json's configs 2, 4 and 5 name -- ResNet-50, 256 x 256, one full step (depth_train.py:393-405,452-456) of depthnet at batch 64,
+    partial_depthnet at batch 64 (partial_depthnet.py:213-229) and fusionnet at batch 32 (fusionnet.py:221-240) -- against the oracle's PyTorch-CPU port from
+    the same deterministic weights on the same batch: loss and 3-D joints within the north_star's 1e-3 relative, the global gradient norm and the post-Adam
+    regressor weights beside them.  (The reference goldens stop at batch 2; at these batches every conv, BatchNorm and reduction kernel picks the plan the
+    bench runs: split counts, slab folds, partial-sum rows, the executor / per-layer mix of the masked families.)  Slow: ~1 min of CPU each."""
     from oracle.torch_port import TorchPort
     meta = dict(model='resnet50', side=256, extra=['-stride', '16', '-depth', '16', '-depth_range', '1000', '-loss_div', '10', '-learn_rate', '5e-5',
-                                                   '-weight_decay', '4e-5', '-grad_norm', '5'])
+                                                   '-weight_decay', '4e-5', '-grad_norm', '5'] + flags)
     args, model, trainer = build(pkg, meta)
     model.train()
     trainer.adapt_learn_rate(1)
     lr = trainer.optimizer.param_groups[0]['lr']
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family='depthnet', model='resnet50')
-    c, d, tc, tv = pkg.synth.make_batch(64, side=256, rank=0, step=0)
+    port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family=family, model='resnet50')
+    c, d, tc, tv = pkg.synth.make_batch(batch, side=256, rank=0, step=0)
     want = port.train_step(c, d, tc, tv, lr=lr, weight_decay=4e-5, grad_norm=5.0, loss_div=10.0)
-    loss = float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+    color = torch.from_numpy(c).cuda() if family != 'partial_depthnet' else None
+    depth = torch.from_numpy(d).cuda() if family != 'depthnet' else None
+    loss = float(trainer.train_step(color, depth, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
     spec = trainer.last_spec_cam.cpu().numpy()
     assert abs(loss - want['loss']) < 1e-3 * abs(want['loss']), (loss, want['loss'])
     assert np.abs(spec - want['spec_cam']).max() < 1e-3 * np.abs(want['spec_cam']).max()
