@@ -41,6 +41,8 @@ SIGNATURES = {
     'p3d_conv2d_bgrad': (_i32, [_ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
     'p3d_conv2d_bgrad_masked': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _ptr, _i32, _ptr]),
     'p3d_block_supported': (_i32, [_ptr]),
+    'p3d_block_tail_supported': (_i32, [_ptr]),
+    'p3d_block_tail_partial_bytes': (ctypes.c_size_t, [_ptr]),
     'p3d_block_workspace_bytes': (_i32, [_ptr, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     'p3d_block_fwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr]),
     'p3d_block_bwd': (_i32, [_ptr, _ptr, _ptr, _sz, _ptr, _sz, _ptr, _ptr]),
@@ -65,6 +67,10 @@ SIGNATURES = {
     'p3d_stem_weight_image': (_i32, [_ptr, _i32, _i32, _ptr, _ptr, _sz, _ptr]),
     'p3d_stem_fwd': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     'p3d_stem_wgrad': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
+    'p3d_stem_masked_supported': (_i32, [_i32] * 5),
+    'p3d_stem_image_masked': (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_stem_fwd_masked': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    'p3d_stem_wgrad_masked': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_profile_enable': (_i32, [_i32]),
     'p3d_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),

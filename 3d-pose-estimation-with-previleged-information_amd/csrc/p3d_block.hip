@@ -462,6 +462,19 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     return check_launch("block_fwd");
 }
 
+// Can this block's backward pass reduce its producer's opening sums (p3d_block_io.tail_*)?  The last writer of dx must be a dense stride-1 launch whose epilogue
+// sees the final value: conv 0's data gradient with an identity shortcut (dx = dgrad + g), the downsample conv's (dx += dgrad) otherwise.
+int32_t p3d_block_tail_supported(const p3d_block_desc* b) {
+    if (check_block(b)) return 0;
+    if (b->has_downsample) return b->conv[3].stride == 1 && fx_dgrad_tail_applies(&b->conv[3]) ? 1 : 0;
+    return fx_dgrad_tail_applies(&b->conv[0]) && fx_dgrad_accumulates_from_source(&b->conv[0]) ? 1 : 0;
+}
+size_t p3d_block_tail_partial_bytes(const p3d_block_desc* b) {
+    if (!p3d_block_tail_supported(b)) return 0;
+    const p3d_conv_desc* d = &b->conv[b->has_downsample ? 3 : 0];
+    return (size_t)fx_dgrad_tail_rows(d) * d->C * 4 * sizeof(float);
+}
+
 // dout -> dx (+ every parameter gradient, accumulated into io->dw / dgamma / dbeta when b->accumulate_grads, else written).
 // side_stream may be null (everything on `stream`); otherwise the weight-gradient kernels run there, ordered by events behind the kernels that produce
 // their operands; the caller joins the two streams before it reads the gradients.
@@ -494,17 +507,28 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     const p3d_conv_desc* dl = &b->conv[last];
     const int acc = b->accumulate_grads;
 
-    // 1. open: g = dout * [out > 0]; channel sums of the closing BN (and of the downsample BN)
-    const int split = close_split(dl->N, dl->K);
+    // 1. open: g = dout * [out > 0]; channel sums of the closing BN (and of the downsample BN) -- unless the block that consumed `out` left them already: the data
+    //    gradient that wrote dout reduced them in its epilogue (io->open_sums = that call's io->tail_sums), and this pass over dout and c is not needed at all
+    const bool sums_given = io->open_sums != nullptr && !g_in_memory;
+    const int split = sums_given ? P3D_TAIL_ROWS : close_split(dl->N, dl->K);
+    const void* open_partial = sums_given ? (const void*)io->open_sums : (const void*)partial;
     const float* g = (b->relu_out && g_in_memory) ? io->gbuf : io->dout;
     const unsigned char* gmask = g_in_memory ? nullptr : io->out_mask;
-    hipLaunchKernelGGL(block_open_bwd_kernel, dim3(dl->K, split), dim3(256), 0, st, io->dout, (const float*)io->out, (const float*)io->c[last],
-                       (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
-                       b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, g_in_memory ? io->gbuf : (float*)nullptr, (double*)partial,
-                       (const unsigned char*)io->out_mask, dl->N, dl->K,
-                       dl->Ho * dl->Wo, b->relu_out);
+    if (!sums_given)
+        hipLaunchKernelGGL(block_open_bwd_kernel, dim3(dl->K, split), dim3(256), 0, st, io->dout, (const float*)io->out, (const float*)io->c[last],
+                           (const float*)io->table[last], b->has_downsample ? (const float*)io->c[3] : (const float*)nullptr,
+                           b->has_downsample ? (const float*)io->table[3] : (const float*)nullptr, g_in_memory ? io->gbuf : (float*)nullptr, (double*)partial,
+                           (const unsigned char*)io->out_mask, dl->N, dl->K,
+                           dl->Ho * dl->Wo, b->relu_out);
     const double cnt_last = (double)dl->N * dl->Ho * dl->Wo;
     if (int32_t e = check_launch("block_bwd open")) return e;
+    // this block as a consumer: may the last writer of dx reduce the producer's opening sums?
+    const bool tail = b->need_dx && io->tail_c_last && io->tail_table_last && io->tail_partial && io->tail_sums && (!io->tail_c_ds || io->tail_table_ds) &&
+                      p3d_block_tail_supported(b);
+    auto set_tail = [&](FxFuse& f) {
+        f.tail_c = io->tail_c_last; f.tail_tab = io->tail_table_last; f.tail_rc = io->tail_c_ds; f.tail_rtab = io->tail_table_ds; f.tail_mask = io->tail_mask;
+        f.tail_partial = io->tail_partial;
+    };
 
     // 2. The gradient that enters conv i is the upstream gradient taken through BN i's backward map (masked by its ReLU, except the closing BN whose ReLU went
     //    into g already): d c_i = A g + B c_i + K, written ONCE, as the image both the weight gradient and the data gradient of conv i copy into LDS.  The
@@ -512,12 +536,13 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     //    others), finalized in the image pass's own prologue when the partial rows are few, by a launch of their own otherwise.
     //    Streams: a weight gradient runs on the second stream behind an event of the launch stream; it reads dcimg[i] and aimg[i - 1] / x, none of which the
     //    launch stream writes again inside this call, so the launch stream never waits for the second one here.
-    auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt, const unsigned char* front_mask = nullptr) -> int32_t {
+    auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt, const unsigned char* front_mask = nullptr,
+                       const void* part = nullptr) -> int32_t {
         const p3d_conv_desc* dc = &b->conv[slot];
         P3D_REQUIRE(io->dcimg[slot], "block_bwd: null gradient image %d", slot);
         if (kind == 3 || rows <= FX_FIN_MAX_ROWS) {
             FxFinalize fin{};
-            fin.kind = kind; fin.partial = partial; fin.rows = rows; fin.which = which; fin.count = cnt; fin.gamma = io->gamma[slot];
+            fin.kind = kind; fin.partial = part ? part : partial; fin.rows = rows; fin.which = which; fin.count = cnt; fin.gamma = io->gamma[slot];
             fin.dgamma = io->dgamma[slot]; fin.dbeta = io->dbeta[slot]; fin.accumulate = acc; fin.table = io->table[slot];
             fin.gmask = front_mask;
             return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, &fin);
@@ -546,14 +571,14 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         // both images in one pass: g (dout and the mask bytes) is read once
         P3D_REQUIRE(io->dcimg[last] && io->dcimg[3], "block_bwd: null gradient image");
         FxFinalize fa{}, fb{};
-        fa.kind = 3; fa.partial = partial; fa.rows = split; fa.which = 0; fa.count = cnt_last; fa.gamma = io->gamma[last]; fa.dgamma = io->dgamma[last];
+        fa.kind = 3; fa.partial = open_partial; fa.rows = split; fa.which = 0; fa.count = cnt_last; fa.gamma = io->gamma[last]; fa.dgamma = io->dgamma[last];
         fa.dbeta = io->dbeta[last]; fa.accumulate = acc; fa.table = io->table[last];
         fb = fa; fb.which = 1; fb.gamma = io->gamma[3]; fb.dgamma = io->dgamma[3]; fb.dbeta = io->dbeta[3]; fb.table = io->table[3];
         if (int32_t e = fx_act_image_pair(g, gmask, io->c[last], io->c[3], io->dcimg[last], io->dcimg[3], &fa, &fb, dl->N, dl->K, dl->Ho * dl->Wo, st)) return e;
     } else {
-        if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask)) return e;
+        if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask, open_partial)) return e;
         if (b->has_downsample)
-            if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last, gmask)) return e;
+            if (int32_t e = bwd_map(g, 3, 0, 3, split, 1, cnt_last, gmask, open_partial)) return e;
     }
     hipEvent_t ready = two ? mark_position(st) : nullptr;           // d c_last (and the downsample branch's gradient image) are complete
     const hipEvent_t ready_ds = ready;
@@ -598,10 +623,15 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
                 P3D_REQUIRE(io->gbuf, "block_bwd: null gradient buffer (dx of an identity shortcut)");
                 dx = io->gbuf; dd.accumulate = 1;
                 if (!g_in_memory) { f.acc_src = io->dout; f.acc_mask = io->out_mask; }      // gbuf is written here for the first time
+                if (tail) set_tail(f);                 // this launch writes the final dx: the producer block's opening sums ride in its epilogue
             }
-            ProfScope ps(1, d, st);
-            fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
+            {
+                ProfScope ps(1, d, st);
+                fx_count(1, d);
+                if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[0], dx, workspace, conv_ws, &f, st)) return e;
+            }
+            if (tail && !b->has_downsample)
+                if (int32_t e = fx_tail_fold(io->tail_partial, fx_dgrad_tail_rows(d), d->C, io->tail_sums, P3D_TAIL_ROWS, st)) return e;
             }
             if (int32_t e = launch_wgrad(0, io->x, nullptr, d->R * d->S > 1, ready)) return e;
         }
@@ -615,9 +645,14 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             f.act_img = io->dcimg[3];
             p3d_conv_desc dd = *d;
             dd.accumulate = 1;
-            ProfScope ps(1, d, st);
-            fx_count(1, d);
-            if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
+            if (tail) set_tail(f);                     // dx += dgrad: the final value of dx leaves this launch
+            {
+                ProfScope ps(1, d, st);
+                fx_count(1, d);
+                if (int32_t e = fx_conv_dgrad(&dd, nullptr, io->w[3], io->dx, workspace, conv_ws, &f, st)) return e;
+            }
+            if (tail)
+                if (int32_t e = fx_tail_fold(io->tail_partial, fx_dgrad_tail_rows(d), d->C, io->tail_sums, P3D_TAIL_ROWS, st)) return e;
         }
         if (int32_t e = launch_wgrad(3, io->x, nullptr, false, ready_ds)) return e;
     }
@@ -819,9 +854,13 @@ size_t p3d_stem_weight_image_bytes(int32_t K) { return fx_stem_weight_image_byte
 size_t p3d_stem_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t K) { return fx_stem_workspace(N, H, W, K); }
 
 int32_t p3d_stem_image(const float* x, void* img, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream) {
-    P3D_REQUIRE(x && img && N > 0 && Cin >= 1 && Cin <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_image: bad argument");
-    return fx_stem_image(x, img, N, Cin, H, W, (hipStream_t)stream);
+    return p3d_stem_image_masked(x, nullptr, img, N, Cin, H, W, stream);
 }
+int32_t p3d_stem_image_masked(const float* x, const float* mask_in, void* img, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream) {
+    P3D_REQUIRE(x && img && N > 0 && Cin >= 1 && Cin <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_image: bad argument");
+    return fx_stem_image(x, mask_in, img, N, Cin, H, W, (hipStream_t)stream);
+}
+int32_t p3d_stem_masked_supported(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K) { return fx_stem_applies(N, Cin, H, W, K) && fx_stem_masked_applies(K) ? 1 : 0; }
 
 int32_t p3d_stem_weight_image(const float* w, int32_t K, int32_t Cin, void* wimg, void* workspace, size_t workspace_bytes, void* stream) {
     P3D_REQUIRE(w && wimg && workspace && K > 0 && K % 16 == 0 && Cin >= 1 && Cin <= 4 && workspace_bytes >= (size_t)K * 256 * sizeof(float), "stem_weight_image: bad argument");
@@ -829,22 +868,29 @@ int32_t p3d_stem_weight_image(const float* w, int32_t K, int32_t Cin, void* wimg
 }
 
 int32_t p3d_stem_fwd(const void* x_img, const void* wimg, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream) {
+    return p3d_stem_fwd_masked(x_img, wimg, y, nullptr, N, Cin, H, W, K, stream);
+}
+int32_t p3d_stem_fwd_masked(const void* x_img, const void* wimg, float* y, const float* mult, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream) {
     P3D_REQUIRE(x_img && wimg && y, "stem_fwd: null argument");
     P3D_REQUIRE(fx_stem_applies(N, Cin, H, W, K), "stem_fwd: shape outside the restated stem (N=%d Cin=%d %dx%d K=%d)", N, Cin, H, W, K);
     const p3d_conv_desc d = stem_desc(N, Cin, H, W, K);
     ProfScope ps(0, &d, (hipStream_t)stream);
     fx_count(0, &d);
-    return fx_stem_fwd(x_img, wimg, y, N, H, W, K, (hipStream_t)stream);
+    return fx_stem_fwd(x_img, wimg, y, mult, N, H, W, K, (hipStream_t)stream);
 }
 
 int32_t p3d_stem_wgrad(const float* dy, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate, void* workspace,
                        size_t workspace_bytes, void* stream) {
+    return p3d_stem_wgrad_masked(dy, nullptr, x_img, dw, N, Cin, H, W, K, accumulate, workspace, workspace_bytes, stream);
+}
+int32_t p3d_stem_wgrad_masked(const float* dy, const float* mult, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     P3D_REQUIRE(dy && x_img && dw, "stem_wgrad: null argument");
     P3D_REQUIRE(fx_stem_applies(N, Cin, H, W, K), "stem_wgrad: shape outside the restated stem (N=%d Cin=%d %dx%d K=%d)", N, Cin, H, W, K);
     const p3d_conv_desc d = stem_desc(N, Cin, H, W, K);
     ProfScope ps(2, &d, (hipStream_t)stream);
     fx_count(2, &d);
-    return fx_stem_wgrad(dy, x_img, dw, N, Cin, H, W, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+    return fx_stem_wgrad(dy, mult, x_img, dw, N, Cin, H, W, K, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // All weight images of a network in one launch.  jobs: device array of njobs records {const float* w; void* img_fwd; void* img_bwd; int32 K, C, RS, pad} (40 bytes each;

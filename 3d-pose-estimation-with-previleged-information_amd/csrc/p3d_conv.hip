@@ -1091,7 +1091,7 @@ int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm,
     if (nslab > 16) {
         // one launch where the destination allows it (every weight of a ResNet): same additions in the same order as fold + reduce
         const size_t tot = (size_t)M * Ncols;
-        if (tapm && d->R * d->S > 1 && d->C % 16 == 0) {
+        if (tapm && d->R * d->S > 1 && d->C % 16 == 0 && (size_t)(17 * d->R * d->S * 16) * sizeof(float) <= 64 * 1024) {      // (its LDS tile: 7x7 = 53 KB; 8x8 and up take fold + reduce)
             const int RS = d->R * d->S;
             hipLaunchKernelGGL(wgrad_reduce16_tapm_kernel, dim3(d->K, d->C / 16), dim3(256), (size_t)(17 * RS * 16) * sizeof(float), st, (const float*)slabs, dw, M, d->C, RS,
                                nslab, ldw, woff, d->accumulate);

@@ -8,6 +8,9 @@
 
 namespace p3d {
 
+// one stride^2 parity class of a strided data gradient: the fields of FxConvParams that differ between the classes of one launch (blockIdx.z selects)
+struct FxConvClass { int nR, nS, ntap, r0, rstep, s0, sstep, hoff, hstep, woff, wstep, oy0, ox0; };
+
 struct FxConvParams {
     const float* X;         // AMODE 0: activation operand, x (FWD) or dy (DGRAD), fp32 [N][Cred][Hi][Wi]
     const unsigned char* Ximg;      // AMODE 1: the same tensor as a pre-split activation image (fx_act_image): three bf16 planes [N][Cred/16][Hi][Wi][16]
@@ -22,6 +25,9 @@ struct FxConvParams {
     const float* emask;     // EPI 4: per-pixel factor of the result, [N][1][YH][YW]
     const float* acc_src;   // dense unsplit launches with `accumulate`: what is added to the result instead of Y's own content (laid out like Y), after
     const unsigned char* acc_mask;   //   masking by these bytes when given (bit e of byte i: element 4 i + e passes): Y = result + src * mask, Y itself is only written
+    // EPI 3 (dense unsplit data gradient that writes a block's dx last): per (pixel tile, channel) partial sums of g, g (tail_c - mean), g (tail_rc - rmean) with
+    // g = Y * [tail_mask bit], Y the final value (after accumulation): the opening sums of the backward pass of the block that produced this block's input
+    const float* tail_c; const float* tail_tab; const float* tail_rc; const float* tail_rtab; const unsigned char* tail_mask; float* tail_partial;   // [tiles_n][M][4]
     size_t slab_stride;     // elements between two split-K slabs
     int N, Cred, Hi, Wi;
     int M, OH, OW, NP;      // the GEMM's pixel grid (for strided dgrad: one parity class of the input) and its size N * OH * OW
@@ -34,6 +40,8 @@ struct FxConvParams {
     int kchunk;             // K steps per split (0: no split-K; otherwise blockIdx.y selects the slab)
     int accumulate;
     int tiles_m;
+    int ncls;               // > 0: a strided data gradient whose parity classes run as ONE launch, class blockIdx.z overriding the fields above from cls[]
+    FxConvClass cls[4];
 };
 
 struct FxWgradParams {
@@ -63,6 +71,8 @@ struct FxFuse {
     const void* wimg;       // FWD / DGRAD: pre-split weight image of this conv for this direction (fx_build_weight_images), or null: built into the workspace by the call
     const float* acc_src;   // DGRAD with d->accumulate, stride 1, unsplit (fx_dgrad_accumulates_from_source): dx = dgrad + acc_src * [acc_mask bit] instead of dx += dgrad
     const unsigned char* acc_mask;
+    // DGRAD (fx_dgrad_tail_applies): also reduce the opening sums of the producer block's backward pass over the final dx (FxConvParams::tail_*)
+    const float* tail_c; const float* tail_tab; const float* tail_rc; const float* tail_rtab; const unsigned char* tail_mask; float* tail_partial;
 };
 constexpr int FX_TAB = 8;   // floats per channel of a table
 
@@ -86,6 +96,9 @@ bool fx_dgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_wgrad_applies(const p3d_conv_desc* d, int min_m = 96);
 bool fx_dgrad_has_dead_classes(const p3d_conv_desc* d);
 bool fx_dgrad_accumulates_from_source(const p3d_conv_desc* d);      // stride 1 and no split-K: FxFuse::acc_src is honoured
+bool fx_dgrad_tail_applies(const p3d_conv_desc* d);                 // the image-fed data gradient of d takes FxFuse::tail_* (dense, unsplit, 128-row channel tiles)
+int fx_dgrad_tail_rows(const p3d_conv_desc* d);                     // rows of tail_partial [rows][C][4]
+int32_t fx_tail_fold(const float* partial, int rows, int C, double* sums, int out_rows, hipStream_t st);      // -> sums [C][out_rows][3]
 bool fx_fwd_masked_applies(const p3d_conv_desc* d);          // partial convolutions: the masked instances exist for unsplit launches without bias
 bool fx_dgrad_masked_applies(const p3d_conv_desc* d);
 bool fx_wgrad_masked_applies(const p3d_conv_desc* d);
@@ -141,10 +154,12 @@ bool fx_stem_applies(int N, int Cin, int H, int W, int K);
 size_t fx_stem_image_bytes(int N, int H, int W);
 size_t fx_stem_weight_image_bytes(int K);
 size_t fx_stem_workspace(int N, int H, int W, int K);
-int32_t fx_stem_image(const float* x, void* img, int N, int Cin, int H, int W, hipStream_t st);
+int32_t fx_stem_image(const float* x, const float* mask, void* img, int N, int Cin, int H, int W, hipStream_t st);      // mask: per-pixel factor of x [N][1][H][W], or null
+bool fx_stem_masked_applies(int K);
 int32_t fx_stem_weight_image(const float* w, int K, int Cin, void* wimg, void* workspace, hipStream_t st);
-int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H, int W, int K, hipStream_t st);
-int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace, size_t workspace_bytes,
-                      hipStream_t st);
+// mult: per-pixel factor of the result (forward) / of dy (weight gradient), [N][1][H/2][W/2], or null -- the partial-convolution stem of the partial families
+int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, const float* mult, int N, int H, int W, int K, hipStream_t st);
+int32_t fx_stem_wgrad(const float* dy, const float* mult, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace,
+                      size_t workspace_bytes, hipStream_t st);
 
 }  // namespace p3d

@@ -151,8 +151,21 @@ __device__ __forceinline__ void fx_tr_frag_off(int lane, int cb, int (&off)[2]) 
 // EPI: 0 store; 1 store + per-(pixel tile, channel) partial sums of y, y^2 (the BatchNorm behind the conv); 2 store + partial sums of g, g * (c2 - mean) with
 //      g = y * [c2 * sc + sh > 0] (the BatchNorm + ReLU in front of the conv whose input gradient this is; ep_c = c2 laid out like the output, ep_tab = its
 //      table); 4 store y * emask[pixel] (partial convolution).  Under split-K the epilogue work is done by fx_reduce_kernel instead.
+// the launch's parameters as block z sees them: a strided data gradient runs its parity classes as the z slices of one grid (the longest K loops first), each a dense
+// GEMM over the filter taps that reach the class
+__device__ __forceinline__ FxConvParams fx_class_params(const FxConvParams& in) {
+    FxConvParams p = in;
+    if (in.ncls > 0) {
+        const FxConvClass& c = in.cls[blockIdx.z];
+        p.nR = c.nR; p.nS = c.nS; p.ntap = c.ntap; p.r0 = c.r0; p.rstep = c.rstep; p.s0 = c.s0; p.sstep = c.sstep;
+        p.hoff = c.hoff; p.hstep = c.hstep; p.woff = c.woff; p.wstep = c.wstep; p.oy0 = c.oy0; p.ox0 = c.ox0;
+    }
+    return p;
+}
+
 template <int AMODE, int PRO, int EPI>
-__global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
+__global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in) {
+    const FxConvParams p = fx_class_params(p_in);
     static_assert(AMODE == 0 || PRO == 0, "the partial-convolution factor is applied by the in-kernel split");
     // one shared array: two buffers of [3 pixel pieces][3 channel pieces]; after the K loop the result tile on its way out (33.8 KB) and, behind it, the
     // per-channel sums of EPI 1 / 2
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     const bool split = p.kchunk > 0;
     float* yout = p.Y + (split ? (size_t)blockIdx.y * p.slab_stride : 0);
     const bool dense = split || (p.oxs == 1 && p.oys == 1 && p.oy0 == 0 && p.ox0 == 0 && p.YW == p.OW && p.YH == p.OH);
-    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f}, sthird[2] = {0.f, 0.f};
     float esc[2] = {0.f, 0.f}, esh[2] = {0.f, 0.f}, emean[2] = {0.f, 0.f};
     if constexpr (EPI == 2) {
 #pragma unroll
@@ -389,10 +402,63 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             if (m < p.M) { esc[b] = p.ep_tab[8 * m]; esh[b] = p.ep_tab[8 * m + 1]; emean[b] = p.ep_tab[8 * m + 2]; }
         }
     }
+    if constexpr (EPI == 3) {             // emean: the mean of the producer's closing BatchNorm; esc: that of its downsample BatchNorm
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int m = m0 + wm * 64 + b * 32 + fr;
+            if (m < p.M) { emean[b] = p.tail_tab[8 * m + 2]; esc[b] = p.tail_rc ? p.tail_rtab[8 * m + 2] : 0.f; }
+        }
+    }
+    if constexpr (EPI == 3) {
+        // The launch that writes a block's dx last (dense, unsplit, accumulating): the summand joins HERE, in the register view, so that v is the final gradient,
+        // and the opening sums of the producer block's backward pass (g = v [producer's out > 0]; its closing and its downsample BatchNorm) are per-lane adds like
+        // EPI 2's.  Straight-line code: out-of-range lanes read element 0 and contribute nothing, optional operands are pointer selects, so no branch separates the
+        // loads and the compiler keeps several iterations' worth in flight (one memory round trip per iteration otherwise, which cost more than the pass saved).
+        const float* src = p.acc_src ? p.acc_src : yout;                       // what is added to the result
+        const unsigned char* amask = p.acc_mask ? p.acc_mask : p.tail_mask;    // (tail_mask: any readable bytes; forced to "all pass" below)
+        const unsigned aforce = p.acc_mask ? 0u : 0xFu;
+        const float* rcp = p.tail_rc ? p.tail_rc : p.tail_c;                   // no downsample BatchNorm: the third sum is computed on the same lines and ignored
+        int dep = 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = n0 + wn * 64 + a * 32 + 8 * g + 4 * fh;
+                const int cc = (c4 < p.NP ? c4 : 0) + dep;          // (the whole index computation of a batch hangs on `dep`: it is not hoisted either)
+                const int n = cc / OHW, rem = cc - n * OHW;
+                const unsigned pix = (unsigned)n * (unsigned)p.M * (unsigned)OHW + (unsigned)rem;       // (fx_common: the tensor has fewer than 2^31 elements)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int m = m0 + wm * 64 + b * 32 + fr;
+                    const bool ok = c4 < p.NP && m < p.M;
+                    const unsigned at = ok ? pix + (unsigned)m * (unsigned)OHW : 0u;
+                    const f32x4 o4 = *reinterpret_cast<const f32x4*>(src + at);
+                    const unsigned am = amask[at >> 2] | aforce;
+                    const unsigned mk = p.tail_mask[at >> 2];
+                    const f32x4 cl = *reinterpret_cast<const f32x4*>(p.tail_c + at);
+                    const f32x4 rc = *reinterpret_cast<const f32x4*>(rcp + at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[a][b][4 * g + e] + ((am >> e) & 1u ? o4[e] : 0.f);
+                        acc[a][b][4 * g + e] = v;
+                        const float gg = (ok && ((mk >> e) & 1u)) ? v : 0.f;
+                        ssum[b] += gg;
+                        ssq[b] = fmaf(gg, cl[e] - emean[b], ssq[b]);
+                        sthird[b] = fmaf(gg, rc[e] - esc[b], sthird[b]);
+                    }
+                }
+                // A batch = the two channel sub-tiles of one pixel group.  Left to itself the compiler hoists all sixteen iterations' loads (200 registers beside the
+                // 64 of the accumulator) and spills them straight to scratch; neither a scheduling barrier nor a memory clobber holds loads it has proven unclobbered.
+                // So the next batch's addresses are made to depend on this batch's sums: `dep` stays 0, which the compiler cannot know.
+                // (ALL the sums: with only the first pair the scheduler rushes that chain ahead and parks the operands of the other two in scratch)
+                if (g & 1) asm volatile("" : "+v"(dep) : "v"(ssum[0]), "v"(ssum[1]), "v"(ssq[0]), "v"(ssq[1]), "v"(sthird[0]), "v"(sthird[1]));
+            }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if constexpr (EPI == 3) continue;
             const int c4 = n0 + wn * 64 + a * 32 + 8 * g + 4 * fh;         // first of this lane's 4 consecutive pixels
             if (c4 >= p.NP) continue;
             const int n = c4 / OHW, rem = c4 - n * OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -452,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
     if (dense) {
         // (every wave left the K loop through its last barrier: the operand buffers are free)
         constexpr int EROW = 512 + 16;               // bytes per staged channel row: 128 pixels + one 16-B pad (staging stores of 8 consecutive rows hit 32 different banks)
-        const bool accum = !split && p.accumulate;
+        const bool accum = EPI != 3 && !split && p.accumulate;      // (EPI 3 has added its summand in the register view above: its sums need the final value)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             if (b == 1) __syncthreads();             // round 0's rows have been read
@@ -506,6 +572,21 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
             }
         }
     }
+    if constexpr (EPI == 3) {
+        // three sums per channel: [wave along pixels][kind][channel] behind the staged tile (3 KB at byte 40960 of the 48 KB array)
+        float (*const red3)[3][128] = reinterpret_cast<float (*)[3][128]>(lds + 40960);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            ssum[b] += __shfl_xor(ssum[b], 32, 64);
+            ssq[b] += __shfl_xor(ssq[b], 32, 64);
+            sthird[b] += __shfl_xor(sthird[b], 32, 64);
+            if (fh == 0) { const int ch = wm * 64 + b * 32 + fr; red3[wn][0][ch] = ssum[b]; red3[wn][1][ch] = ssq[b]; red3[wn][2][ch] = sthird[b]; }
+        }
+        __syncthreads();
+        if (t < 128 && m0 + t < p.M)
+            *reinterpret_cast<f32x4*>(p.tail_partial + ((size_t)tile_n * p.M + m0 + t) * 4) =
+                f32x4{red3[0][0][t] + red3[1][0][t], red3[0][1][t] + red3[1][1][t], red3[0][2][t] + red3[1][2][t], 0.f};
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
@@ -523,7 +604,8 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p) {
 // In the accumulator a lane is output channel (lane & 15) of a 16-channel group and holds four consecutive pixels 4 (lane >> 4) .. + 3 of a 16-pixel group.
 // ------------------------------------------------------------------------------------------------------------------------------------------
 template <int BM, int EPI>
-__global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p) {
+__global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_in) {
+    const FxConvParams p = fx_class_params(p_in);
     static_assert(BM == 128 || BM == 96 || BM == 64, "channel tile");
     constexpr int GA = 4, GB = BM / 32;                 // 16-pixel / 16-channel groups of a wave (2 x 2 waves; a wave: 64 pixels x BM / 2 channels)
     constexpr int WCH = BM / 2;
@@ -714,8 +796,13 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p)
             if (!split) {
                 if (p.bias) { const float bb = p.bias[m]; v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb; }
             }
-            if (dense) acc[a][b] = v;
-            else {
+            if (dense) {
+                if (p.emask && !split) {        // partial convolution: the result times the per-pixel renormalisation factor (before any statistics are taken of it)
+                    const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + oh) * p.YW + ow);
+                    v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
+                }
+                acc[a][b] = v;
+            } else {
                 float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
                 if (p.oxs == 1) {
                     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
@@ -870,7 +957,7 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // chunk is the pixel's one 32-B row, fetched at the tap's offset.  grid (taps / 8, K tiles, splits); slabs [split][k][taps * 16].
 template <bool AIMG, bool BIMG, bool MASKED, bool TAPS = false>
 __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
-    static_assert(!MASKED || (!AIMG && !BIMG), "the partial-convolution factors are applied by the in-kernel split");
+    static_assert(!MASKED || !AIMG || !BIMG, "the partial-convolution factors are applied by the in-kernel split of an fp32 operand (an image carries its factor already)");
     static_assert(!TAPS || BIMG, "tap-major columns come from an image operand");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * 3 * FX_PIECE];
@@ -921,8 +1008,8 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * (TAPS ? 16 : p.C) * HWi * 2);
     } else rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
-    const i32x4 rAM = fx_rsrc(MASKED ? p.amask : nullptr, MASKED ? (size_t)p.N * OHW * sizeof(float) : 0);
-    const i32x4 rBM = fx_rsrc(MASKED ? p.bmask : nullptr, MASKED ? (size_t)p.N * HWi * sizeof(float) : 0);
+    const i32x4 rAM = fx_rsrc(MASKED && !AIMG ? p.amask : nullptr, MASKED && !AIMG ? (size_t)p.N * OHW * sizeof(float) : 0);
+    const i32x4 rBM = fx_rsrc(MASKED && !BIMG ? p.bmask : nullptr, MASKED && !BIMG ? (size_t)p.N * HWi * sizeof(float) : 0);
     int a_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a_voff[i] = a_ok[i] ? ((m0 + row + 64 * i) * OHW + 4 * kq) * 4 : FX_OOB;
@@ -1440,6 +1527,7 @@ static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0
 // image-fed forward / data gradient on v_mfma_f32_16x16x32_bf16 (fx16_conv_kernel): -1 = environment (P3D_FX16), 0 never, 1 (default) where its 64- and 96-row
 // channel tiles fit the layer better than 128 rows, 2 everywhere (the A/B of the two MFMA shapes: profiles/r04_fx16.md -- at 128 rows the 16x16x32 form is 1-3 %
 // SLOWER on the large layers, 20 fragment reads per step against 12, and the chip holds no higher clock on it in these kernels)
+static int g_class_launches = 0;      // 1: one launch per parity class of a strided data gradient (the round-3 form; p3d_fx_tune(5, 1), A/B and tests)
 static int g_fx16 = -1;
 static int fx16_mode() {
     if (g_fx16 < 0) { const char* e = getenv("P3D_FX16"); g_fx16 = e ? atoi(e) : 1; if (g_fx16 < 0 || g_fx16 > 2) g_fx16 = 1; }
@@ -1456,6 +1544,7 @@ static int fx16_bm(int M, bool img, int pro, int epi) {
 }
 void fx_tune(int what, int value) {
     if (what == 3) { g_pair_map = value; return; }      // 0: the two opening image passes of a downsample block as two launches (A/B, tests)
+    if (what == 5) { g_class_launches = value ? 1 : 0; return; }
     if (what == 4) { g_fx16 = value < 0 || value > 2 ? 1 : value; return; }  // A/B of the two MFMA shapes in one process
     (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value;
 }
@@ -1585,7 +1674,7 @@ static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, in
 #undef P3D_FX16_CASE
 #define P3D_FX_CASE(AM, PRO, EPI) if (am == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
     P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 4)
-    P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2)
+    P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2) P3D_FX_CASE(1, 0, 3)
 #undef P3D_FX_CASE
 }
 
@@ -1678,6 +1767,13 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     const bool dsplit = d->stride == 1 && fx_dgrad_split(d).splits > 1;
+    if (fuse && fuse->tail_c) {
+        if (!(img && epi == 0 && pro == 0 && fx_dgrad_tail_applies(d) && fuse->tail_tab && fuse->tail_partial && (!fuse->tail_rc || fuse->tail_rtab))) {
+            set_error("fx_conv_dgrad: the tail sums need an image-fed, dense, unsplit stride-1 data gradient without a BatchNorm epilogue (fx_dgrad_tail_applies)"); return P3D_EINVAL;
+        }
+        epi = 3;
+        p.tail_c = fuse->tail_c; p.tail_tab = fuse->tail_tab; p.tail_rc = fuse->tail_rc; p.tail_rtab = fuse->tail_rtab; p.tail_mask = fuse->tail_mask; p.tail_partial = fuse->tail_partial;
+    }
     const int bm = fx16_bm(d->C, img, dsplit ? 0 : pro, dsplit ? 0 : epi);
     p.tiles_m = (int)ceil_div(d->C, bm ? bm : FX_BM);
     if (d->stride == 1) {
@@ -1703,6 +1799,8 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     p.OH = d->H / st2; p.OW = d->W / st2; p.NP = d->N * p.OH * p.OW; p.oys = st2; p.oxs = st2;
     p.hmul = 1; p.wmul = 1;
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
+    FxConvClass cls[4];
+    int ncls = 0;
     for (int ph = 0; ph < st2; ++ph)
         for (int pw = 0; pw < st2; ++pw) {
             int nr = 0, ns = 0, r0 = -1, r1 = -1, q0 = -1, q1 = -1;
@@ -1715,9 +1813,41 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
             c.hoff = th >= 0 ? th / st2 : -((-th) / st2); c.hstep = -(c.rstep * d->dil) / st2;
             c.woff = tw >= 0 ? tw / st2 : -((-tw) / st2); c.wstep = -(c.sstep * d->dil) / st2;
             c.oy0 = ph; c.ox0 = pw;
-            fx_launch_conv(c, img, pro, epi, bm, dim3((unsigned)(c.tiles_m * tiles_n), 1), st);
+            if (g_class_launches) { fx_launch_conv(c, img, pro, epi, bm, dim3((unsigned)(c.tiles_m * tiles_n), 1), st); continue; }
+            cls[ncls++] = FxConvClass{c.nR, c.nS, c.ntap, c.r0, c.rstep, c.s0, c.sstep, c.hoff, c.hstep, c.woff, c.wstep, c.oy0, c.ox0};
         }
+    if (ncls > 0) {
+        // one launch, the classes with the most taps in the lowest z (dispatched first: the short ones fill the tail)
+        for (int i = 1; i < ncls; ++i)
+            for (int j = i; j > 0 && cls[j].ntap > cls[j - 1].ntap; --j) { const FxConvClass t = cls[j]; cls[j] = cls[j - 1]; cls[j - 1] = t; }
+        p.ncls = ncls;
+        for (int i = 0; i < ncls; ++i) p.cls[i] = cls[i];
+        fx_launch_conv(p, img, pro, epi, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1, (unsigned)ncls), st);
+    }
     return check_launch("fx_conv_dgrad");
+}
+
+// The data gradient that writes a block's dx last can also reduce the opening sums of the producer block's backward pass (EPI 3 of fx_conv_kernel): dense rows
+// (stride 1), one launch (no split-K), channel tiles of 128 rows (the fx16 instances have no such epilogue), whole 16-B pixel groups
+bool fx_dgrad_tail_applies(const p3d_conv_desc* d) {
+    return fx_dgrad_applies(d, 96) && d->stride == 1 && fx_dgrad_split(d).splits == 1 && (d->H * d->W) % 4 == 0 && fx16_bm(d->C, true, 0, 0) == 0;
+}
+int fx_dgrad_tail_rows(const p3d_conv_desc* d) { return (int)ceil_div((int64_t)d->N * d->H * d->W, FX_BN); }
+// partial [rows][C][4] (fp32: sum g, sum g (c - mean), sum g (rc - rmean), 0) -> sums [C][out_rows][3] (fp64), row r of the output = rows r, r + out_rows, ... in order
+__global__ __launch_bounds__(64) void fx_tail_fold_kernel(const float* __restrict__ partial, int rows, int C, double* __restrict__ sums, int out_rows) {
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = r; i < rows; i += out_rows) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + ((size_t)i * C + c) * 4);
+        s0 += v[0]; s1 += v[1]; s2 += v[2];
+    }
+    double* dst = sums + ((size_t)c * out_rows + r) * 3;
+    dst[0] = s0; dst[1] = s1; dst[2] = s2;
+}
+int32_t fx_tail_fold(const float* partial, int rows, int C, double* sums, int out_rows, hipStream_t st) {
+    hipLaunchKernelGGL(fx_tail_fold_kernel, dim3((unsigned)ceil_div(C, 64), (unsigned)out_rows), dim3(64), 0, st, partial, rows, C, sums, out_rows);
+    return check_launch("fx_tail_fold");
 }
 
 // input pixels of a strided 1x1 that no tap reaches: fx_conv_dgrad leaves them untouched, so a caller that does not accumulate zero-fills dx first
@@ -1789,7 +1919,8 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
 // columns are the 16 x 16 (tap, channel) pairs (fx_wgrad_kernel<.., TAPS>).
 // ------------------------------------------------------------------------------------------------------------------------------------------
 // one thread per pixel of the half-resolution grid: 4 Cin input values -> three 32-B rows
-__global__ __launch_bounds__(256) void fx_s2d_image_kernel(const float* __restrict__ x, unsigned char* __restrict__ img, size_t plane_bytes, int N, int Cin, int H, int W) {
+__global__ __launch_bounds__(256) void fx_s2d_image_kernel(const float* __restrict__ x, const float* __restrict__ mask, unsigned char* __restrict__ img, size_t plane_bytes, int N,
+                                                           int Cin, int H, int W) {
     const int H2 = H >> 1, W2 = W >> 1;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)N * H2 * W2) return;
@@ -1802,7 +1933,11 @@ __global__ __launch_bounds__(256) void fx_s2d_image_kernel(const float* __restri
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
             if (c < Cin) {
-                const f32x2 q = *reinterpret_cast<const f32x2*>(x + (((size_t)n * Cin + c) * H + 2 * i2 + pi) * W + 2 * j2);
+                f32x2 q = *reinterpret_cast<const f32x2*>(x + (((size_t)n * Cin + c) * H + 2 * i2 + pi) * W + 2 * j2);
+                if (mask) {          // partial convolution (partial_conv.py:45): the operand is x * mask_in, one factor per pixel
+                    const f32x2 mq = *reinterpret_cast<const f32x2*>(mask + ((size_t)n * H + 2 * i2 + pi) * W + 2 * j2);
+                    q[0] *= mq[0]; q[1] *= mq[1];
+                }
                 v[c * 4 + pi * 2] = q[0]; v[c * 4 + pi * 2 + 1] = q[1];
             }
     unsigned hp[8], mp[8], lp[8];
@@ -1870,9 +2005,9 @@ size_t fx_stem_workspace(int N, int H, int W, int K) {
     return w2 > slabs ? w2 : slabs;
 }
 
-int32_t fx_stem_image(const float* x, void* img, int N, int Cin, int H, int W, hipStream_t st) {
+int32_t fx_stem_image(const float* x, const float* mask, void* img, int N, int Cin, int H, int W, hipStream_t st) {
     const long long total = (long long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(fx_s2d_image_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, x, (unsigned char*)img, (size_t)total * 32, N, Cin, H, W);
+    hipLaunchKernelGGL(fx_s2d_image_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, x, mask, (unsigned char*)img, (size_t)total * 32, N, Cin, H, W);
     return check_launch("fx_stem_image");
 }
 
@@ -1894,8 +2029,13 @@ static FxConvParams fx_stem_params(int N, int H, int W, int K) {
 }
 
 // y [N][K][H/2][W/2] = conv1(x) from the space-to-depth image of x and the restated weight image
-int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H, int W, int K, hipStream_t st) {
+bool fx_stem_masked_applies(int K) { return fx16_bm(K, true, 0, 0) != 0; }       // the per-pixel output factor lives in the fx16 kernel's epilogue
+int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, const float* mult, int N, int H, int W, int K, hipStream_t st) {
     FxConvParams p = fx_stem_params(N, H, W, K);
+    if (mult) {
+        if (!fx_stem_masked_applies(K)) { set_error("fx_stem_fwd: the output factor needs the fx16 kernel (K <= 64 or a 96-row fit, P3D_FX16 != 0)"); return P3D_EINVAL; }
+        p.emask = mult;
+    }
     p.Ximg = (const unsigned char*)x_img; p.plane_bytes = (size_t)N * (H / 2) * (W / 2) * 32;
     p.Wimg = (const unsigned char*)wimg; p.Y = y;
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
@@ -1906,8 +2046,8 @@ int32_t fx_stem_fwd(const void* x_img, const void* wimg, float* y, int N, int H,
 }
 
 // dw [K][Cin][7][7] (=|+=) from dy [N][K][H/2][W/2] (fp32) and the space-to-depth image of x
-int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace, size_t workspace_bytes,
-                      hipStream_t st) {
+int32_t fx_stem_wgrad(const float* dy, const float* mult, const void* x_img, float* dw, int N, int Cin, int H, int W, int K, int accumulate, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
     if (!workspace || workspace_bytes < fx_stem_workspace(N, H, W, K)) { set_error("fx_stem_wgrad: workspace %zu B < required %zu B", workspace_bytes, fx_stem_workspace(N, H, W, K)); return P3D_EWORKSPACE; }
     FxWgradParams p{};
     const int H2 = H / 2, W2 = W / 2;
@@ -1915,7 +2055,11 @@ int32_t fx_stem_wgrad(const float* dy, const void* x_img, float* dw, int N, int 
     p.N = N; p.K = K; p.C = 256; p.Hi = H2; p.Wi = W2; p.OH = H2; p.OW = W2; p.R = 4; p.S = 4; p.stride = 1; p.pad = 2; p.dil = 1;
     p.nsplit = fx_stem_splits(N, H, W);
     p.spb = (int)ceil_div((int64_t)N * (H2 * W2 / FX_BK), p.nsplit);
-    hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+    if (mult) {      // partial convolution: dw = wgrad(dy * mult, x * mask_in); the image holds x * mask_in, dy is scaled on its way into LDS
+        p.amask = mult;
+        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, true, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+    } else
+        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
     hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K, 4), dim3(1024), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
     return check_launch("fx_stem_wgrad");
 }

@@ -337,6 +337,10 @@ class Trainer:
 
     def test(self, epoch, test_loader):
         self.model.eval()
+        if os.environ.get('P3D_RELEASE_ON_EVAL'):          # evaluation needs none of the training plans' device memory (~13 GB for ResNet-50 at batch 64):
+            from . import ops_block                          # opt-in, because the next training epoch then re-allocates it (ops_block.release_buffers)
+            torch.cuda.synchronize()
+            ops_block.release_buffers(self.model)
         return self._run_test(epoch, test_loader, self.list_params[0].device)      # -do_teach evaluates the student (depth_train.py:613-614)
 
     # ---- distillation: the "privileged information" training (depth_train.py:107-129,161-283,641-647,682-691) --------

@@ -26,8 +26,9 @@ def env_ranks():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
-# The librccl build whose gfx950 code was disassembled (tools/scan_rccl.py -> profiles/r04_rccl_scan.txt): its ring kernels hold no packed-fp32 instruction,
-# its tree / PAT kernels do.  A collective may only run BESIDE the backward pass's MFMA kernels when the loaded library is this build and NCCL_ALGO pins the
+# The librccl build whose gfx950 code was disassembled (tools/scan_rccl.py -> profiles/r04_rccl_scan.txt; 4927 device functions): packed-fp32 instructions sit in
+# the fp32 TREE all-reduce (FuncSum, FuncProd, FuncPreMulSum), the PAT reduce-scatter and the ring kernels of FuncPreMulSum (ReduceOp.AVG / PREMUL_SUM) -- none in
+# the ring kernels of FuncSum, which is the only reduction GradReducer issues (ReduceOp.SUM; the 1 / world scale is folded into the Adam kernel).  A collective may only run BESIDE the backward pass's MFMA kernels when the loaded library is this build and NCCL_ALGO pins the
 # ring; otherwise GradReducer sends every bucket from finish(), after both streams have drained (no overlap, no kernel of RCCL shares a SIMD with an MFMA kernel).
 RCCL_SCANNED = {'bytes': 335927601, 'sha256': 'b7033b2627eca5365936296d9de858ad880308314c0d4f01a508e5f35ef8da32'}
 _overlap_verdict = None          # (ok, reason), decided once per process

@@ -21,6 +21,7 @@ class GraphedStep:
     buffers and replays the captured graph; returns the static loss tensor (device, valid until the next call)."""
 
     def __init__(self, trainer, warmup=3):
+        warmup = max(int(warmup), 1)       # (at least one eager step: it builds the plans, the weight-image job table and sizes every workspace OUTSIDE the capture)
         if trainer.world != 1 or trainer.reducer.active:
             raise RuntimeError('GraphedStep: whole-step capture is single-process only')
         self.trainer = trainer
@@ -35,6 +36,12 @@ class GraphedStep:
         tr = self.trainer
         self.static = tuple(None if t is None else t.clone() for t in batch)
         run = self._run
+        if self.graph is not None:
+            # re-capture: the events inside the buffer sets were last recorded in the old graph; eager warm-up steps must not wait on them
+            torch.cuda.synchronize()
+            from . import ops_block
+            ops_block.reset_side_events(tr.model)
+            self.graph = None
         # the eager warm-up steps must not train: parameters, Adam moments, step counters and BatchNorm buffers are put back afterwards,
         # so the first call of step() amounts to exactly one optimisation step (the first replay), like every later call
         opt = tr.optimizer
@@ -55,10 +62,20 @@ class GraphedStep:
             for dst, src in zip(tr.model.buffers(), saved_buffers):
                 dst.copy_(src)
         ops.weights_changed()          # the restore wrote flat_p under the parameter views; the capture below must contain the image rebuild of every weight
+        # Build the batched weight-image job table for "every convolution stale" NOW: its first use uploads the table from the host, which a capture does not
+        # allow (a single warm-up step only ever saw one-convolution tables, as each layer asked for its image for the first time).  Then mark the images stale
+        # again so that the captured step contains the rebuild.
+        from . import ops_block
+        ops_block._rebuild_stale_images(opt.flat_p.device)
+        ops.weights_changed()
         if tr.half_acc:
             from . import ops_half
             ops_half.refresh_weights(tr.model, opt.flat_p)
         torch.cuda.synchronize()
+        # The buffer sets' "last weight-gradient reader" events were recorded by the warm-up steps (or inside a PREVIOUS capture, when this is a re-capture after
+        # a learning-rate change): the device is idle now, so nothing has to wait for them, and a captured event must not be waited on from outside its graph.
+        from . import ops_block
+        ops_block.reset_side_events(tr.model)
         profile, ops.PROFILE = ops.PROFILE, None           # timing events cannot be recorded inside a capture
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -82,10 +99,12 @@ class GraphedStep:
         shapes = tuple(None if t is None else tuple(t.shape) for t in batch)
         if self.graph is None or shapes != self._shapes or self.trainer.optimizer.param_groups[0]['lr'] != self._lr:
             self._capture(batch)                           # warm-up steps are rolled back; the capture pass only records
-            self.graph.replay()
-            return self.loss
-        for dst, src in zip(self.static, batch):
-            if dst is not None:
-                dst.copy_(src, non_blocking=True)
+        else:
+            for dst, src in zip(self.static, batch):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replayed optimizer kernels changed the weights behind Python's back: whatever eager code runs next (an evaluation pass, the warm-up of a re-capture)
+        # must rebuild the weight images (the graph itself rebuilds them at its head on every replay)
+        ops.weights_changed()
         return self.loss

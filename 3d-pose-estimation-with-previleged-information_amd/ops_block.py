@@ -21,6 +21,12 @@ _vp = ctypes.c_void_p
 BLOCK_SIDE_STREAM = os.environ.get('P3D_BLOCK_SIDE', '1') != '0'
 # P3D_OUT_MASK=0: the backward pass reads the block's fp32 output for the closing ReLU's mask instead of the mask bytes forward leaves (p3d_block_io.out_mask = NULL)
 USE_OUT_MASK = os.environ.get('P3D_OUT_MASK', '1') != '0'
+# P3D_TAIL_SUMS=1 (opt-in, measured SLOWER: profiles/r04_summary.md section 3): a block takes the channel sums its backward pass opens with from the epilogue of the data
+# gradient that wrote dout (the consumer block's p3d_block_io.tail_*) instead of its own pass over dout (block_open_bwd).  13 of ResNet-50's 16 opening passes go away, but
+# the data gradient's epilogue then waits on uncoalesced reads of c_last / c_ds / the mask bytes: the step is 0.2 - 0.4 ms LONGER.  Kept tested, off by default.
+USE_TAIL_SUMS = os.environ.get('P3D_TAIL_SUMS', '0') == '1'
+TAIL_ROWS = 16                   # P3D_TAIL_ROWS
+TAIL_STATS = {'reduced': 0, 'opening_passes_skipped': 0}     # (tests: how often a consumer reduced its producer's sums / a producer found them valid)
 
 
 class BlockDesc(ctypes.Structure):
@@ -34,7 +40,9 @@ class BlockIO(ctypes.Structure):
     """struct p3d_block_io"""
     _fields_ = [('x', _vp), ('out', _vp), ('w', _vp * 4), ('wimg', _vp * 4), ('wimgT', _vp * 4), ('c', _vp * 4), ('aimg', _vp * 4), ('table', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcimg', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
-                ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('out_mask', _vp)]
+                ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('out_mask', _vp),
+                ('tail_c_last', _vp), ('tail_table_last', _vp), ('tail_c_ds', _vp), ('tail_table_ds', _vp), ('tail_mask', _vp), ('tail_partial', _vp), ('tail_sums', _vp),
+                ('open_sums', _vp)]
 
 
 def _one(v):
@@ -82,6 +90,10 @@ class _Plan:
         self.table_rows = sum(ks)
         self.slots = [slot for slot, _, _ in _layers(block)]
         self.sets = []                  # _Buffers owned by this plan (see there)
+        # as a consumer: can this block's backward pass reduce the opening sums of the block that produced its input? (p3d_block_io.tail_*)
+        self.tail_ok = bool(self.ok and lib().p3d_block_tail_supported(ctypes.byref(d)))
+        self.tail_bytes = int(lib().p3d_block_tail_partial_bytes(ctypes.byref(d))) if self.tail_ok else 0
+        self.in_shape = tuple(x_shape)
 
     def acquire(self, device):
         """A free buffer set (or a new one).  Two are kept per plan (a block that runs twice before its backward: labelled + unlabelled batch of semi_train);
@@ -110,6 +122,8 @@ class _Buffers:
 
     def __init__(self, plan, device):
         self.device, self.held, self.side_done, self.bwd = device, False, None, None
+        self.tail = None                # (partial scratch, sums [C][TAIL_ROWS][3] fp64): where a consumer block leaves this block's opening sums
+        self.open_ready = None          # (data_ptr, _version) of the gradient tensor those sums were reduced over
         f32 = dict(dtype=torch.float32, device=device)
         self.tables = torch.empty((plan.table_rows, 8), **f32)
         self.c = {slot: torch.empty(plan.shapes[slot], **f32) for slot in plan.slots}
@@ -125,6 +139,12 @@ class _Buffers:
             _spare_shapes.add(key)
             spare = [torch.empty(plan.out_shape, **f32) for _ in range(3)]
             del spare
+
+    def tail_buffers(self, plan, nbytes):
+        if self.tail is None or self.tail[0].numel() < nbytes:
+            self.tail = (torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                         torch.empty((plan.out_shape[1], TAIL_ROWS, 3), dtype=torch.float64, device=self.device))
+        return self.tail
 
     def backward_scratch(self, plan):
         if self.bwd is None:
@@ -280,6 +300,38 @@ class _Transient(dict):
         return (_Transient, ())
 
 
+def _buffer_sets(model):
+    """Every buffer set (_Buffers, _OwnedBuffers) the modules of `model` own."""
+    for module in model.modules():
+        for plan in (module.__dict__.get('_blk_plans') or {}).values():
+            for b in plan.sets:
+                yield b
+        for sets in (module.__dict__.get('_owned_bufs') or {}).values():
+            for b in sets:
+                yield b
+
+
+def reset_side_events(model):
+    """Forget the "last reader on the weight-gradient stream" events of every buffer set.  Call with the device idle (after a synchronize): an event last recorded
+    INSIDE a stream capture must not be waited on by eager work or by the next capture (graphed.GraphedStep re-captures on every learning-rate change)."""
+    for b in _buffer_sets(model):
+        b.side_done = None
+
+
+def release_buffers(model):
+    """Give the plan-owned device memory of `model` back to the allocator (forward buffers, activation / gradient images, backward scratch: ~13 GB for ResNet-50 at
+    batch 64): for a caller that switches to evaluation or ends an epoch and wants the memory; the next training step builds the plans again.
+    Buffer sets still held by a live autograd graph stay alive with it.  Returns the number of plans dropped."""
+    dropped = 0
+    for module in model.modules():
+        for name in ('_blk_plans', '_owned_bufs'):
+            cache = module.__dict__.get(name)
+            if cache:
+                dropped += len(cache)
+                cache.clear()
+    return dropped
+
+
 def plan_for(block, x):
     cache = block.__dict__.get('_blk_plans')
     if cache is None:
@@ -323,6 +375,9 @@ class ResidualBlockFn(torch.autograd.Function):
         io.out = out.data_ptr()
         bufs = plan.acquire(x.device)
         lease = _Lease(bufs)
+        bufs.open_ready = None
+        # the block whose output this input is (residual_block tags its result): its buffers, for the tail sums of backward
+        ctx.producer = getattr(x, '_p3d_block_out', None) if (USE_TAIL_SUMS and plan.tail_ok) else None
         tables, cs, acts, row = bufs.tables, bufs.c, bufs.act, 0
         if bufs.mask is not None:
             io.out_mask = bufs.mask.data_ptr()
@@ -345,6 +400,7 @@ class ResidualBlockFn(torch.autograd.Function):
         ctx.block, ctx.plan = block, plan
         ctx.saved = (lease, bufs)                          # (a plain attribute: the plan's buffers are never inputs / outputs of another node)
         ctx.save_for_backward(x, out)
+        block.__dict__['_last_exec'] = (bufs, plan)        # residual_block() tags the returned tensor with it
         return out
 
     @staticmethod
@@ -372,6 +428,34 @@ class ResidualBlockFn(torch.autograd.Function):
         io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
         if bufs.mask is not None:
             io.out_mask = bufs.mask.data_ptr()
+        # This block as the producer: the block that consumed `out` reduced the opening sums over the gradient it wrote -- valid if that very tensor arrives here
+        # untouched (another consumer's gradient would have been added by autograd: a new tensor, or an in-place add that bumps the version).
+        if bufs.open_ready is not None and bufs.open_ready == (dout.data_ptr(), dout._version) and bufs.tail is not None:
+            io.open_sums = bufs.tail[1].data_ptr()
+            TAIL_STATS['opening_passes_skipped'] += 1
+        bufs.open_ready = None
+        # This block as the consumer: hand the producer's tensors to the data gradient that writes dx last.
+        prod = ctx.producer
+        ctx.producer = None
+        tail_for = None
+        if prod is not None and need_dx:
+            pb, pp = prod
+            plast = pp.desc.nconv - 1
+            if pb.held and pp.out_shape == plan.in_shape and pb.device == x.device and (pb.mask is not None) == bool(pp.desc.relu_out):
+                prow = 0
+                ptab = {}
+                for slot in pp.slots:
+                    ptab[slot] = pb.tables.data_ptr() + prow * 32
+                    prow += pp.shapes[slot][1]
+                scratch, sums = pb.tail_buffers(pp, plan.tail_bytes)
+                io.tail_c_last, io.tail_table_last = pb.c[plast].data_ptr(), ptab[plast]
+                if pp.desc.has_downsample:
+                    io.tail_c_ds, io.tail_table_ds = pb.c[3].data_ptr(), ptab[3]
+                if pb.mask is not None:
+                    io.tail_mask = pb.mask.data_ptr()
+                io.tail_partial, io.tail_sums = scratch.data_ptr(), sums.data_ptr()
+                tail_for = pb
+                TAIL_STATS['reduced'] += 1
         row = 0
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
@@ -413,6 +497,8 @@ class ResidualBlockFn(torch.autograd.Function):
             sws = ops._second_workspace(x.device, plan.side_bytes)
             side_handle = None
         check(L.p3d_block_bwd(ctypes.byref(desc), ctypes.byref(io), ops._p(ws), ws.numel(), ops._p(sws), sws.numel(), ops._stream(), side_handle), 'p3d_block_bwd')
+        if tail_for is not None and dx is not None:
+            tail_for.open_ready = (dx.data_ptr(), dx._version)      # the producer's backward checks that this is what it receives
         if two:
             x.record_stream(side)          # the one allocator-owned tensor the second stream reads (first conv's and the downsample's weight gradients)
             if bufs.side_done is None:
@@ -430,7 +516,11 @@ def residual_block(block, x):
     params = []
     for _, conv, bn in _layers(block):
         params += [conv.weight, bn.weight, bn.bias]
-    return ResidualBlockFn.apply(x, block, *params)
+    out = ResidualBlockFn.apply(x, block, *params)
+    last = block.__dict__.pop('_last_exec', None)
+    if last is not None and USE_TAIL_SUMS:
+        out._p3d_block_out = last        # a consumer block that receives THIS tensor object as its input may reduce our opening sums in its backward pass
+    return out
 
 
 # ---- a single convolution on image operands (the 3x3 `regressor` behind layer4: depthnet.py:156,199) ------------------------------------------------------
@@ -538,13 +628,20 @@ def conv2d_images(conv, x):
 
 
 # ---- the stem conv1 (7x7, stride 2, Cin = 3 or 1: depthnet.py:138) on the x3 kernels -------------------------------------------------------------------------
-def stem_takes_x3(conv, x):
-    if not (IMAGE_CONVS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv).__name__ == 'Conv2d' and conv.bias is None):
+def stem_takes_x3(conv, x, masked=False):
+    """conv1 on the restated stem kernels?  masked: as a partial convolution (PartialConv stems of partial_depthnet / partial_fusionnet: per-pixel factors)."""
+    if not (IMAGE_CONVS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv).__name__ == ('PartialConv' if masked else 'Conv2d') and conv.bias is None):
         return False
     if (conv.kernel_size[0], _one(conv.stride), _one(conv.padding), _one(conv.dilation)) != (7, 2, 3, 1) or conv.in_channels > 4:
         return False
     n, c, h, w = x.shape
+    if masked:
+        return MASKED_STEM and bool(lib().p3d_stem_masked_supported(n, c, h, w, conv.out_channels))
     return bool(lib().p3d_stem_supported(n, c, h, w, conv.out_channels))
+
+
+# P3D_MASKED_STEM=0: the 1-channel partial-convolution stems stay on the fp32-MFMA kernel (the round-3 path; A/B)
+MASKED_STEM = os.environ.get('P3D_MASKED_STEM', '1') != '0'
 
 
 def stem_weight_image(conv):
@@ -566,7 +663,9 @@ class StemConvFn(torch.autograd.Function):
     """conv1(x): the space-to-depth image of the batch is built once in forward and read again by the weight gradient (no data gradient: x is the input)."""
 
     @staticmethod
-    def forward(ctx, x, conv, w):
+    def forward(ctx, x, conv, w, mask_in=None, mult=None):
+        """mask_in [N,1,H,W] / mult [N,1,H/2,W/2]: the partial-convolution stem (partial_conv.py:45-52): y = conv(x * mask_in) * mult; the input factor goes into
+        the space-to-depth image, the output factor into the forward epilogue and, in backward, onto dy as the weight gradient fetches it."""
         if x.requires_grad:
             raise P3DError('StemConvFn: a data gradient for the network input is not implemented (the reference never asks for one)')
         x = x.contiguous()
@@ -576,10 +675,15 @@ class StemConvFn(torch.autograd.Function):
         bufs = _owned(conv, ('stem', tuple(x.shape)), x.device)
         ctx.lease = _Lease(bufs)
         x_img = bufs.tensor('x', L.p3d_stem_image_bytes(n, h, wd))
-        check(L.p3d_stem_image(ops._p(x), ops._p(x_img), n, c, h, wd, ops._stream()), 'p3d_stem_image')
+        if mask_in is not None:
+            mask_in, mult = mask_in.contiguous(), mult.contiguous()
+            assert tuple(mask_in.shape) == (n, 1, h, wd) and tuple(mult.shape) == (n, 1, h // 2, wd // 2) and mask_in.dtype == mult.dtype == torch.float32
+        check(L.p3d_stem_image_masked(ops._p(x), ops._p(mask_in) if mask_in is not None else None, ops._p(x_img), n, c, h, wd, ops._stream()), 'p3d_stem_image')
         y = torch.empty((n, k, h // 2, wd // 2), dtype=torch.float32, device=x.device)
-        check(L.p3d_stem_fwd(ops._p(x_img), ops._p(stem_weight_image(conv)), ops._p(y), n, c, h, wd, k, ops._stream()), 'p3d_stem_fwd')
+        check(L.p3d_stem_fwd_masked(ops._p(x_img), ops._p(stem_weight_image(conv)), ops._p(y), ops._p(mult) if mult is not None else None, n, c, h, wd, k, ops._stream()),
+              'p3d_stem_fwd')
         ctx.conv, ctx.shape = conv, (n, c, h, wd, k)
+        ctx.mult = mult
         ctx.save_for_backward(x_img)
         return y
 
@@ -591,6 +695,8 @@ class StemConvFn(torch.autograd.Function):
         L = lib()
         dy = dy.contiguous()
         dw = None
+        mult = ctx.mult
+        mp = ops._p(mult) if mult is not None else None
         lease, ctx.lease = ctx.lease, None
         if lease is None:
             raise P3DError('stem_conv: backward called a second time on the same graph; run the forward again')
@@ -605,17 +711,20 @@ class StemConvFn(torch.autograd.Function):
                 side.wait_event(dy_ready)
                 sws = ops._side_workspace(dy.device, nbytes)
                 with torch.cuda.stream(side):
-                    check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
+                    check(L.p3d_stem_wgrad_masked(ops._p(dy), mp, ops._p(x_img), ops._p(dw), n, c, h, wd, k, 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
                 dy.record_stream(side)                      # (allocator-owned: the stem BatchNorm's data gradient)
+                if mult is not None:
+                    mult.record_stream(side)
                 lease.bufs.mark_side(side)
             else:
                 sws = ops.workspace(dy.device, nbytes)
-                check(L.p3d_stem_wgrad(ops._p(dy), ops._p(x_img), ops._p(dw), n, c, h, wd, k, 0 if sink is None else 1, ops._p(sws), sws.numel(), ops._stream()), 'p3d_stem_wgrad')
+                check(L.p3d_stem_wgrad_masked(ops._p(dy), mp, ops._p(x_img), ops._p(dw), n, c, h, wd, k, 0 if sink is None else 1, ops._p(sws), sws.numel(), ops._stream()),
+                      'p3d_stem_wgrad')
             if sink is not None:
                 dw = None
                 ops._grad_done(w)
-        return None, None, dw
+        return None, None, dw, None, None
 
 
-def stem_conv(conv, x):
-    return StemConvFn.apply(x, conv, conv.weight)
+def stem_conv(conv, x, mask_in=None, mult=None):
+    return StemConvFn.apply(x, conv, conv.weight, mask_in, mult)

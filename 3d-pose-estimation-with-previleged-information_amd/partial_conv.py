@@ -8,7 +8,7 @@ operand gather and the renormalisation in its epilogue, so only the tiny box-sum
 """
 import torch
 
-from . import ops
+from . import ops, ops_block
 from .nn import Conv2d, _one
 
 
@@ -29,7 +29,10 @@ class PartialConv(Conv2d):
             mult, mask_out = ops.mask_count(mask_in, k, stride, pad, dil)    # partial_conv.py:35-43
         if self.bias is not None and self.bias.requires_grad and torch.is_grad_enabled() and input.dtype == torch.float16:
             raise ops.P3DError('PartialConv with a trainable bias under -half_acc: backward is not implemented (no reference network uses it)')
-        if input.dtype == torch.float16:                                    # -half_acc: masks stay fp32 [B,1,H,W], activations NHWC fp16
+        if input.dtype == torch.float32 and not input.requires_grad and join_put is None and join_take is None and ops_block.stem_takes_x3(self, input, masked=True):
+            # the 7x7 stride-2 stem of the partial families (partial_depthnet.py:177): the restated stem kernels with the two per-pixel factors
+            output = ops_block.stem_conv(self, input, mask_in.contiguous(), mult)
+        elif input.dtype == torch.float16:                                    # -half_acc: masks stay fp32 [B,1,H,W], activations NHWC fp16
             from . import ops_half
             output = ops_half.conv2d(input, self, stride, pad, dil, join_put, join_take, mask_in=mask_in.contiguous(), mult=mult)
         else:

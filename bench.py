@@ -325,11 +325,16 @@ def main():
                     'x3_flop_fraction': round(x3_fl / max(x3_fl + fp_fl, 1.0), 4)}
         # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic.sh -> profiles/r02_traffic.json);
         # a profiler cannot run inside the timed region, so the committed measurement of the same workload is quoted
-        traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_traffic.json' % r) for r in (3, 2)) if os.path.exists(q)), '')
+        traffic, traffic_source = None, None
+        tpath = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_traffic.json' % r) for r in (4, 3, 2)) if os.path.exists(q)), '')
         if os.path.exists(tpath) and opt.model == 'resnet50' and opt.batch == 64 and opt.family == 'depthnet' and not opt.half:
             with open(tpath) as f:
-                traffic = round(json.load(f)['bytes_per_launch'])
+                tj = json.load(f)
+            traffic = round(tj['bytes_per_launch'])
+            # where the number comes from: a committed PMC measurement of this workload, NOT this run (a reader can see when it is older than the kernels)
+            traffic_source = {'file': os.path.relpath(tpath, ROOT), 'measured_at_commit': tj.get('commit'),
+                              'algorithmic_bytes_per_launch': round(tj['algorithmic_bytes_per_launch']) if 'algorithmic_bytes_per_launch' in tj else None,
+                              'by_pass_ratio_measured_over_algorithmic': {k: v['ratio'] for k, v in tj.get('by_pass', {}).items()} or None}
         is_contract = opt.model == 'resnet50' and opt.family == 'depthnet'
         gflop_crop = R50_FWD_BWD_GFLOP_PER_CROP if is_contract else conv_flops / 1e9 / (opt.batch * ksteps)
         achieved = gflop_crop * opt.batch * ksteps / conv_total_ms             # GFLOP/ms == TFLOP/s
@@ -355,7 +360,7 @@ def main():
                          'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'peak_note': 'dense f16 MFMA peak' if opt.half else ('fp32-equivalent ceiling of the pipe the kernel runs on: 2500 TFLOP/s dense bf16 / 6 piece products' if x3_on else 'dense fp32 MFMA peak'),
                          'frac_of_fp32_mfma_peak': None if opt.half else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'fp32_mfma_peak': FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': traffic, 'launches_per_step': launches,
+                         'traffic': traffic, 'traffic_source': traffic_source, 'launches_per_step': launches,
                          'avg_launch_ms': round(conv_total_ms / max(nlaunch, 1), 4),
                          'conv_ms_per_step': {k: round(v / ksteps, 3) for k, v in conv_ms.items()},
                          'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1),

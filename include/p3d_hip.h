@@ -169,7 +169,24 @@ typedef struct p3d_block_io {
     /* forward + backward, optional (NULL: backward reads `out`): one byte per four consecutive output elements, bit e = [out[4 i + e] > 0]; written by
        p3d_block_fwd of a block that ends in a ReLU, read by p3d_block_bwd instead of `out` (N * K_last * Ho * Wo / 4 bytes) */
     unsigned char* out_mask;
+    /* backward only, optional: the block whose OUTPUT is this block's input x (the "producer").  When given -- and p3d_block_tail_supported(b) -- the data gradient
+       that writes this block's dx last also reduces, in its epilogue, the channel sums the producer's backward pass opens with (sum g, sum g (c - mean) of its closing
+       BatchNorm and of its downsample BatchNorm, g = dx * [producer's out > 0]), and a small fold kernel leaves them in tail_sums: the producer's p3d_block_bwd, handed
+       the same buffer as open_sums, then skips its opening pass over dout (8 - 12 bytes per element).  Valid only if dx reaches the producer unchanged (no other
+       consumer of the producer's output adds a gradient): the caller checks that. */
+    const float* tail_c_last;       /* producer's c[last] */
+    const float* tail_table_last;   /* producer's table[last] */
+    const float* tail_c_ds;         /* producer's c[3] / table[3], or NULL (no downsample branch) */
+    const float* tail_table_ds;
+    const unsigned char* tail_mask; /* producer's out_mask, or NULL (its block does not end in a ReLU) */
+    float* tail_partial;            /* scratch, p3d_block_tail_partial_bytes(b) */
+    double* tail_sums;              /* [C_in][P3D_TAIL_ROWS][3], written here */
+    const double* open_sums;        /* this block as the producer: the sums a consumer's backward left (its tail_sums), or NULL: the opening pass computes them */
 } p3d_block_io;
+#define P3D_TAIL_ROWS 16
+/* 1 when p3d_block_bwd(b) can compute its producer's opening sums (io->tail_*): dx needed, and its last writer a dense, unsplit stride-1 data gradient on image operands */
+int32_t p3d_block_tail_supported(const p3d_block_desc* b);
+size_t p3d_block_tail_partial_bytes(const p3d_block_desc* b);
 
 /* 1 when every convolution of the block can run on the fused kernels (dense, channel counts in steps of 16 and >= 64, four-pixel-aligned rows, maps of a
  * multiple of 16 pixels, stride <= 2 and never on a 1x1 of the main chain) */
@@ -247,6 +264,13 @@ int32_t p3d_stem_weight_image(const float* w, int32_t K, int32_t Cin, void* wimg
 int32_t p3d_stem_fwd(const void* x_img, const void* wimg, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream);
 int32_t p3d_stem_wgrad(const float* dy, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same stem as a PARTIAL convolution (partial_conv.py:32-57; partial_depthnet.py:177, partial_fusionnet.py: conv(x * mask_in) * mult): mask_in [N][1][H][W] is multiplied
+ * into the space-to-depth image, mult [N][1][H/2][W/2] scales the result in the forward epilogue and dy on its way into the weight gradient.  NULL factors = the dense stem. */
+int32_t p3d_stem_masked_supported(int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K);
+int32_t p3d_stem_image_masked(const float* x, const float* mask_in, void* img, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream);
+int32_t p3d_stem_fwd_masked(const void* x_img, const void* wimg, float* y, const float* mult, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, void* stream);
+int32_t p3d_stem_wgrad_masked(const float* dy, const float* mult, const void* x_img, float* dw, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t K, int32_t accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */

@@ -377,3 +377,67 @@ def test_pair_image_pass_equals_two_passes(pkg):
     assert torch.equal(res[1]['y'], res[0]['y']) and torch.equal(res[1]['dx'], res[0]['dx'])
     for n, g in res[1]['grads'].items():
         assert torch.equal(g, res[0]['grads'][n]), n
+
+
+@pytest.mark.parametrize('consumer', ['identity', 'downsample_s1', 'downsample_s2'])
+def test_opening_sums_from_the_consumer_blocks_epilogue(pkg, consumer):
+    """A chain of two blocks: the second block's backward pass reduces the channel sums the FIRST block's backward pass opens with (sum g, sum g (c - mean) of its
+    closing and downsample BatchNorm over g = dout [out > 0]) in the epilogue of the data gradient that writes dout, so the first block skips its pass over dout
+    (p3d_block_io.tail_* / open_sums; depthnet.py:101-116 and its autograd).  Same gradients as with the opening pass (P3D_TAIL_SUMS=0) to fp32 summation-order
+    accuracy; a strided downsample consumer cannot do it (its last dx writer is not dense) and a second consumer of the tensor invalidates the sums."""
+    ob = pkg.ops_block
+    torch.manual_seed(5)
+    first = build(pkg, 'bottleneck', 128, 64, 1, 1, True, 3)                       # output 256 channels, with a downsample branch (three sums)
+    if consumer == 'identity':
+        second = build(pkg, 'bottleneck', 256, 64, 1, 1, False, 4)
+    elif consumer == 'downsample_s1':
+        second = build(pkg, 'bottleneck', 256, 128, 1, 2, True, 4)
+    else:
+        second = build(pkg, 'bottleneck', 256, 128, 2, 1, True, 4)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    x0 = torch.randn(6, 128, 32, 32, device='cuda', generator=gen)
+
+    def step(tail, extra_consumer=False):
+        keep = ob.USE_TAIL_SUMS
+        ob.USE_TAIL_SUMS = tail
+        try:
+            for blk in (first, second):
+                blk.zero_grad(set_to_none=True)
+            state = [{k: v.clone() for k, v in blk.state_dict().items()} for blk in (first, second)]
+            x = x0.clone().requires_grad_(True)
+            mid = first(x)
+            y = second(mid)
+            loss = (y * dy).sum() + ((mid * 0.5).sum() if extra_consumer else 0.0)
+            loss.backward()
+            pkg.ops.join_side_stream()
+            torch.cuda.synchronize()
+            res = {'dx': x.grad.clone()}
+            for tag, blk in (('a.', first), ('b.', second)):
+                res.update({tag + n: p.grad.clone() for n, p in blk.named_parameters()})
+            for blk, st in zip((first, second), state):
+                blk.load_state_dict(st)
+            return res
+        finally:
+            ob.USE_TAIL_SUMS = keep
+
+    with torch.no_grad():
+        dy = torch.randn(second(first(x0)).shape, device='cuda', generator=gen)
+    base = step(False)
+    before = dict(ob.TAIL_STATS)
+    fused = step(True)
+    did = {k: ob.TAIL_STATS[k] - before[k] for k in before}
+    if consumer == 'downsample_s2':
+        assert did == {'reduced': 0, 'opening_passes_skipped': 0}
+    else:
+        assert did == {'reduced': 1, 'opening_passes_skipped': 1}, did
+    for k in base:
+        scale = base[k].abs().max().item()
+        assert (fused[k] - base[k]).abs().max().item() <= 2e-5 * scale, (k, (fused[k] - base[k]).abs().max().item(), scale)
+    if consumer != 'downsample_s2':
+        # a second consumer of the first block's output: autograd adds its gradient to the second block's dx, the sums no longer describe what arrives
+        base2 = step(False, extra_consumer=True)
+        before = dict(ob.TAIL_STATS)
+        fused2 = step(True, extra_consumer=True)
+        assert ob.TAIL_STATS['opening_passes_skipped'] == before['opening_passes_skipped']
+        for k in base2:
+            assert (fused2[k] - base2[k]).abs().max().item() <= 2e-5 * base2[k].abs().max().item(), k

@@ -793,3 +793,51 @@ def test_extra_channel_stem_forward_backward(pkg):
     assert np.abs(host(model.bn1.weight.grad) - dgamma).max() < 5e-5 * np.abs(dgamma).max()
     assert np.abs(host(model.bn1.bias.grad) - dbeta).max() < 5e-5 * np.abs(dbeta).max()
     assert np.abs(host(model.conv1.weight.grad) - dw).max() < 1e-4 * np.abs(dw).max()
+
+
+def test_large_filter_weight_gradient_with_deep_split(pkg):
+    """An 11x11 filter whose weight gradient is cut into more than 16 slabs (forced): the one-launch slab sum needs 17 * 121 * 16 floats of LDS (> 64 KB), so the call
+    must take the fold + reduce pair instead of a launch that cannot start; against the float64 oracle."""
+    ops = pkg.ops
+    L = pkg._lib.lib()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((10, 64, 16, 16)).astype(np.float32)
+    wt = (rng.standard_normal((96, 64, 11, 11)) / np.sqrt(64 * 121)).astype(np.float32)
+    dy = rng.standard_normal((10, 96, 16, 16)).astype(np.float32)
+    xt, wtt = dev(x).requires_grad_(True), dev(wt).requires_grad_(True)
+    L.p3d_fx_tune(0, 20)
+    try:
+        y = ops.conv2d(xt, wtt, None, 1, 5, 1)
+        y.backward(dev(dy))
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        L.p3d_fx_tune(0, 0)
+    assert relerr(host(wtt.grad), ref.conv2d_wgrad(dy, x, wt.shape, 1, 5, 1)) < 2e-5
+
+
+@pytest.mark.parametrize('case', [(3, 1, 64, 64), (2, 1, 128, 96)], ids=lambda c: 'n%d_c%d_%dx%d' % c)
+def test_partial_conv_stem_on_the_restated_kernels(case, pkg):
+    """The 1-channel PartialConv stem of the partial families (partial_depthnet.py:177: PartialConv(1, 64, 7, stride 2, padding 3); partial_conv.py:32-57) on the
+    restated stem kernels: mask_in is multiplied into the space-to-depth image, mult scales the result in the forward epilogue and dy as the weight gradient fetches
+    it.  Forward, mask_out and the weight gradient against the float64 oracle; a general 0/1 mask (not only x != 0) and pixels whose whole window is masked."""
+    n, cin, h, w = case
+    conv = pkg.partial_conv.PartialConv(cin, 64, kernel_size=7, stride=2, padding=3, bias=False).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(n + h)
+    x = torch.randn(n, cin, h, w, device='cuda', generator=gen)
+    mask = (torch.rand(n, 1, h, w, device='cuda', generator=gen) > 0.35).float()
+    mask[0, 0, :24, :24] = 0.0                                                    # windows without a single valid pixel: mult = 0 there
+    assert pkg.ops_block.stem_takes_x3(conv, x, masked=True)
+    y, mask_out = conv(x, mask)
+    assert type(y.grad_fn).__name__.startswith('StemConvFn')
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    y.backward(dy)
+    pkg.ops.join_side_stream()
+    torch.cuda.synchronize()
+    xh, mh, wh, dyh = host(x), host(mask), host(conv.weight), host(dy)
+    want_y, want_mo, mult = ref.partial_conv_fwd(xh, mh, wh, None, 2, 3, 1)
+    _, want_dw = ref.partial_conv_bwd(dyh, xh, mh, wh, mult, 2, 3, 1)
+    assert np.array_equal(host(mask_out), want_mo)
+    assert np.abs(host(y) - want_y).max() < 2e-5 * np.abs(want_y).max()
+    assert np.all(host(y)[0, :, :9, :9] == 0.0)                                   # fully masked windows give exact zeros
+    assert np.abs(host(conv.weight.grad) - want_dw).max() < 5e-5 * np.abs(want_dw).max()

@@ -151,6 +151,41 @@ def test_whole_step_graph_capture_matches_eager(pkg):
         assert torch.allclose(v.detach().cpu().float(), eager[k].float(), rtol=1e-5, atol=1e-7), k
 
 
+def test_graph_recapture_after_a_learning_rate_change(pkg):
+    """GraphedStep re-captures when adapt_learn_rate changes the learning rate (depth_train.py:637-638).  The buffer sets of the block executor carry events that
+    were last recorded inside the FIRST capture; the re-capture (eager warm-up steps, then a new capture) must neither wait on them nor fail, and the two
+    replayed steps must equal two eager steps with the same learning rates."""
+    g = np.load(golden_path('step_depth_r18_b2.npz'))
+    meta = json.loads(str(g['meta']))
+    batches = []
+    for it in range(2):
+        c, d, tc, tv = pkg.synth.make_batch(2, side=meta['side'], rank=0, step=it)
+        batches.append((torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+    args, model, trainer = build(pkg, meta)
+    model.train()
+    for i, epoch in enumerate((1, 2)):                     # epoch 1: warm-up rate (x 0.2), epoch 2: the full rate
+        trainer.adapt_learn_rate(epoch)
+        keep = trainer.optimizer.clip_and_step
+        trainer.optimizer.clip_and_step = lambda m, grad_scale=1.0: trainer.optimizer.clip_and_step_dev(m, grad_scale, skip_nonfinite=False)
+        trainer.train_step(*batches[i])
+        trainer.optimizer.clip_and_step = keep
+    eager = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    args, model2, trainer2 = build(pkg, meta)
+    model2.train()
+    graphed = pkg.graphed.GraphedStep(trainer2, warmup=1)
+    lrs = []
+    for i, epoch in enumerate((1, 2)):
+        trainer2.adapt_learn_rate(epoch)
+        lrs.append(trainer2.optimizer.param_groups[0]['lr'])
+        graphed.step(*batches[i])
+    torch.cuda.synchronize()
+    assert lrs[0] != lrs[1]
+    assert trainer2.optimizer.steps_taken() == 2
+    for k, v in model2.state_dict().items():
+        assert torch.allclose(v.detach().cpu().float(), eager[k].float(), rtol=1e-5, atol=1e-7), k
+    assert pkg.ops_block.release_buffers(model2) > 0        # the plans' device memory can be handed back (and is rebuilt by the next step)
+
+
 @pytest.mark.parametrize('extra', [[], ['-half_acc']], ids=['fp32', 'half'])
 def test_training_reduces_the_loss_on_a_fixed_batch(extra, pkg):
     """End-to-end sanity at the contract's input size: 40 optimisation steps on one batch of 8 crops bring the loss from ~32 to ~9

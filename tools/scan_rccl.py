@@ -4,7 +4,7 @@ The gradient all-reduce runs beside the backward pass's MFMA kernels on purpose,
 another queue's MFMA kernel shares the SIMD (profiles/r03_summary.md section 7).  dist.py only lets a bucket's collective overlap the backward pass when the
 librccl that torch loads is the build this scan was run on (sha256 below) and NCCL_ALGO pins the ring kernels, which the scan shows free of such instructions.
 
-Reads the library as a file (every `__CLANG_OFFLOAD_BUNDLE__` in .hip_fatbin, the gfx950 entries), writes temporaries under $TMPDIR only.
+Reads the library as a file (llvm-objcopy of .hip_fatbin -> clang-offload-bundler --unbundle of the gfx950 entry -> llvm-objdump -d), writes temporaries under $TMPDIR only.
 usage: python tools/scan_rccl.py [path to librccl.so] > profiles/r04_rccl_scan.txt"""
 import collections, hashlib, os, re, struct, subprocess, sys, tempfile
 
@@ -36,41 +36,40 @@ def main():
     funcs_total = 0
     objects = 0
     examples = collections.defaultdict(list)
+    llvm = os.path.dirname(OBJDUMP)
     with tempfile.TemporaryDirectory() as tmp:
-        for m in re.finditer(MAGIC, data):
-            base = m.start()
-            n = struct.unpack_from('<Q', data, base + 24)[0]
-            pos = base + 32
-            for _ in range(n):
-                off, size, tl = struct.unpack_from('<QQQ', data, pos)
-                triple = data[pos + 24:pos + 24 + tl].decode()
-                pos += 24 + tl
-                if 'gfx950' not in triple or size == 0:
-                    continue
-                objects += 1
-                obj = os.path.join(tmp, 'co.o')
-                with open(obj, 'wb') as f:
-                    f.write(data[base + off:base + off + size])
-                proc = subprocess.Popen([OBJDUMP, '-d', '--no-show-raw-insn', obj], stdout=subprocess.PIPE, text=True)
-                cur = None
-                for line in proc.stdout:
+        # torch's librccl carries ONE compressed offload bundle (CCOB) in .hip_fatbin: copy the section out, let clang-offload-bundler unpack the gfx950 entry
+        fat, obj = os.path.join(tmp, 'fatbin.bin'), os.path.join(tmp, 'gfx950.co')
+        subprocess.run([os.path.join(llvm, 'llvm-objcopy'), '-O', 'binary', '--only-section=.hip_fatbin', path, fat], check=True)
+        listing = subprocess.run([os.path.join(llvm, 'clang-offload-bundler'), '--list', '--type=o', '--input=' + fat], capture_output=True, text=True).stdout.split()
+        targets = [t for t in listing if 'gfx950' in t]
+        print('bundle entries: %s' % ' '.join(sorted(listing)))
+        for target in targets:
+            subprocess.run([os.path.join(llvm, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fat, '--targets=' + target, '--output=' + obj], check=True)
+            objects += 1
+            print('%s: %d bytes' % (target, os.path.getsize(obj)))
+            proc = subprocess.Popen([OBJDUMP, '-d', '--no-show-raw-insn', obj], stdout=subprocess.PIPE, text=True)
+            cur = None
+            for line in proc.stdout:
+                if line and line[0] in '0123456789abcdef':
                     mm = re.match(r'^[0-9a-f]+ <(.*)>:$', line)
                     if mm:
                         cur = mm.group(1)
                         funcs_total += 1
-                    elif 'v_pk_' in line and PACKED.search(line):
-                        a = classify(cur or '')
-                        per_algo[a] += 1
-                        per_algo_funcs[a].add(cur)
-                        if len(examples[a]) < 4 and cur not in examples[a]:
-                            examples[a].append(cur)
-                proc.wait()
+                        continue
+                if 'v_pk_' in line and PACKED.search(line):
+                    a = classify(cur or '')
+                    per_algo[a] += 1
+                    per_algo_funcs[a].add(cur)
+                    if len(examples[a]) < 4 and cur not in examples[a]:
+                        examples[a].append(cur)
+            proc.wait()
     print('gfx950 code objects: %d, functions: %d' % (objects, funcs_total))
     print('packed-fp32 instructions by algorithm class of the function that holds them:')
     for a in ('Ring', 'Tree', 'PAT', 'CollNet', 'NVLS', 'other'):
         print('  %-8s %6d instructions in %4d functions' % (a, per_algo[a], len(per_algo_funcs[a])))
-        for e in examples[a]:
-            print('      e.g. %s' % e[:200])
+        for e in sorted(per_algo_funcs[a]):
+            print('      %s' % e[:240])
 
 
 if __name__ == '__main__':
