@@ -98,6 +98,8 @@ class _ResidualBlock(nn.Module):
         return out
 
     def forward_partial(self, x, veil):
+        if FUSED_BLOCKS and ops_block.usable(self, x, veil):          # training: the masked block as one C call per direction, like the dense ones
+            return ops_block.residual_block(self, x, veil)
         join = ops.GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
         out = x
         last = len(self._chain) - 1

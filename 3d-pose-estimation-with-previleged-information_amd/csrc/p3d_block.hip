@@ -341,6 +341,9 @@ ProfScope::~ProfScope() {
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// a partial convolution inside the executor: the per-pixel factors live in the conv kernels' epilogues (for a split-K launch: in the pass that sums the slabs)
+static bool masked_conv_ok(const p3d_conv_desc* d) { return fx_fwd_masked_applies(d) && fx_dgrad_masked_applies(d); }
+
 static int32_t check_block(const p3d_block_desc* b) {
     P3D_REQUIRE(b != nullptr, "block: null descriptor");
     P3D_REQUIRE(b->nconv == 2 || b->nconv == 3, "block: nconv must be 2 (BasicBlock) or 3 (Bottleneck), got %d", b->nconv);
@@ -349,6 +352,7 @@ static int32_t check_block(const p3d_block_desc* b) {
         const p3d_conv_desc* d = &b->conv[i];
         P3D_REQUIRE(block_conv_ok(d, i < 3),
                     "block: convolution %d (C=%d K=%d %dx%d stride %d, %dx%d input) is outside the fused path", i, d->C, d->K, d->R, d->S, d->stride, d->H, d->W);
+        P3D_REQUIRE(!b->masked || i == 3 || masked_conv_ok(d), "block: partial convolution %d is outside the masked instances of the x3 kernels", i);
     }
     return P3D_OK;
 }
@@ -365,6 +369,7 @@ int32_t p3d_block_supported(const p3d_block_desc* b) {
         if (i >= b->nconv && !(i == 3 && b->has_downsample)) continue;
         const p3d_conv_desc* d = &b->conv[i];
         if (!block_conv_ok(d, i < 3)) return 0;
+        if (b->masked && i != 3 && !masked_conv_ok(d)) return 0;
     }
     return 1;
 }
@@ -428,6 +433,12 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         f.act_img = from_x ? nullptr : io->aimg[i - 1];
         f.partial = ds ? partial2 : partial;
         f.wimg = io->wimg[i];
+        const bool mk = b->masked && !ds;
+        if (mk) {
+            P3D_REQUIRE(io->pix_in[i] && io->pix_out[i], "block_fwd: null per-pixel factor of partial convolution %d", i);
+            f.emask = io->pix_out[i];
+            if (from_x) f.pmask = io->pix_in[i];           // (an image operand carries mask_in already: the pass that wrote a_{i-1} multiplied it in)
+        }
         {
             ProfScope ps(0, d, st);
             fx_count(0, d);
@@ -443,11 +454,11 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             FxFinalize fin{};
             fin.kind = 1; fin.partial = partial; fin.rows = rows; fin.count = cnt; fin.gamma = io->gamma[i]; fin.beta = io->beta[i];
             fin.running_mean = io->running_mean[i]; fin.running_var = io->running_var[i]; fin.momentum = b->momentum[i]; fin.eps = b->eps[i]; fin.table = io->table[i];
-            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st, &fin)) return e;
+            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st, &fin, mk ? io->pix_in[i + 1] : nullptr)) return e;
         } else {
             hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(d->K, FIN_CH)), dim3(fin_threads(rows)), 0, st, (const float*)partial, rows, d->K, cnt, io->gamma[i],
                                io->beta[i], io->running_mean[i], io->running_var[i], b->momentum[i], b->eps[i], io->table[i]);
-            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st)) return e;
+            if (int32_t e = fx_act_image(1, io->c[i], nullptr, io->table[i], 0, io->aimg[i], d->N, d->K, d->Ho * d->Wo, st, nullptr, mk ? io->pix_in[i + 1] : nullptr)) return e;
         }
     }
     const p3d_conv_desc* dl = &b->conv[last];
@@ -465,7 +476,7 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 // Can this block's backward pass reduce its producer's opening sums (p3d_block_io.tail_*)?  The last writer of dx must be a dense stride-1 launch whose epilogue
 // sees the final value: conv 0's data gradient with an identity shortcut (dx = dgrad + g), the downsample conv's (dx += dgrad) otherwise.
 int32_t p3d_block_tail_supported(const p3d_block_desc* b) {
-    if (check_block(b)) return 0;
+    if (check_block(b) || b->masked) return 0;
     if (b->has_downsample) return b->conv[3].stride == 1 && fx_dgrad_tail_applies(&b->conv[3]) ? 1 : 0;
     return fx_dgrad_tail_applies(&b->conv[0]) && fx_dgrad_accumulates_from_source(&b->conv[0]) ? 1 : 0;
 }
@@ -536,6 +547,9 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     //    others), finalized in the image pass's own prologue when the partial rows are few, by a launch of their own otherwise.
     //    Streams: a weight gradient runs on the second stream behind an event of the launch stream; it reads dcimg[i] and aimg[i - 1] / x, none of which the
     //    launch stream writes again inside this call, so the launch stream never waits for the second one here.
+    // partial convolutions: the gradient image of conv `slot` carries its renormalisation factor (d raw = d c * mult: partial_conv.py:53 and its autograd)
+    for (int i = 0; b->masked && i < b->nconv; ++i) P3D_REQUIRE(io->pix_in[i] && io->pix_out[i], "block_bwd: null per-pixel factor of partial convolution %d", i);
+    auto pixmul = [&](int slot) -> const float* { return (b->masked && slot != 3) ? io->pix_out[slot] : nullptr; };
     auto bwd_map = [&](const float* gin, int slot, int masked, int kind, int rows, int which, double cnt, const unsigned char* front_mask = nullptr,
                        const void* part = nullptr) -> int32_t {
         const p3d_conv_desc* dc = &b->conv[slot];
@@ -545,11 +559,11 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             fin.kind = kind; fin.partial = part ? part : partial; fin.rows = rows; fin.which = which; fin.count = cnt; fin.gamma = io->gamma[slot];
             fin.dgamma = io->dgamma[slot]; fin.dbeta = io->dbeta[slot]; fin.accumulate = acc; fin.table = io->table[slot];
             fin.gmask = front_mask;
-            return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, &fin);
+            return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, &fin, pixmul(slot));
         }
         hipLaunchKernelGGL(bn_finalize_bwd_kernel<false>, dim3((unsigned)ceil_div(dc->K, FIN_CH)), dim3(fin_threads(rows)), 0, st, (const void*)partial, rows, dc->K, cnt, 0,
                            io->gamma[slot], io->dgamma[slot], io->dbeta[slot], acc, io->table[slot]);
-        return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st);
+        return fx_act_image(2, gin, io->c[slot], io->table[slot], masked, io->dcimg[slot], dc->N, dc->K, dc->Ho * dc->Wo, st, nullptr, pixmul(slot));
     };
     // `ready`: the launch stream's position when the gradient image of this convolution was complete (the data gradient of the same layer has been queued on
     // the launch stream since: it is the critical path and gets to the GPU first; the weight gradient only feeds the optimizer)
@@ -560,6 +574,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         fx_count(2, d);
         FxFuse fw{};
         fw.dy_img = io->dcimg[slot]; fw.x_img = ximg;
+        if (b->masked && slot != 3 && !ximg) fw.emask = io->pix_in[slot];      // the block input is fp32: x * mask_in in the kernel's split (an image carries it)
         const int splits = fx_wgrad_splits(d);
         if (int32_t e = fx_conv_wgrad_slabs(d, nullptr, xin, (float*)side_workspace, splits, &fw, ss)) return e;
         p3d_conv_desc dw_desc = *d;
@@ -574,7 +589,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         fa.kind = 3; fa.partial = open_partial; fa.rows = split; fa.which = 0; fa.count = cnt_last; fa.gamma = io->gamma[last]; fa.dgamma = io->dgamma[last];
         fa.dbeta = io->dbeta[last]; fa.accumulate = acc; fa.table = io->table[last];
         fb = fa; fb.which = 1; fb.gamma = io->gamma[3]; fb.dgamma = io->dgamma[3]; fb.dbeta = io->dbeta[3]; fb.table = io->table[3];
-        if (int32_t e = fx_act_image_pair(g, gmask, io->c[last], io->c[3], io->dcimg[last], io->dcimg[3], &fa, &fb, dl->N, dl->K, dl->Ho * dl->Wo, st)) return e;
+        if (int32_t e = fx_act_image_pair(g, gmask, io->c[last], io->c[3], io->dcimg[last], io->dcimg[3], &fa, &fb, dl->N, dl->K, dl->Ho * dl->Wo, st, pixmul(last))) return e;
     } else {
         if (int32_t e = bwd_map(g, last, 0, 3, split, 0, cnt_last, gmask, open_partial)) return e;
         if (b->has_downsample)
@@ -594,6 +609,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             const p3d_conv_desc* dp = &b->conv[i - 1];                       // producer of this conv's input
             const bool epi = d->stride == 1;
             if (epi) { f.partial = (float*)partial; f.ep_c = io->c[i - 1]; f.ep_tab = io->table[i - 1]; }
+            if (b->masked) f.emask = io->pix_in[i];            // dx = dgrad(d raw) * mask_in: the gradient w.r.t. a_{i-1}, of which the BatchNorm-backward sums are taken
             dd.accumulate = 0;
             P3D_REQUIRE(io->da[i - 1], "block_bwd: null gradient buffer %d", i - 1);
             {
@@ -617,6 +633,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
             // block input: identity shortcut -> the gradient joins g's own buffer in place (dx = g + dgrad); downsample shortcut -> dx is written here and
             // the downsample conv's dgrad adds to it below.  No weight-gradient kernel reads g (they read the images), so the launch stream does not wait.
             float* dx;
+            if (b->masked) f.emask = io->pix_in[0];
             if (b->has_downsample) { dx = io->dx; dd.accumulate = 0; }
             else {
                 P3D_REQUIRE(b->relu_out, "block_bwd: an identity shortcut without the closing ReLU would overwrite the caller's gradient (not a reference block)");

@@ -114,7 +114,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
 // p3d_conv.hip: fold the split slabs and write (or add) the weight gradient in the weight's own [K][C][R][S] layout
 int32_t wgrad_finish(const p3d_conv_desc* d, float* slabs, int nslab, bool tapm, float* dw, hipStream_t st);
 size_t fx_weight_image_bytes(int K, int C, int RS, bool bwd);
-int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st);
+int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st, int ctot = 0, int coff = 0);      // ctot > 0: a window of C input channels at coff
 int32_t fx_build_weight_images_batched(const void* jobs, int njobs, int blocks, hipStream_t st);      // jobs: device array of {w, fwd, bwd, K, C, RS, pad} (40 B each)
 int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float* x, float* slabs, int splits, const FxFuse* fuse, hipStream_t st);
 // Pre-split activation images: a fp32 NCHW tensor [N][C][HW] (C % 16 == 0, HW % 4 == 0) as three bf16 planes [N][C/16][HW][16] (hi + mid + lo == value exactly):
@@ -144,10 +144,11 @@ struct FxFinalize {
 constexpr int FX_FIN_MAX_ROWS = 512;
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW);
 bool fx_pair_map_enabled();
+// pixmul (optional, [N][HW]): the image holds the tensor times this per-pixel factor (partial convolutions inside the block executor)
 int32_t fx_act_image_pair(const float* x, const unsigned char* gmask, const float* c_a, const float* c_b, void* img_a, void* img_b, const FxFinalize* fa, const FxFinalize* fb,
-                          int N, int C, int HW, hipStream_t st);
+                          int N, int C, int HW, hipStream_t st, const float* pixmul_a = nullptr);
 int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
-                     const FxFinalize* fin = nullptr);
+                     const FxFinalize* fin = nullptr, const float* pixmul = nullptr);
 
 // The 7x7 stride-2 stem (Cin = 1..4) as a 4x4 stride-1 convolution over a space-to-depth image of the input (p3d_fx.hip)
 bool fx_stem_applies(int N, int Cin, int H, int W, int K);

@@ -163,8 +163,12 @@ __device__ __forceinline__ FxConvParams fx_class_params(const FxConvParams& in) 
     return p;
 }
 
-template <int AMODE, int PRO, int EPI>
+template <int AMODE, int PRO, int EPIX>
 __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in) {
+    // EPIX 5 / 6 / 7 = EPI 1 / 2 / 0 with the result first multiplied by emask[pixel] (a partial convolution inside the residual-block executor: the BatchNorm sums are
+    // taken of the renormalised result); EPIX 4 = the per-layer partial convolution (factor, no sums)
+    constexpr int EPI = EPIX == 5 ? 1 : EPIX == 6 ? 2 : EPIX == 7 ? 0 : EPIX;
+    constexpr bool EM = EPIX == 4 || EPIX >= 5;
     const FxConvParams p = fx_class_params(p_in);
     static_assert(AMODE == 0 || PRO == 0, "the partial-convolution factor is applied by the in-kernel split");
     // one shared array: two buffers of [3 pixel pieces][3 channel pieces]; after the K loop the result tile on its way out (33.8 KB) and, behind it, the
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
                     if (p.bias) { const float bb = p.bias[m]; v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb; }
                 }
                 if (dense) {
-                    if constexpr (EPI == 4) {           // partial convolution: the result times the per-pixel factor (before it joins an existing gradient)
+                    if constexpr (EM) {           // partial convolution: the result times the per-pixel factor (before it joins an existing gradient)
                         const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + oh) * p.YW + ow);
                         v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
                     }
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
                 } else {
                     float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
                     if (p.oxs == 1) {
-                        if constexpr (EPI == 4) {
+                        if constexpr (EM) {
                             const f32x4 em = *reinterpret_cast<const f32x4*>(p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow);
                             v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
                         }
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
                         if (p.accumulate) { const f32x4 o4 = *d4; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
                         *d4 = v;
                     } else {
-                        if constexpr (EPI == 4) {
+                        if constexpr (EM) {
                             const float* em = p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= em[e * p.oxs];
@@ -804,6 +808,11 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_
                 acc[a][b] = v;
             } else {
                 float* dst = yout + (((size_t)n * p.M + m) * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+                if (p.emask) {              // (a strided data gradient of a partial convolution: the factor of the input pixels this class writes)
+                    const float* em = p.emask + ((size_t)n * p.YH + p.oy0 + oh * p.oys) * p.YW + p.ox0 + ow * p.oxs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= em[e * p.oxs];
+                }
                 if (p.oxs == 1) {
                     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
                     if (p.accumulate) { const f32x4 o4 = *d4; v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_
 template <int EPI>
 __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ y, const float* __restrict__ bias, int nsplit,
                                                         size_t slab_stride, int N, int M, int OHW, int accumulate, const float* __restrict__ ep_c,
-                                                        const float* __restrict__ ep_tab, float* __restrict__ partial) {
+                                                        const float* __restrict__ ep_tab, float* __restrict__ partial, const float* __restrict__ emask) {
     const int m = blockIdx.x, grp = blockIdx.y, ngrp = gridDim.y;
     const float bb = bias ? bias[m] : 0.f;
     float esc = 0.f, esh = 0.f, emean = 0.f;
@@ -916,6 +925,10 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
                 v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
             }
             v[0] += bb; v[1] += bb; v[2] += bb; v[3] += bb;
+            if (emask) {         // partial convolution: the per-pixel factor of the result (the split launches carry no epilogue)
+                const f32x4 em = *reinterpret_cast<const f32x4*>(emask + (size_t)n * OHW + 4 * i);
+                v[0] *= em[0]; v[1] *= em[1]; v[2] *= em[2]; v[3] *= em[3];
+            }
             f32x4* dst = reinterpret_cast<f32x4*>(y + base + 4 * i);
             if (accumulate) { const f32x4 o = *dst; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
             *dst = v;
@@ -1220,7 +1233,8 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 // ------------------------------------------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ tab,
-                                                           unsigned char* __restrict__ img, size_t plane_bytes, int N, int C, int HW, int masked, const FxFinalize fin) {
+                                                           unsigned char* __restrict__ img, size_t plane_bytes, int N, int C, int HW, int masked, const FxFinalize fin,
+                                                           const float* __restrict__ pixmul) {
     __shared__ float cst[16][FX_TAB];
     __shared__ double fred[2][16][16];
     const int cg = blockIdx.y, t = threadIdx.x;
@@ -1335,6 +1349,14 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
             }
         }
     }
+    if (pixmul) {        // partial convolution: the operand the next kernel copies is this tensor times a per-pixel factor (mask_in of the conv that reads an
+                         // activation image, mult of the conv whose gradient image this is); multiplied in here, the image-fed kernels stay factor-free
+        const f32x4 f = *reinterpret_cast<const f32x4*>(pixmul + (size_t)n * HW + 4 * pq);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] *= f[e];
+    }
     unsigned char* dst = img + (((size_t)n * (C >> 4) + cg) * HW + 4 * pq) * 32 + 16 * ih;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1351,7 +1373,7 @@ __global__ __launch_bounds__(256) void fx_act_image_kernel(const float* __restri
 // upstream gradient -- in ONE pass: g (and the closing ReLU's mask bytes) are read once instead of twice.  MODE 2 with kind-3 finalize on both outputs (the fp64
 // partials [C][rows][3] of block_open_bwd: sum g, sum g (c_last - mean), sum g (c_ds - mean_ds)); every value by the expressions, and the partial rows in the order, of
 // fx_act_image_kernel<2>, so the images are bit-identical to two separate passes (p3d_fx_tune(3, 0) switches back: tests/test_block_gpu.py).
-struct FxPairSide { const float* c; unsigned char* img; const float* gamma; float* dgamma; float* dbeta; const float* table; };
+struct FxPairSide { const float* c; unsigned char* img; const float* gamma; float* dgamma; float* dbeta; const float* table; const float* pixmul; };
 __global__ __launch_bounds__(256) void fx_act_image_pair_kernel(const float* __restrict__ X, const unsigned char* __restrict__ gmask, const FxPairSide a, const FxPairSide b,
                                                                 const double* __restrict__ partial, int rows, double count, int accumulate, size_t plane_bytes,
                                                                 int N, int C, int HW) {
@@ -1427,6 +1449,13 @@ __global__ __launch_bounds__(256) void fx_act_image_pair_kernel(const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[j][e] = fmaf(A, g[j][e], fmaf(B, c2[e], K));
         }
+        if (q.pixmul) {          // (a partial convolution's gradient image carries its renormalisation factor: fx_act_image_kernel)
+            const f32x4 f = *reinterpret_cast<const f32x4*>(q.pixmul + (size_t)n * HW + 4 * pq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j][e] *= f[e];
+        }
         unsigned char* dst = q.img + (((size_t)n * (C >> 4) + cg) * HW + 4 * pq) * 32 + 16 * ih;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1443,12 +1472,12 @@ __global__ __launch_bounds__(256) void fx_act_image_pair_kernel(const float* __r
 static int g_pair_map = 1;
 bool fx_pair_map_enabled() { return g_pair_map != 0; }
 int32_t fx_act_image_pair(const float* x, const unsigned char* gmask, const float* c_a, const float* c_b, void* img_a, void* img_b, const FxFinalize* fa, const FxFinalize* fb,
-                          int N, int C, int HW, hipStream_t st) {
+                          int N, int C, int HW, hipStream_t st, const float* pixmul_a) {
     if (!x || !c_a || !c_b || !img_a || !img_b || !fa || !fb || fa->kind != 3 || fb->kind != 3 || fa->partial != fb->partial || fa->rows != fb->rows || fa->which != 0 ||
         fb->which != 1 || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3)) {
         set_error("fx_act_image_pair: bad argument"); return P3D_EINVAL;
     }
-    const FxPairSide a{c_a, (unsigned char*)img_a, fa->gamma, fa->dgamma, fa->dbeta, fa->table}, b{c_b, (unsigned char*)img_b, fb->gamma, fb->dgamma, fb->dbeta, fb->table};
+    const FxPairSide a{c_a, (unsigned char*)img_a, fa->gamma, fa->dgamma, fa->dbeta, fa->table, pixmul_a}, b{c_b, (unsigned char*)img_b, fb->gamma, fb->dgamma, fb->dbeta, fb->table, nullptr};
     const dim3 grid((unsigned)ceil_div((int64_t)N * (HW >> 2) * 2, 256), (unsigned)(C >> 4));
     hipLaunchKernelGGL(fx_act_image_pair_kernel, grid, dim3(256), 0, st, x, gmask, a, b, (const double*)fa->partial, fa->rows, fa->count, fa->accumulate,
                        (size_t)N * C * HW * 2, N, C, HW);
@@ -1458,7 +1487,7 @@ int32_t fx_act_image_pair(const float* x, const unsigned char* gmask, const floa
 size_t fx_act_image_bytes(int64_t N, int64_t C, int64_t HW) { return (size_t)(3 * N * C * HW * 2); }
 
 int32_t fx_act_image(int mode, const float* x, const float* x2, const float* table, int masked, void* img, int N, int C, int HW, hipStream_t st,
-                     const FxFinalize* fin) {
+                     const FxFinalize* fin, const float* pixmul) {
     if (!x || !img || N <= 0 || C <= 0 || (C & 15) || HW <= 0 || (HW & 3) || (mode != 0 && !table && !fin) || (mode == 2 && !x2) || mode < 0 || mode > 2) {
         set_error("fx_act_image: bad argument (N=%d C=%d HW=%d mode=%d; C %% 16 == 0 and HW %% 4 == 0 are required)", N, C, HW, mode); return P3D_EINVAL;
     }
@@ -1471,9 +1500,9 @@ int32_t fx_act_image(int mode, const float* x, const float* x2, const float* tab
     }
     const size_t plane = (size_t)N * C * HW * 2;
     const dim3 grid((unsigned)ceil_div((int64_t)N * (HW >> 2) * 2, 256), (unsigned)(C >> 4));
-    if (mode == 0) hipLaunchKernelGGL(fx_act_image_kernel<0>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
-    else if (mode == 1) hipLaunchKernelGGL(fx_act_image_kernel<1>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
-    else hipLaunchKernelGGL(fx_act_image_kernel<2>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f);
+    if (mode == 0) hipLaunchKernelGGL(fx_act_image_kernel<0>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f, pixmul);
+    else if (mode == 1) hipLaunchKernelGGL(fx_act_image_kernel<1>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f, pixmul);
+    else hipLaunchKernelGGL(fx_act_image_kernel<2>, grid, dim3(256), 0, st, x, x2, table, (unsigned char*)img, plane, N, C, HW, masked, f, pixmul);
     return check_launch("fx_act_image");
 }
 
@@ -1503,7 +1532,8 @@ void fx_stats(unsigned long long* counts, double* flops, int reset) {
 }
 
 static bool fx_common(const p3d_conv_desc* d) {
-    return fx_enabled() && d->c_offset == 0 && d->c_total == d->C && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
+    // (an input-channel window of a wider weight, c_offset / c_total: the per-call weight image is built from the window; callers with cached images pass whole weights)
+    return fx_enabled() && d->c_offset >= 0 && d->c_offset + d->C <= d->c_total && d->R == d->S && (d->R & 1) && d->stride <= 2 &&
            (int64_t)d->N * d->C * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->K * d->Ho * d->Wo < (1ll << 31) &&
            (int64_t)(d->K + 127) * (d->C + 127) * d->R * d->S * 6 < (1ll << 31);          // (32-bit byte offsets into the weight images)
 }
@@ -1537,6 +1567,7 @@ static int fx16_mode() {
 // mostly padding (the 272-channel regressor: 3 x 96 = 288 rows instead of 384; 64-channel layers: all four waves live)
 static int fx16_bm(int M, bool img, int pro, int epi) {
     const int mode = fx16_mode();
+    if (epi == 5 || epi == 6 || epi == 7) epi = epi == 7 ? 0 : epi - 4;      // the masked epilogues run on the base instance with the factor pointer set
     if (!img || pro != 0 || (epi != 0 && epi != 1 && epi != 2) || mode == 0) return 0;
     if (M <= 64) return 64;
     if (ceil_div(M, 96) * 96 < ceil_div(M, 128) * 128) return 96;
@@ -1582,8 +1613,8 @@ static FxSplit fx_dgrad_split(const p3d_conv_desc* d) {
 }
 // partial convolutions (PRO 4 / EPI 4 instances): 64-channel layers included (half-dead tiles), unsplit launches only
 static bool fx_masked_on() { static const bool on = [] { const char* e = getenv("P3D_FX_MASKED"); return !(e && atoi(e) == 0); }(); return on; }      // A/B switch
-bool fx_fwd_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_fwd_applies(d, 64) && fx_fwd_split(d).splits == 1; }
-bool fx_dgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_dgrad_applies(d, 64) && (d->stride != 1 || fx_dgrad_split(d).splits == 1); }
+bool fx_fwd_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_fwd_applies(d, 64); }
+bool fx_dgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_dgrad_applies(d, 64); }
 bool fx_wgrad_masked_applies(const p3d_conv_desc* d) { return fx_masked_on() && fx_wgrad_applies(d, 96); }
 // workspace of a call: room for the weight image (built by the call unless the caller hands one in) + the split-K slabs
 size_t fx_fwd_workspace(const p3d_conv_desc* d) {
@@ -1607,7 +1638,9 @@ int fx_partial_rows_dgrad(const p3d_conv_desc* d) {
 // 1 the data-gradient image (rows = input channels, reduction = output channels); a null image pointer skips that direction.  One thread per 16-B chunk
 // position (tap, row tile, K step, row, half): eight fp32 weights -> three bf16 pieces (here the truncating split: piece = the top 16 bits of what is left;
 // exact like the rounding one), written where fx_conv_kernel's linear 12 KB copy wants them.
-__device__ __forceinline__ void fx_weight_image_chunks(const float* __restrict__ w, unsigned char* __restrict__ img, int K, int C, int RS, bool bwd, size_t first, size_t step) {
+// (ctot / coff: the image covers input channels coff .. coff + C of a weight with ctot of them -- the two halves of fusionnet's concat conv, fusionnet.py:138-139)
+__device__ __forceinline__ void fx_weight_image_chunks(const float* __restrict__ w, unsigned char* __restrict__ img, int K, int C, int RS, bool bwd, size_t first, size_t step,
+                                                       int ctot, int coff) {
     const int rows = bwd ? C : K, red = bwd ? K : C;
     const int tiles = (rows + 127) / 128, ksteps = red / FX_BK;
     const size_t total = (size_t)RS * tiles * ksteps * 256;
@@ -1622,7 +1655,7 @@ __device__ __forceinline__ void fx_weight_image_chunks(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float x = 0.f;
-            if (m < rows) x = bwd ? w[((size_t)(k0 + e) * C + m) * RS + tap] : w[((size_t)m * C + k0 + e) * RS + tap];
+            if (m < rows) x = bwd ? w[((size_t)(k0 + e) * ctot + coff + m) * RS + tap] : w[((size_t)m * ctot + coff + k0 + e) * RS + tap];
             const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
             const float r1 = x - __builtin_bit_cast(float, hb);
             const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
@@ -1636,10 +1669,10 @@ __device__ __forceinline__ void fx_weight_image_chunks(const float* __restrict__
     }
 }
 __global__ __launch_bounds__(256) void fx_weight_images_kernel(const float* __restrict__ w, unsigned char* __restrict__ img_fwd, unsigned char* __restrict__ img_bwd, int K,
-                                                               int C, int RS) {
+                                                               int C, int RS, int ctot, int coff) {
     const bool bwd = blockIdx.y == 1;
     unsigned char* img = bwd ? img_bwd : img_fwd;
-    if (img) fx_weight_image_chunks(w, img, K, C, RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+    if (img) fx_weight_image_chunks(w, img, K, C, RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256, ctot, coff);
 }
 // every convolution of a network in ONE launch (54 launches of a few microseconds each sat on the forward critical path of ResNet-50): grid (blocks, 2 * jobs)
 struct FxImageJob { const float* w; unsigned char* fwd; unsigned char* bwd; int K, C, RS, pad; };
@@ -1647,7 +1680,7 @@ __global__ __launch_bounds__(256) void fx_weight_images_batched_kernel(const FxI
     const FxImageJob j = jobs[blockIdx.y >> 1];
     const bool bwd = blockIdx.y & 1;
     unsigned char* img = bwd ? j.bwd : j.fwd;
-    if (img) fx_weight_image_chunks(j.w, img, j.K, j.C, j.RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+    if (img) fx_weight_image_chunks(j.w, img, j.K, j.C, j.RS, bwd, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256, j.C, 0);
 }
 int32_t fx_build_weight_images_batched(const void* jobs, int njobs, int blocks, hipStream_t st) {
     static_assert(sizeof(FxImageJob) == 40, "job table layout (ops_block.py builds it)");
@@ -1656,43 +1689,49 @@ int32_t fx_build_weight_images_batched(const void* jobs, int njobs, int blocks, 
     return check_launch("fx_build_weight_images_batched");
 }
 
-int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st) {
+int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_fwd, void* img_bwd, hipStream_t st, int ctot, int coff) {
+    if (ctot <= 0) { ctot = C; coff = 0; }
     const size_t a = img_fwd ? fx_weight_image_bytes(K, C, RS, false) / 48 : 0, b = img_bwd ? fx_weight_image_bytes(K, C, RS, true) / 48 : 0;        // chunk positions (3 chunks each)
     const size_t total = a > b ? a : b;
     if (total == 0) return P3D_OK;
     const unsigned blocks = (unsigned)(ceil_div((int64_t)total, 256) < 4096 ? ceil_div((int64_t)total, 256) : 4096);
-    hipLaunchKernelGGL(fx_weight_images_kernel, dim3(blocks, 2), dim3(256), 0, st, w, (unsigned char*)img_fwd, (unsigned char*)img_bwd, K, C, RS);
+    hipLaunchKernelGGL(fx_weight_images_kernel, dim3(blocks, 2), dim3(256), 0, st, w, (unsigned char*)img_fwd, (unsigned char*)img_bwd, K, C, RS, ctot, coff);
     return check_launch("fx_build_weight_images");
 }
 
 static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, int bm, dim3 grid, hipStream_t st) {
     const int am = img ? 1 : 0;
-#define P3D_FX16_CASE(BM, EPI) if (bm == BM && epi == EPI) { hipLaunchKernelGGL((fx16_conv_kernel<BM, EPI>), grid, dim3(256), 0, st, p); return; }
+    // (the fx16 kernel applies p.emask at run time: the masked epilogues 5 / 6 / 7 are its 1 / 2 / 0 with the factor pointer set)
+#define P3D_FX16_CASE(BM, EPI) if (bm == BM && (epi == EPI || epi == (EPI == 0 ? 7 : EPI + 4))) { hipLaunchKernelGGL((fx16_conv_kernel<BM, EPI>), grid, dim3(256), 0, st, p); return; }
     P3D_FX16_CASE(128, 0) P3D_FX16_CASE(128, 1) P3D_FX16_CASE(128, 2)
     P3D_FX16_CASE(96, 0) P3D_FX16_CASE(96, 1) P3D_FX16_CASE(96, 2)
     P3D_FX16_CASE(64, 0) P3D_FX16_CASE(64, 1) P3D_FX16_CASE(64, 2)
 #undef P3D_FX16_CASE
 #define P3D_FX_CASE(AM, PRO, EPI) if (am == AM && pro == PRO && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<AM, PRO, EPI>), grid, dim3(256), 0, st, p); return; }
-    P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 4)
-    P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2) P3D_FX_CASE(1, 0, 3)
+    P3D_FX_CASE(0, 0, 0) P3D_FX_CASE(0, 0, 1) P3D_FX_CASE(0, 0, 2) P3D_FX_CASE(0, 4, 0) P3D_FX_CASE(0, 4, 4) P3D_FX_CASE(0, 4, 5)
+    P3D_FX_CASE(1, 0, 0) P3D_FX_CASE(1, 0, 1) P3D_FX_CASE(1, 0, 2) P3D_FX_CASE(1, 0, 3) P3D_FX_CASE(1, 0, 5) P3D_FX_CASE(1, 0, 6) P3D_FX_CASE(1, 0, 7)
 #undef P3D_FX_CASE
 }
 
 static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* slabs, float* y, const float* bias, int nsplit, size_t slab_stride, int N, int M,
-                             int OHW, int accumulate, const float* ep_c, const float* ep_tab, float* partial) {
-    if (epi == 1) hipLaunchKernelGGL(fx_reduce_kernel<1>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
-    else if (epi == 2) hipLaunchKernelGGL(fx_reduce_kernel<2>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
-    else hipLaunchKernelGGL(fx_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial);
+                             int OHW, int accumulate, const float* ep_c, const float* ep_tab, float* partial, const float* emask) {
+    if (epi == 5 || epi == 6 || epi == 7 || epi == 4) epi = epi == 5 ? 1 : epi == 6 ? 2 : 0;      // the masked epilogues: the base sums over the result times emask
+    if (epi == 1) hipLaunchKernelGGL(fx_reduce_kernel<1>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
+    else if (epi == 2) hipLaunchKernelGGL(fx_reduce_kernel<2>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
+    else hipLaunchKernelGGL(fx_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
 }
 
 // y = conv(x, w) (+ bias); fuse may be null (plain convolution from fp32 x, the weight image built here)
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st) {
-    const bool masked = fuse && fuse->pmask;
+    // partial convolution (partial_conv.py:45-53): y = conv(x * pmask) * emask.  An fp32 operand is multiplied by pmask before the in-kernel split (PRO 4); an image
+    // operand carries its factor already (the pass that wrote it multiplied it in), so only emask is given.  With `partial` the BatchNorm statistics are taken of
+    // the renormalised result (the residual-block executor: epilogue 5).
     const bool img = fuse && fuse->act_img;
+    const bool masked = fuse && (fuse->pmask || fuse->emask);
     const void* wimg = fuse ? fuse->wimg : nullptr;
-    if (masked && (!fuse->emask || bias || img || fuse->partial || fx_fwd_split(d).splits > 1)) {
-        set_error("fx_conv_fwd: the partial-convolution instance takes both factors, fp32 operands, no bias and an unsplit launch"); return P3D_EINVAL;
+    if (masked && (!fuse->emask || bias || (img ? fuse->pmask != nullptr : fuse->pmask == nullptr))) {
+        set_error("fx_conv_fwd: the partial-convolution instances take the output factor, the input factor exactly for an fp32 operand, and no bias"); return P3D_EINVAL;
     }
     const size_t need = fx_fwd_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
@@ -1707,7 +1746,7 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
     if (!wimg) {
-        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, ws, nullptr, st)) return e;
+        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, ws, nullptr, st, d->c_total, d->c_offset)) return e;
         wimg = ws;
     }
     ws += align256(fx_weight_image_bytes(d->K, d->C, RS, false));
@@ -1715,7 +1754,7 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     int pro = 0, epi = 0;
     if (fuse) {
         if (fuse->partial) { epi = 1; p.partial = fuse->partial; }
-        if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
+        if (masked) { pro = img ? 0 : 4; epi = fuse->partial ? 5 : (img ? 7 : 4); p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     const int tiles_n = (int)ceil_div(p.NP, FX_BN);
     const FxSplit sp = fx_fwd_split(d);
@@ -1723,9 +1762,11 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     p.tiles_m = (int)ceil_div(d->K, bm ? bm : FX_BM);
     if (sp.splits > 1) {
         p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
-        fx_launch_conv(p, img, 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+        const float* em = p.emask;
+        p.emask = nullptr;             // (the slabs are raw partial products: the factor, like the sums, belongs to the reduce pass)
+        fx_launch_conv(p, img, pro == 4 ? 4 : 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
         fx_launch_reduce(epi, dim3((unsigned)d->K, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, y, bias, sp.splits, p.slab_stride, d->N, d->K,
-                         d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial);
+                         d->Ho * d->Wo, d->accumulate, nullptr, nullptr, p.partial, em);
     } else {
         fx_launch_conv(p, img, pro, epi, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
     }
@@ -1735,11 +1776,13 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
 // dx (=|+=) dgrad(dy, w); strided: one launch per parity class of the input, written straight into dx
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,
                       hipStream_t st) {
-    const bool masked = fuse && fuse->pmask;
+    // partial convolution: dx = dgrad(dy * pmask) * emask (pmask = mult of the output pixel, emask = mask_in of the input pixel).  As in fx_conv_fwd an image operand
+    // carries its factor; with `partial` the BatchNorm-backward sums are taken of the masked result (epilogue 6).
     const bool img = fuse && fuse->act_img;
+    const bool masked = fuse && (fuse->pmask || fuse->emask);
     const void* wimg = fuse ? fuse->wimg : nullptr;
-    if (masked && (!fuse->emask || img || fuse->partial || (d->stride == 1 && fx_dgrad_split(d).splits > 1))) {
-        set_error("fx_conv_dgrad: the partial-convolution instance takes both factors, fp32 operands and an unsplit launch"); return P3D_EINVAL;
+    if (masked && (!fuse->emask || (img ? fuse->pmask != nullptr : fuse->pmask == nullptr) || (!img && fuse->partial))) {
+        set_error("fx_conv_dgrad: the partial-convolution instances take the result factor and the operand factor exactly for an fp32 operand"); return P3D_EINVAL;
     }
     const size_t need = fx_dgrad_workspace(d);
     if (need && (!workspace || workspace_bytes < need)) { set_error("fx_conv_dgrad: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
@@ -1756,7 +1799,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     const int RS = d->R * d->S;
     char* ws = (char*)workspace;
     if (!wimg) {
-        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, nullptr, ws, st)) return e;
+        if (int32_t e = fx_build_weight_images(w, d->K, d->C, RS, nullptr, ws, st, d->c_total, d->c_offset)) return e;
         wimg = ws;
     }
     ws += align256(fx_weight_image_bytes(d->K, d->C, RS, true));
@@ -1764,7 +1807,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
     int pro = 0, epi = 0;
     if (fuse) {
         if (fuse->partial) { epi = 2; p.partial = fuse->partial; p.ep_c = fuse->ep_c; p.ep_tab = fuse->ep_tab; }
-        if (masked) { pro = 4; epi = 4; p.pmask = fuse->pmask; p.emask = fuse->emask; }
+        if (masked) { pro = img ? 0 : 4; epi = fuse->partial ? 6 : (img ? 7 : 4); p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     const bool dsplit = d->stride == 1 && fx_dgrad_split(d).splits > 1;
     if (fuse && fuse->tail_c) {
@@ -1784,9 +1827,11 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         const FxSplit sp = fx_dgrad_split(d);
         if (sp.splits > 1) {
             p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
-            fx_launch_conv(p, img, 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
+            const float* em = p.emask;
+            p.emask = nullptr;
+            fx_launch_conv(p, img, pro == 4 ? 4 : 0, 0, bm, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)sp.splits), st);
             fx_launch_reduce(epi, dim3((unsigned)d->C, (unsigned)(d->N < 16 ? d->N : 16)), st, (const float*)ws, dx, nullptr, sp.splits, p.slab_stride, d->N, d->C,
-                             d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial);
+                             d->H * d->W, d->accumulate, p.ep_c, p.ep_tab, p.partial, em);
         } else {
             if (fuse && fuse->acc_src && d->accumulate) { p.acc_src = fuse->acc_src; p.acc_mask = fuse->acc_mask; }
             fx_launch_conv(p, img, pro, epi, bm, dim3((unsigned)(p.tiles_m * tiles_n), 1), st);
@@ -1794,7 +1839,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         return check_launch("fx_conv_dgrad");
     }
     // stride 2: input pixel (ph + 2 i, pw + 2 j) of class (ph, pw) gathers dy at (i + off0 - ir * offstep, ...) over the taps r = r0 + rstep * ir that reach it
-    if (epi != 0 && epi != 4) { set_error("fx_conv_dgrad: the BatchNorm-backward epilogue is not available for strided data gradients"); return P3D_EINVAL; }
+    if (epi != 0 && epi != 4 && epi != 7) { set_error("fx_conv_dgrad: the BatchNorm-backward epilogue is not available for strided data gradients"); return P3D_EINVAL; }
     const int st2 = d->stride;
     p.OH = d->H / st2; p.OW = d->W / st2; p.NP = d->N * p.OH * p.OW; p.oys = st2; p.oxs = st2;
     p.hmul = 1; p.wmul = 1;
@@ -1895,14 +1940,18 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     if (fuse) {
         if (fuse->dy_img) { aimg = true; p.DYimg = (const unsigned char*)fuse->dy_img; p.dy_plane = (size_t)d->N * d->K * d->Ho * d->Wo * 2; }
         if (fuse->x_img) { bimg = true; p.Ximg = (const unsigned char*)fuse->x_img; p.x_plane = (size_t)d->N * d->C * d->H * d->W * 2; }
-        if (fuse->pmask) {
-            if (aimg || bimg || !fuse->emask) { set_error("fx_conv_wgrad: the partial-convolution instance takes both factors and fp32 operands"); return P3D_EINVAL; }
+        if (fuse->pmask || fuse->emask) {
+            // dw = wgrad(dy * pmask, x * emask): a factor goes with an fp32 operand (an image carries its own)
+            if ((fuse->pmask != nullptr) == aimg || (fuse->emask != nullptr) == bimg || (aimg && bimg)) {
+                set_error("fx_conv_wgrad: a partial-convolution factor belongs to an fp32 operand (pmask: dy, emask: x)"); return P3D_EINVAL;
+            }
             masked = true; p.amask = fuse->pmask; p.bmask = fuse->emask;
         }
     }
     if ((aimg && (d->K & 15)) || (bimg && (d->C & 15)) || (bimg && !aimg)) { set_error("fx_conv_wgrad: image operands need channel counts in steps of 16 (and a dy image beside an x image)"); return P3D_EINVAL; }
     const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
-    if (masked) hipLaunchKernelGGL((fx_wgrad_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+    if (masked && aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, true>), grid, dim3(256), 0, st, p);
+    else if (masked) hipLaunchKernelGGL((fx_wgrad_kernel<false, false, true>), grid, dim3(256), 0, st, p);
     else if (aimg && bimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false>), grid, dim3(256), 0, st, p);
     else if (aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fx_wgrad_kernel<false, false, false>), grid, dim3(256), 0, st, p);
@@ -1933,12 +1982,16 @@ __global__ __launch_bounds__(256) void fx_s2d_image_kernel(const float* __restri
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
             if (c < Cin) {
-                f32x2 q = *reinterpret_cast<const f32x2*>(x + (((size_t)n * Cin + c) * H + 2 * i2 + pi) * W + 2 * j2);
+                const f32x2 q = *reinterpret_cast<const f32x2*>(x + (((size_t)n * Cin + c) * H + 2 * i2 + pi) * W + 2 * j2);
+                float q0 = q[0], q1 = q[1];
                 if (mask) {          // partial convolution (partial_conv.py:45): the operand is x * mask_in, one factor per pixel
                     const f32x2 mq = *reinterpret_cast<const f32x2*>(mask + ((size_t)n * H + 2 * i2 + pi) * W + 2 * j2);
-                    q[0] *= mq[0]; q[1] *= mq[1];
+                    // (two explicit scalar multiplies: written in C++ the pair is merged into v_pk_mul_f32 on its way into the packed conversion below, and the library
+                    // must not contain packed-fp32 instructions -- csrc/Makefile, tests/test_build_flags.py)
+                    asm("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(q0), "v"(mq[0]));
+                    asm("v_mul_f32 %0, %1, %2" : "=v"(q1) : "v"(q1), "v"(mq[1]));
                 }
-                v[c * 4 + pi * 2] = q[0]; v[c * 4 + pi * 2 + 1] = q[1];
+                v[c * 4 + pi * 2] = q0; v[c * 4 + pi * 2 + 1] = q1;
             }
     unsigned hp[8], mp[8], lp[8];
 #pragma unroll

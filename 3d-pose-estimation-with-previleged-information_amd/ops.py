@@ -387,8 +387,10 @@ class ConvCat1x1Fn(torch.autograd.Function):
         d1 = _desc(x.shape, w.shape, 1, 0, 1, c_offset=0, c_total=c1 + c2)
         d2 = _desc(y.shape, w.shape, 1, 0, 1, c_offset=c1, c_total=c1 + c2, accumulate=1)
         out = torch.empty((d1.N, d1.K, d1.Ho, d1.Wo), dtype=torch.float32, device=x.device)
-        check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), None, 0, st), 'p3d_conv2d_fwd')
-        check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), None, 0, st), 'p3d_conv2d_fwd')
+        # (each half runs on the x3 kernels: its weight image is built per call from the half's input-channel window of w)
+        ws = workspace(x.device, max(L.p3d_conv2d_fwd_workspace_bytes(ctypes.byref(d1)), L.p3d_conv2d_fwd_workspace_bytes(ctypes.byref(d2)), 16))
+        check(L.p3d_conv2d_fwd(ctypes.byref(d1), _p(x), _p(w), None, None, None, _p(out), _p(ws), ws.numel(), st), 'p3d_conv2d_fwd')
+        check(L.p3d_conv2d_fwd(ctypes.byref(d2), _p(y), _p(w), None, None, None, _p(out), _p(ws), ws.numel(), st), 'p3d_conv2d_fwd')
         ctx.save_for_backward(x, y, w)
         ctx.w_param = w
         return out
@@ -402,12 +404,13 @@ class ConvCat1x1Fn(torch.autograd.Function):
         d1 = _desc(x.shape, w.shape, 1, 0, 1, c_offset=0, c_total=c1 + c2)
         d2 = _desc(y.shape, w.shape, 1, 0, 1, c_offset=c1, c_total=c1 + c2)
         dx = dyy = dw = None
+        wsd = workspace(x.device, max(L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d1)), L.p3d_conv2d_dgrad_workspace_bytes(ctypes.byref(d2)), 16))
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(L.p3d_conv2d_dgrad(ctypes.byref(d1), _p(dy), _p(w), None, None, _p(dx), None, 0, st), 'p3d_conv2d_dgrad')
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d1), _p(dy), _p(w), None, None, _p(dx), _p(wsd), wsd.numel(), st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[1]:
             dyy = torch.empty_like(y)
-            check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), None, 0, st), 'p3d_conv2d_dgrad')
+            check(L.p3d_conv2d_dgrad(ctypes.byref(d2), _p(dy), _p(w), None, None, _p(dyy), _p(wsd), wsd.numel(), st), 'p3d_conv2d_dgrad')
         if ctx.needs_input_grad[2]:
             sink = _grad_sink(ctx.w_param)
             dw = torch.empty_like(w) if sink is None else sink

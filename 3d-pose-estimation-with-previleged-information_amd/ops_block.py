@@ -32,7 +32,7 @@ TAIL_STATS = {'reduced': 0, 'opening_passes_skipped': 0}     # (tests: how often
 class BlockDesc(ctypes.Structure):
     """struct p3d_block_desc"""
     _fields_ = [('nconv', ctypes.c_int32), ('has_downsample', ctypes.c_int32), ('relu_out', ctypes.c_int32), ('need_dx', ctypes.c_int32),
-                ('accumulate_grads', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3), ('eps', ctypes.c_float * 4), ('momentum', ctypes.c_float * 4),
+                ('accumulate_grads', ctypes.c_int32), ('masked', ctypes.c_int32), ('reserved', ctypes.c_int32 * 2), ('eps', ctypes.c_float * 4), ('momentum', ctypes.c_float * 4),
                 ('conv', ConvDesc * 4)]
 
 
@@ -42,7 +42,7 @@ class BlockIO(ctypes.Structure):
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('gbuf', _vp), ('dcimg', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4),
                 ('dgamma', _vp * 4), ('dbeta', _vp * 4), ('out_mask', _vp),
                 ('tail_c_last', _vp), ('tail_table_last', _vp), ('tail_c_ds', _vp), ('tail_table_ds', _vp), ('tail_mask', _vp), ('tail_partial', _vp), ('tail_sums', _vp),
-                ('open_sums', _vp)]
+                ('open_sums', _vp), ('pix_in', _vp * 4), ('pix_out', _vp * 4)]
 
 
 def _one(v):
@@ -60,9 +60,10 @@ def _layers(block):
 class _Plan:
     """Per (block, input shape): the descriptor, workspace sizes and output shapes.  None if the fused executor does not take the block."""
 
-    def __init__(self, block, x_shape):
+    def __init__(self, block, x_shape, masked=False):
         d = BlockDesc()
         d.nconv = len(block._chain)
+        d.masked = int(masked)
         d.has_downsample = int(block.downsample is not None)
         d.relu_out = int(not block.skip_relu)
         shape = tuple(x_shape)
@@ -332,11 +333,11 @@ def release_buffers(model):
     return dropped
 
 
-def plan_for(block, x):
+def plan_for(block, x, masked=False):
     cache = block.__dict__.get('_blk_plans')
     if cache is None:
         cache = block.__dict__['_blk_plans'] = _Transient()
-    key = (tuple(x.shape), ops.X3_EPOCH)
+    key = (tuple(x.shape), ops.X3_EPOCH, bool(masked))
     plan = cache.pop(key, None)
     if plan is None:
         # a plan owns device buffers: keep those of the PLAN_LIMIT most recently used input shapes (a training loop has one or two: the batch and the epoch's
@@ -346,27 +347,36 @@ def plan_for(block, x):
                 if not any(b.held for b in cache[old].sets):
                     del cache[old]
                     break
-        plan = _Plan(block, x.shape)
+        plan = _Plan(block, x.shape, masked)
     cache[key] = plan               # (re-inserted: the dict's order is the order of last use)
     return plan
 
 
-def usable(block, x):
-    """The fused executor takes this call: dense fp32 block on the GPU, every BatchNorm computing batch statistics, supported shapes."""
-    if block.partial or x.dtype != torch.float32 or not x.is_cuda:
+# P3D_MASKED_BLOCKS=0: the partial-convolution blocks of the partial families stay on the per-layer path (one autograd node per conv / BatchNorm; A/B)
+MASKED_BLOCKS = os.environ.get('P3D_MASKED_BLOCKS', '1') != '0'
+
+
+def usable(block, x, veil=None):
+    """The fused executor takes this call: fp32 block on the GPU, every BatchNorm computing batch statistics, supported shapes; dense, or (veil given) with
+    partial convolutions in its main chain (partial_depthnet.py:62-75,140-157; the downsample branch is a dense conv there too)."""
+    masked = veil is not None
+    if bool(block.partial) != masked or x.dtype != torch.float32 or not x.is_cuda or (masked and not MASKED_BLOCKS):
         return False
-    for _, conv, bn in _layers(block):
-        if not bn.training or not (bn.affine and bn.track_running_stats) or conv.bias is not None or type(conv).__name__ != 'Conv2d':
+    if masked and not (veil.is_cuda and veil.dtype == torch.float32 and veil.dim() == 4 and veil.shape[1] == 1 and veil.shape[0] == x.shape[0] and veil.shape[2:] == x.shape[2:]):
+        return False
+    for slot, conv, bn in _layers(block):
+        want = 'PartialConv' if (masked and slot != 3) else 'Conv2d'
+        if not bn.training or not (bn.affine and bn.track_running_stats) or conv.bias is not None or type(conv).__name__ != want:
             return False
-    return plan_for(block, x).ok
+    return plan_for(block, x, masked).ok
 
 
 class ResidualBlockFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, block, *params):
+    def forward(ctx, x, block, veil, *params):
         x = x.contiguous()
-        plan = plan_for(block, x)
+        plan = plan_for(block, x, veil is not None)
         layers = _layers(block)
         L = lib()
         io = BlockIO()
@@ -381,6 +391,22 @@ class ResidualBlockFn(torch.autograd.Function):
         tables, cs, acts, row = bufs.tables, bufs.c, bufs.act, 0
         if bufs.mask is not None:
             io.out_mask = bufs.mask.data_ptr()
+        # partial convolutions: the veil chain of the block (partial_conv.py:35-43, one tiny box-sum kernel per conv) gives every conv its two per-pixel factors
+        pix = None
+        veil_out = None
+        if veil is not None:
+            pix = {}
+            v = veil.contiguous()
+            with torch.no_grad():
+                for slot, conv, _ in layers:
+                    if slot == 3:
+                        continue
+                    mult, v_next = ops.mask_count(v, _one(conv.kernel_size), _one(conv.stride), _one(conv.padding), _one(conv.dilation))
+                    pix[slot] = (v, mult)
+                    io.pix_in[slot], io.pix_out[slot] = v.data_ptr(), mult.data_ptr()
+                    v = v_next
+            veil_out = v
+        ctx.pix = pix
         for slot, conv, bn in layers:
             io.w[slot], io.c[slot] = conv.weight.data_ptr(), cs[slot].data_ptr()
             if USE_WEIGHT_IMAGES:
@@ -401,10 +427,13 @@ class ResidualBlockFn(torch.autograd.Function):
         ctx.saved = (lease, bufs)                          # (a plain attribute: the plan's buffers are never inputs / outputs of another node)
         ctx.save_for_backward(x, out)
         block.__dict__['_last_exec'] = (bufs, plan)        # residual_block() tags the returned tensor with it
+        if veil is not None:
+            ctx.mark_non_differentiable(veil_out)
+            return out, veil_out
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *unused):
         block, plan = ctx.block, ctx.plan
         x, out = ctx.saved_tensors
         if ctx.saved is None:
@@ -428,6 +457,9 @@ class ResidualBlockFn(torch.autograd.Function):
         io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
         if bufs.mask is not None:
             io.out_mask = bufs.mask.data_ptr()
+        if ctx.pix is not None:
+            for slot, (v, mult) in ctx.pix.items():
+                io.pix_in[slot], io.pix_out[slot] = v.data_ptr(), mult.data_ptr()
         # This block as the producer: the block that consumed `out` reduced the opening sums over the gradient it wrote -- valid if that very tensor arrives here
         # untouched (another consumer's gradient would have been added by autograd: a new tensor, or an in-place add that bumps the version).
         if bufs.open_ready is not None and bufs.open_ready == (dout.data_ptr(), dout._version) and bufs.tail is not None:
@@ -501,6 +533,8 @@ class ResidualBlockFn(torch.autograd.Function):
             tail_for.open_ready = (dx.data_ptr(), dx._version)      # the producer's backward checks that this is what it receives
         if two:
             x.record_stream(side)          # the one allocator-owned tensor the second stream reads (first conv's and the downsample's weight gradients)
+            if ctx.pix is not None:
+                ctx.pix[0][0].record_stream(side)          # (and, for a masked block, conv 1's mask_in: its weight gradient multiplies x by it)
             if bufs.side_done is None:
                 bufs.side_done = torch.cuda.Event()
             bufs.side_done.record(side)    # the plan's buffers: their next user (plan.acquire) orders itself behind this
@@ -508,19 +542,21 @@ class ResidualBlockFn(torch.autograd.Function):
         if direct:
             for _, _, p in params:
                 ops._grad_done(p)
-            return (dx, None) + (None,) * len(params)
-        return (dx, None) + tuple(grads)
+            return (dx, None, None) + (None,) * len(params)
+        return (dx, None, None) + tuple(grads)
 
 
-def residual_block(block, x):
+def residual_block(block, x, veil=None):
+    """One autograd node for the whole block.  veil: the block's input mask (a block of partial convolutions); returns (out, veil_out) then."""
     params = []
     for _, conv, bn in _layers(block):
         params += [conv.weight, bn.weight, bn.bias]
-    out = ResidualBlockFn.apply(x, block, *params)
+    res = ResidualBlockFn.apply(x, block, veil, *params)
+    out = res[0] if veil is not None else res
     last = block.__dict__.pop('_last_exec', None)
     if last is not None and USE_TAIL_SUMS:
         out._p3d_block_out = last        # a consumer block that receives THIS tensor object as its input may reduce our opening sums in its backward pass
-    return out
+    return res
 
 
 # ---- a single convolution on image operands (the 3x3 `regressor` behind layer4: depthnet.py:156,199) ------------------------------------------------------

@@ -136,7 +136,9 @@ typedef struct p3d_block_desc {
     int32_t relu_out;           /* 0: -skip_relu on the last block of a stage (depthnet.py:176-186) */
     int32_t need_dx;
     int32_t accumulate_grads;
-    int32_t reserved[3];
+    int32_t masked;             /* 1: the convolutions of the main chain are partial convolutions (partial_conv.py:32-57; partial_depthnet.py:62-75,140-157): p3d_block_io.pix_in /
+                                   pix_out carry their per-pixel factors; the downsample branch stays dense */
+    int32_t reserved[2];
     float eps[4];
     float momentum[4];
     p3d_conv_desc conv[4];
@@ -182,6 +184,10 @@ typedef struct p3d_block_io {
     float* tail_partial;            /* scratch, p3d_block_tail_partial_bytes(b) */
     double* tail_sums;              /* [C_in][P3D_TAIL_ROWS][3], written here */
     const double* open_sums;        /* this block as the producer: the sums a consumer's backward left (its tail_sums), or NULL: the opening pass computes them */
+    /* masked blocks (p3d_block_desc.masked), conv i of the main chain: pix_in[i] = mask_in [N][1][H_i][W_i] of its input pixels, pix_out[i] = the renormalisation
+       factor `mult` [N][1][Ho_i][Wo_i] of its output pixels (p3d_mask_count).  y_i = conv_i(a_{i-1} * pix_in[i]) * pix_out[i]. */
+    const float* pix_in[4];
+    const float* pix_out[4];
 } p3d_block_io;
 #define P3D_TAIL_ROWS 16
 /* 1 when p3d_block_bwd(b) can compute its producer's opening sums (io->tail_*): dx needed, and its last writer a dense, unsplit stride-1 data gradient on image operands */

@@ -441,3 +441,70 @@ def test_opening_sums_from_the_consumer_blocks_epilogue(pkg, consumer):
         assert ob.TAIL_STATS['opening_passes_skipped'] == before['opening_passes_skipped']
         for k in base2:
             assert (fused2[k] - base2[k]).abs().max().item() <= 2e-5 * base2[k].abs().max().item(), k
+
+
+#                kind          inplanes planes stride dil  N  H   downsample
+MASKED_CASES = [('bottleneck', 64, 64, 1, 1, 3, 32, True),         # partial_depthnet layer1.0: 64-channel partial convs (the 64-row tiles), dense stride-1 downsample
+                ('bottleneck', 256, 64, 1, 1, 4, 32, False),       # layer1.1+
+                ('bottleneck', 256, 128, 2, 1, 4, 32, True),       # layer2.0: a strided 3x3 partial conv (strided data gradient with the input-mask factor)
+                ('bottleneck', 512, 128, 1, 1, 4, 16, False),      # layer2.1+
+                ('basic', 64, 64, 1, 1, 4, 32, False),             # ResNet-18 layer1: conv 1 is a 3x3 partial conv on the fp32 block input
+                ('basic', 64, 128, 2, 1, 4, 32, True)]             # ResNet-18 layer2.0
+
+
+@pytest.mark.parametrize('case', MASKED_CASES, ids=['%s_c%d_p%d_s%d_n%d_h%d%s' % (c[0], c[1], c[2], c[3], c[5], c[6], '_ds' if c[7] else '') for c in MASKED_CASES])
+def test_masked_block_on_the_executor_matches_the_per_layer_path(case, pkg):
+    """A residual block of partial convolutions (partial_depthnet.py:62-75,140-157; partial_conv.py:32-57) as ONE executor call per direction -- mask_in multiplied
+    into the activation images (or into the in-kernel split of the fp32 block input), mult into the conv epilogues in front of the BatchNorm statistics and into
+    the gradient images -- against the per-layer path (one autograd node per PartialConv / BatchNorm, itself pinned to the reference's goldens): output, mask_out,
+    input gradient, every parameter gradient, running statistics.  The mask has holes, fully masked windows included."""
+    kind, inplanes, planes, stride, dil, n, h, with_ds = case
+    tr = pkg._trunk
+    block_cls = tr.Bottleneck if kind == 'bottleneck' else tr.BasicBlock
+    ds = None
+    if with_ds:
+        ds = tr.Sequential(pkg.nn.Conv2d(inplanes, planes * block_cls.expansion, kernel_size=1, stride=stride, bias=False), pkg.nn.BatchNorm2d(planes * block_cls.expansion))
+    torch.manual_seed(11)
+    block = block_cls(inplanes, planes, stride, dil, ds, partial=True)
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    block = block.cuda().train()
+    _decide_relus(block, 31)        # every ReLU is on or off for a whole channel: one flipped activation would move a whole channel's gradient through the BatchNorm sums
+    gen = torch.Generator(device='cuda').manual_seed(21)
+    x0 = torch.randn(n, inplanes, h, h, device='cuda', generator=gen)
+    veil = (torch.rand(n, 1, h, h, device='cuda', generator=gen) > 0.3).float()
+    veil[0, 0, :9, :11] = 0.0
+    assert pkg.ops_block.usable(block, x0, veil)
+
+    def go(fused):
+        before = pkg._trunk.FUSED_BLOCKS
+        pkg._trunk.FUSED_BLOCKS = fused
+        try:
+            state = {k: v.clone() for k, v in block.state_dict().items()}
+            block.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y, vo = block((x, veil))
+            if not hasattr(go, 'dy'):
+                go.dy = torch.randn(y.shape, device='cuda', generator=gen)
+            y.backward(go.dy)
+            pkg.ops.join_side_stream()
+            torch.cuda.synchronize()
+            res = dict(y=y.detach().clone(), vo=vo.clone(), dx=x.grad.clone(), node=type(y.grad_fn).__name__, grads={k: p.grad.clone() for k, p in block.named_parameters()},
+                       buffers={k: v.clone() for k, v in block.state_dict().items() if 'running' in k})
+            block.load_state_dict(state)
+            return res
+        finally:
+            pkg._trunk.FUSED_BLOCKS = before
+
+    plain = go(False)
+    fused = go(True)
+    assert fused['node'].startswith('ResidualBlockFn') and not plain['node'].startswith('ResidualBlockFn')
+    assert torch.equal(fused['vo'], plain['vo'])
+    assert rel(fused['y'], plain['y']) < 2e-5
+    assert rel(fused['dx'], plain['dx']) < 5e-5
+    for k in plain['grads']:
+        assert rel(fused['grads'][k], plain['grads'][k]) < 1e-4, (k, rel(fused['grads'][k], plain['grads'][k]))
+    for k in plain['buffers']:
+        assert rel(fused['buffers'][k], plain['buffers'][k]) < 1e-5, k
