@@ -197,6 +197,14 @@ class TrunkBase(nn.Module):
                 module.eval()
 
 
+def stem_tail(bn, pool, c):
+    """maxpool(relu(bn(c))) behind a stem convolution that was called separately (the partial families' PartialConv stems return (c, veil)): in training, fp32,
+    one node that never writes the BatchNorm output (ops.stem_tail), otherwise the two layers."""
+    if ops.stem_tail_usable(c, bn, pool):
+        return ops.stem_tail(c, bn)
+    return pool(bn(c, relu=True))
+
+
 def stem(conv, bn, pool, x):
     """conv -> BN+ReLU (one kernel) -> maxpool; at inference conv + BN + ReLU are one kernel."""
     if ops.can_fuse_eval(x, conv, bn):

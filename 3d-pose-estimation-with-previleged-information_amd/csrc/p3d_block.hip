@@ -390,7 +390,8 @@ int32_t p3d_block_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, s
         const size_t open = (size_t)d->K * CLOSE_MAX_SPLIT * 3 * sizeof(double), open2 = (size_t)d->C * CLOSE_MAX_SPLIT * 3 * sizeof(double);
         if (open > part) part = open;
         if (open2 > part) part = open2;
-        const size_t slabs = (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
+        const int ns = fx_wgrad_splits(d, false) > fx_wgrad_splits(d, true) ? fx_wgrad_splits(d, false) : fx_wgrad_splits(d, true);
+        const size_t slabs = (size_t)ns * d->K * d->C * d->R * d->S * sizeof(float);
         if (slabs > sw) sw = slabs;
     }
     if (main_bytes) *main_bytes = align256(mw) + 2 * align256(part);          // (two partial-sum regions: the closing conv's and the downsample conv's live side by side)
@@ -575,7 +576,7 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
         FxFuse fw{};
         fw.dy_img = io->dcimg[slot]; fw.x_img = ximg;
         if (b->masked && slot != 3 && !ximg) fw.emask = io->pix_in[slot];      // the block input is fp32: x * mask_in in the kernel's split (an image carries it)
-        const int splits = fx_wgrad_splits(d);
+        const int splits = fx_wgrad_splits(d, ximg != nullptr);
         if (int32_t e = fx_conv_wgrad_slabs(d, nullptr, xin, (float*)side_workspace, splits, &fw, ss)) return e;
         p3d_conv_desc dw_desc = *d;
         dw_desc.accumulate = acc;
@@ -808,7 +809,8 @@ size_t p3d_fx_conv_img_workspace_bytes(const p3d_conv_desc* d, int32_t pass) {
     if (!d) return 0;
     if (pass == 0) return fx_fwd_workspace(d);
     if (pass == 1) return fx_dgrad_workspace(d);
-    return (size_t)fx_wgrad_splits(d) * d->K * d->C * d->R * d->S * sizeof(float);
+    const int ns = fx_wgrad_splits(d, false) > fx_wgrad_splits(d, true) ? fx_wgrad_splits(d, false) : fx_wgrad_splits(d, true);
+    return (size_t)ns * d->K * d->C * d->R * d->S * sizeof(float);
 }
 
 // bit 0 / 1 / 2: the forward / data-gradient / weight-gradient pass of this convolution can run on image operands
@@ -846,7 +848,7 @@ int32_t p3d_fx_conv_wgrad_img(const p3d_conv_desc* d, const void* dy_img, const 
                               void* stream) {
     P3D_REQUIRE(d && dy_img && (x || x_img) && dw, "fx_conv_wgrad_img: null argument");
     P3D_REQUIRE(fx_wgrad_applies(d, 32) && d->K % 16 == 0 && (!x_img || d->C % 16 == 0), "fx_conv_wgrad_img: shape outside the x3 kernels");
-    const int splits = fx_wgrad_splits(d);
+    const int splits = fx_wgrad_splits(d, x_img != nullptr);
     const size_t need = (size_t)splits * d->K * d->C * d->R * d->S * sizeof(float);
     if (!workspace || workspace_bytes < need) { set_error("fx_conv_wgrad_img: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
     FxFuse f{};

@@ -40,6 +40,10 @@ struct FxConvParams {
     int kchunk;             // K steps per split (0: no split-K; otherwise blockIdx.y selects the slab)
     int accumulate;
     int tiles_m;
+    int tap_inner;          // K-step order of a multi-tap launch: 0 tap outer (all channel steps of a tap, then the next tap), 1 tap inner (the taps of a 16-channel
+                            // step back to back: the shifted windows of one channel group are the same cache lines, which a wide layer otherwise re-fetches per tap)
+    int order;              // block order inside an XCD's run of logical ids: 0 channel tile fastest (consecutive blocks share an activation tile), 1 pixel tile fastest
+                            // (consecutive blocks share a weight tile and stream its K steps together: layers whose weight image outweighs what an L2 holds)
     int ncls;               // > 0: a strided data gradient whose parity classes run as ONE launch, class blockIdx.z overriding the fields above from cls[]
     FxConvClass cls[4];
 };
@@ -55,6 +59,7 @@ struct FxWgradParams {
     float* slabs;           // [split][K][taps][C]
     int N, K, C, Hi, Wi, OH, OW, R, S, stride, pad, dil;
     int nsplit, spb;        // K steps (16 pixels each) per split
+    int order;              // logical block order: 0 (input-channel tile, output-channel tile, tap, slab), 1 (tap, output-channel tile, input-channel tile, slab)
 };
 
 // what a launch adds to the plain convolution; null pointers = not used
@@ -106,7 +111,8 @@ size_t fx_fwd_workspace(const p3d_conv_desc* d);
 size_t fx_dgrad_workspace(const p3d_conv_desc* d);
 int fx_partial_rows_fwd(const p3d_conv_desc* d);
 int fx_partial_rows_dgrad(const p3d_conv_desc* d);
-int fx_wgrad_splits(const p3d_conv_desc* d);
+int fx_wgrad_splits(const p3d_conv_desc* d, bool images = false);      // images: dy AND x arrive as images (the slab count of fx_wgrad_two_taps layers differs)
+bool fx_wgrad_two_taps(const p3d_conv_desc* d, bool images);
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st);
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,

@@ -163,8 +163,10 @@ __device__ __forceinline__ FxConvParams fx_class_params(const FxConvParams& in) 
     return p;
 }
 
-template <int AMODE, int PRO, int EPIX>
+// TAPI (image-fed multi-tap launches of wide layers, FxConvParams::tap_inner): the K steps walk the taps innermost
+template <int AMODE, int PRO, int EPIX, bool TAPI = false>
 __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in) {
+    static_assert(!TAPI || AMODE == 1, "the tap-inner K order is an image-fed instance");
     // EPIX 5 / 6 / 7 = EPI 1 / 2 / 0 with the result first multiplied by emask[pixel] (a partial convolution inside the residual-block executor: the BatchNorm sums are
     // taken of the renormalised result); EPIX 4 = the per-layer partial convolution (factor, no sums)
     constexpr int EPI = EPIX == 5 ? 1 : EPIX == 6 ? 2 : EPIX == 7 ? 0 : EPIX;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+    const int tiles_n_all = gridDim.x / p.tiles_m;
+    const int tile_m = p.order ? bid / tiles_n_all : bid % p.tiles_m, tile_n = p.order ? bid % tiles_n_all : bid / p.tiles_m;
     const int m0 = tile_m * FX_BM, n0 = tile_n * FX_BN;
     const int OHW = p.OH * p.OW;
     const int HWi = p.Hi * p.Wi;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
         nk = min(nk - kt0, p.kchunk);
     }
     int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
+    if constexpr (TAPI) { f_k = (kt0 / p.ntap) * FX_BK; f_tap = kt0 - (kt0 / p.ntap) * p.ntap; }       // K step kt = (channel step kt / ntap, tap kt % ntap)
 
     // weight operand: three 16-B chunks of the K step's 12 KB image tile
     const i32x4 rW = fx_rsrc(p.Wimg, (size_t)p.R * p.S * p.tiles_m * csteps * (3 * FX_PIECE));
@@ -288,8 +292,11 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
             }
             if constexpr (PRO == 4) smask = tmask;            // (the factor of the tap these loads belong to: the next fetch may already be at another tap)
         }
-        f_k += FX_BK;
-        if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+        if constexpr (TAPI) { if (++f_tap == p.ntap) { f_tap = 0; f_k += FX_BK; } }
+        else {
+            f_k += FX_BK;
+            if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+        }
     };
     // LDS addresses of this thread's staging stores, relative to a buffer's first piece
     const int st_p[2] = {fx_tr_off(trow, tp4 >> 1) + 8 * (tp4 & 1), fx_tr_off(trow + 8, tp4 >> 1) + 8 * (tp4 & 1)};
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(256, 3) void fx_conv_kernel(const FxConvParams p_in
 // by fetching, for LDS position 16 t, the chunk that belongs there.
 // In the accumulator a lane is output channel (lane & 15) of a 16-channel group and holds four consecutive pixels 4 (lane >> 4) .. + 3 of a 16-pixel group.
 // ------------------------------------------------------------------------------------------------------------------------------------------
-template <int BM, int EPI>
+template <int BM, int EPI, bool TAPI = false>
 __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_in) {
     const FxConvParams p = fx_class_params(p_in);
     static_assert(BM == 128 || BM == 96 || BM == 64, "channel tile");
@@ -624,7 +631,8 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+    const int tiles_n_all = gridDim.x / p.tiles_m;
+    const int tile_m = p.order ? bid / tiles_n_all : bid % p.tiles_m, tile_n = p.order ? bid % tiles_n_all : bid / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * FX_BN;
     const int OHW = p.OH * p.OW;
     const int HWi = p.Hi * p.Wi;
@@ -637,6 +645,7 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_
         nk = min(nk - kt0, p.kchunk);
     }
     int f_tap = kt0 / csteps, f_k = (kt0 - f_tap * csteps) * FX_BK;
+    if constexpr (TAPI) { f_k = (kt0 / p.ntap) * FX_BK; f_tap = kt0 - (kt0 / p.ntap) * p.ntap; }       // K step kt = (channel step kt / ntap, tap kt % ntap)
 
     // weight operand: chunk id (piece, row of the tile, half) -> where it lies in the weight image (per 128-row tile and K step: 12 KB, fx_rc_off inside a piece)
     const i32x4 rW = fx_rsrc(p.Wimg, (size_t)p.R * p.S * tiles128 * csteps * (3 * FX_PIECE));
@@ -694,8 +703,11 @@ __global__ __launch_bounds__(256, 3) void fx16_conv_kernel(const FxConvParams p_
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) rxi[pc] = fx_buffer_load_i32x4(rXi[pc], x_voff, so, 0);
         }
-        f_k += FX_BK;
-        if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+        if constexpr (TAPI) { if (++f_tap == p.ntap) { f_tap = 0; f_k += FX_BK; } }
+        else {
+            f_k += FX_BK;
+            if (f_k == p.Cred) { f_k = 0; ++f_tap; }
+        }
     };
     auto stage = [&](int buf) {
         unsigned char* pb = lds + buf * BUFB;
@@ -968,8 +980,11 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // TAPS (the 7x7 stride-2 stem restated as a 4x4 stride-1 convolution over a space-to-depth image with ONE 16-channel group: fx_stem_*): the columns of the
 // GEMM are (filter tap, channel) pairs, a 128-column tile = eight taps, and what is a channel group for an ordinary image operand is a tap here: the thread's
 // chunk is the pixel's one 32-B row, fetched at the tap's offset.  grid (taps / 8, K tiles, splits); slabs [split][k][taps * 16].
-template <bool AIMG, bool BIMG, bool MASKED, bool TAPS = false>
+// TAPS 2 (image-fed 64-input-channel layers with a multi-tap filter: ResNet-50's layer1 3x3, ResNet-18's): a 128-column tile = TWO filter taps x 64 channels, so a 64 x 64
+// weight block per tap no longer leaves three of the four waves without work (both column waves live).  grid (ceil(taps / 2), K tiles, splits); slabs as ever.
+template <bool AIMG, bool BIMG, bool MASKED, int TAPS = 0>
 __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
+    static_assert(TAPS != 2 || (AIMG && BIMG && !MASKED), "the two-tap column tile is an image-fed instance");
     static_assert(!MASKED || !AIMG || !BIMG, "the partial-convolution factors are applied by the in-kernel split of an fp32 operand (an image carries its factor already)");
     static_assert(!TAPS || BIMG, "tap-major columns come from an image operand");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
@@ -984,10 +999,22 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
         const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        bx = bid % gx;
-        const int rest = bid / gx;
-        by = rest % gy;
-        bz = rest / gy;
+        if (p.order == 0 || TAPS) {
+            bx = bid % gx;
+            const int rest = bid / gx;
+            by = rest % gy;
+            bz = rest / gy;
+        } else {
+            // filter tap fastest, then the output-channel tile, then the input-channel tile, the pixel slab slowest: the blocks an XCD holds at one time read few x
+            // tiles (the taps of one tile are shifted views of the same lines) -- for a wide input and few output channels (the 2048 -> 272 regressor: 27 blocks per
+            // x tile) that is what keeps x from being fetched once per (output-channel tile, tap)
+            const int nt = p.R * p.S;
+            const int tp = bid % nt;
+            int rest = bid / nt;
+            by = rest % gy; rest /= gy;
+            bx = rest % gx;
+            bz = (rest / gx) * nt + tp;
+        }
     }
     const int m0 = by * FX_BM, n0 = bx * FX_BN;
     const int ntaps = TAPS ? 1 : p.R * p.S;
@@ -1006,10 +1033,12 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // the group's 16-B chunks share a bank quad of the "tr" image)
     const int ih = t & 1, ipix = ((t >> 1) & 1) | (((t >> 3) & 3) << 1) | (((t >> 2) & 1) << 3), icg = t >> 5;
     const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
-    const int KG = p.K >> 4, CG = TAPS ? 1 : p.C >> 4;
-    const int a_cg = (m0 >> 4) + icg, b_cg = TAPS ? 0 : (n0 >> 4) + icg;
-    const bool ai_ok = a_cg < KG, bi_ok = TAPS ? true : b_cg < CG;
-    const int t_tap = (n0 >> 4) + icg, t_dh = t_tap / p.S - p.pad, t_dw = t_tap - (t_tap / p.S) * p.S - p.pad;      // TAPS: this thread's filter tap (stride 1)
+    const int KG = p.K >> 4, CG = TAPS == 1 ? 1 : p.C >> 4;
+    // TAPS 1 / 2: this thread's filter tap (one per 16-column / 64-column group of the tile) and its input offset
+    const int t_tap = TAPS == 2 ? 2 * bx + (icg >> 2) : (n0 >> 4) + icg;
+    const int t_dh = (t_tap / p.S) * p.dil - p.pad, t_dw = (t_tap - (t_tap / p.S) * p.S) * p.dil - p.pad;
+    const int a_cg = (m0 >> 4) + icg, b_cg = TAPS == 1 ? 0 : TAPS == 2 ? (icg & 3) : (n0 >> 4) + icg;
+    const bool ai_ok = a_cg < KG, bi_ok = TAPS == 1 ? true : TAPS == 2 ? t_tap < p.R * p.S : b_cg < CG;
     // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
     // pixel position of the K step in a wave-uniform scalar offset.  (fx_wgrad_applies bounds every tensor below 2^29 elements.)
     i32x4 rA, rB, rAi[3], rBi[3];
@@ -1019,7 +1048,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     } else rA = fx_rsrc(p.DY, (size_t)p.N * p.K * OHW * sizeof(float));
     if constexpr (BIMG) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * (TAPS ? 16 : p.C) * HWi * 2);
+        for (int pc = 0; pc < 3; ++pc) rBi[pc] = fx_rsrc(p.Ximg + pc * p.x_plane, (size_t)p.N * (TAPS == 1 ? 16 : p.C) * HWi * 2);
     } else rB = fx_rsrc(p.X, (size_t)p.N * p.C * HWi * sizeof(float));
     const i32x4 rAM = fx_rsrc(MASKED && !AIMG ? p.amask : nullptr, MASKED && !AIMG ? (size_t)p.N * OHW * sizeof(float) : 0);
     const i32x4 rBM = fx_rsrc(MASKED && !BIMG ? p.bmask : nullptr, MASKED && !BIMG ? (size_t)p.N * HWi * sizeof(float) : 0);
@@ -1154,7 +1183,8 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
         if constexpr (BIMG) fx_tr_frag_off(lane, wn * 64 + a * 32, rd_b[a]);
         else rd_b[a][0] = rd_b[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
     }
-    const int live_a = fx_live_subtiles(m0 + wm * 64, p.K), live_b = fx_live_subtiles(n0 + wn * 64, p.C);
+    const int live_a = fx_live_subtiles(m0 + wm * 64, p.K);
+    const int live_b = TAPS == 2 ? (2 * bx + wn < p.R * p.S ? 2 : 0) : fx_live_subtiles(n0 + wn * 64, p.C);      // (TAPS 2: a column wave = one tap's 64 channels)
     if (nk > 0) { fetch(); stage(0); if (nk > 1) fetch(); }       // software pipeline as in fx_conv_kernel: stage step kt + 1 at the head of step kt, fetch step kt + 2
     __syncthreads();
     auto kloop = [&](auto nat, auto nbt) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles
@@ -1208,18 +1238,19 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     else if (live_a == 2 && live_b == 1) kloop(I2{}, I1{});
     else kloop(I1{}, I1{});
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
-    const int RS = TAPS ? 1 : p.R * p.S;
+    const int RS = TAPS == 1 ? 1 : p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;
+    const int otap = TAPS == 2 ? 2 * bx + wn : tap;                         // (TAPS 2: the column wave's tap; its 64 columns are the layer's 64 input channels)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int c = n0 + wn * 64 + b * 32 + fr;
-            if (c >= p.C) continue;
+            const int c = TAPS == 2 ? b * 32 + fr : n0 + wn * 64 + b * 32 + fr;
+            if (c >= p.C || otap >= RS) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (k < p.K) out[((size_t)k * RS + tap) * p.C + c] = acc[a][b][r];
+                if (k < p.K) out[((size_t)k * RS + otap) * p.C + c] = acc[a][b][r];
             }
         }
 }
@@ -1557,6 +1588,26 @@ static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0
 // image-fed forward / data gradient on v_mfma_f32_16x16x32_bf16 (fx16_conv_kernel): -1 = environment (P3D_FX16), 0 never, 1 (default) where its 64- and 96-row
 // channel tiles fit the layer better than 128 rows, 2 everywhere (the A/B of the two MFMA shapes: profiles/r04_fx16.md -- at 128 rows the 16x16x32 form is 1-3 %
 // SLOWER on the large layers, 20 fragment reads per step against 12, and the chip holds no higher clock on it in these kernels)
+// image-fed multi-tap launches with at least this many reduction channels walk the taps innermost (0: never; p3d_fx_tune(10, v)).  Measured (tools/r4_i.sh): the
+// regressor's forward (2048 channels x 9 taps) fetches 5.5x fewer bytes beyond L2 and runs 2 % faster; the 512-channel 3x3 layers fetch 3.1x fewer but run 2 % slower
+// (a tap change per K step costs more than their re-reads out of the Infinity Cache): 1024 takes the first and leaves the second
+static int g_tap_inner_min = 1024;
+static int g_two_taps = 1;             // image-fed weight gradients of 64-input-channel multi-tap layers: two taps per column tile; p3d_fx_tune(9, 0): off (A/B)
+static int g_conv_order = -1, g_wgrad_order = -1;      // -1: the built-in choice (fx_conv_order / fx_wgrad_order); 0 / 1 forced (p3d_fx_tune(7 / 8, v): A/B)
+// Which operand should the blocks an XCD runs at one time share?  An XCD's L2 holds 4 MB.  With the channel tile fastest an activation tile is fetched once and every
+// pixel tile streams the WHOLE weight image past the L2 (fine while that image stays in it); with the pixel tile fastest the ~96 resident blocks stream one
+// channel tile's weights together and each its own pixels.  Measured (profiles/r04_summary.md section 4): layer4 and the regressor fetched 3.7 - 28 x their algorithmic bytes.
+// MEASURED (tools/r4_g.sh, profiles/r04_summary.md section 4): the pixel-tile-fastest order is 1 - 46 % SLOWER on every shape, layer4 and the regressor included (forward
+// 0.896 vs 0.845 ms): the bytes FETCH_SIZE counts beyond L2 come out of the 256 MB Infinity Cache at a rate these matrix-pipe-bound kernels do not feel, while losing
+// the shared activation tile costs L2 hits they do.  So the built-in choice stays 0 everywhere; the switches remain for the record (p3d_fx_tune(7 / 8, 1)).
+static int fx_conv_order(size_t wimg_bytes, int tiles_m, int tiles_n) {
+    (void)wimg_bytes; (void)tiles_m; (void)tiles_n;
+    return g_conv_order > 0 ? 1 : 0;
+}
+static int fx_wgrad_order(const p3d_conv_desc* d) {
+    (void)d;
+    return g_wgrad_order > 0 ? 1 : 0;
+}
 static int g_class_launches = 0;      // 1: one launch per parity class of a strided data gradient (the round-3 form; p3d_fx_tune(5, 1), A/B and tests)
 static int g_fx16 = -1;
 static int fx16_mode() {
@@ -1576,6 +1627,10 @@ static int fx16_bm(int M, bool img, int pro, int epi) {
 void fx_tune(int what, int value) {
     if (what == 3) { g_pair_map = value; return; }      // 0: the two opening image passes of a downsample block as two launches (A/B, tests)
     if (what == 5) { g_class_launches = value ? 1 : 0; return; }
+    if (what == 9) { g_two_taps = value ? 1 : 0; return; }
+    if (what == 10) { g_tap_inner_min = value; return; }
+    if (what == 7) { g_conv_order = value; return; }
+    if (what == 8) { g_wgrad_order = value; return; }
     if (what == 4) { g_fx16 = value < 0 || value > 2 ? 1 : value; return; }  // A/B of the two MFMA shapes in one process
     (what == 0 ? g_force_wgrad_splits : what == 1 ? g_force_conv_splits : g_wgrad_target) = value;
 }
@@ -1699,8 +1754,17 @@ int32_t fx_build_weight_images(const float* w, int K, int C, int RS, void* img_f
     return check_launch("fx_build_weight_images");
 }
 
-static void fx_launch_conv(const FxConvParams& p, bool img, int pro, int epi, int bm, dim3 grid, hipStream_t st) {
+static void fx_launch_conv(const FxConvParams& p_in, bool img, int pro, int epi, int bm, dim3 grid, hipStream_t st) {
     const int am = img ? 1 : 0;
+    FxConvParams p = p_in;
+    // the tap-inner instances exist where the layers that want them land: 128-row tiles with the plain / BatchNorm epilogues, and the 96-row fx16 tile (the regressor)
+    if (p.tap_inner && !((bm == 0 && am == 1 && pro == 0 && epi >= 0 && epi <= 2) || (bm == 96 && epi >= 0 && epi <= 2))) p.tap_inner = 0;
+    if (p.tap_inner) {
+#define P3D_FX_TAPI(EPI) if (bm == 0 && epi == EPI) { hipLaunchKernelGGL((fx_conv_kernel<1, 0, EPI, true>), grid, dim3(256), 0, st, p); return; } \
+                         if (bm == 96 && epi == EPI) { hipLaunchKernelGGL((fx16_conv_kernel<96, EPI, true>), grid, dim3(256), 0, st, p); return; }
+        P3D_FX_TAPI(0) P3D_FX_TAPI(1) P3D_FX_TAPI(2)
+#undef P3D_FX_TAPI
+    }
     // (the fx16 kernel applies p.emask at run time: the masked epilogues 5 / 6 / 7 are its 1 / 2 / 0 with the factor pointer set)
 #define P3D_FX16_CASE(BM, EPI) if (bm == BM && (epi == EPI || epi == (EPI == 0 ? 7 : EPI + 4))) { hipLaunchKernelGGL((fx16_conv_kernel<BM, EPI>), grid, dim3(256), 0, st, p); return; }
     P3D_FX16_CASE(128, 0) P3D_FX16_CASE(128, 1) P3D_FX16_CASE(128, 2)
@@ -1760,6 +1824,8 @@ int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, cons
     const FxSplit sp = fx_fwd_split(d);
     const int bm = fx16_bm(d->K, img, sp.splits > 1 ? 0 : pro, sp.splits > 1 ? 0 : epi);
     p.tiles_m = (int)ceil_div(d->K, bm ? bm : FX_BM);
+    p.order = fx_conv_order(fx_weight_image_bytes(d->K, d->C, RS, false), p.tiles_m, tiles_n);
+    p.tap_inner = img && RS > 1 && g_tap_inner_min > 0 && d->C >= g_tap_inner_min;
     if (sp.splits > 1) {
         p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->K * d->Ho * d->Wo; p.Y = (float*)ws; p.bias = nullptr;
         const float* em = p.emask;
@@ -1810,6 +1876,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         if (masked) { pro = img ? 0 : 4; epi = fuse->partial ? 6 : (img ? 7 : 4); p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     const bool dsplit = d->stride == 1 && fx_dgrad_split(d).splits > 1;
+    p.tap_inner = img && RS > 1 && g_tap_inner_min > 0 && d->K >= g_tap_inner_min;
     if (fuse && fuse->tail_c) {
         if (!(img && epi == 0 && pro == 0 && fx_dgrad_tail_applies(d) && fuse->tail_tab && fuse->tail_partial && (!fuse->tail_rc || fuse->tail_rtab))) {
             set_error("fx_conv_dgrad: the tail sums need an image-fed, dense, unsplit stride-1 data gradient without a BatchNorm epilogue (fx_dgrad_tail_applies)"); return P3D_EINVAL;
@@ -1825,6 +1892,7 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         p.hmul = 1; p.hoff = d->pad; p.hstep = -d->dil; p.wmul = 1; p.woff = d->pad; p.wstep = -d->dil;
         const int tiles_n = (int)ceil_div(p.NP, FX_BN);
         const FxSplit sp = fx_dgrad_split(d);
+        p.order = fx_conv_order(fx_weight_image_bytes(d->K, d->C, RS, true), p.tiles_m, tiles_n);
         if (sp.splits > 1) {
             p.kchunk = sp.kchunk; p.slab_stride = (size_t)d->N * d->C * d->H * d->W; p.Y = (float*)ws;
             const float* em = p.emask;
@@ -1905,8 +1973,13 @@ bool fx_dgrad_accumulates_from_source(const p3d_conv_desc* d) { return d->stride
 // blocks are resident at once (two or three per CU), so what matters is how evenly tiles x slabs covers the 256 CUs and whether the taps of one slab land on
 // one XCD.  The round-2 plan (576 blocks for the 3x3 grids, 512 / 768 for powers of two, 3072 for the regressor) left 15-22 % on the 9-, 16-, 36- and
 // 144-tile classes and 3 % on the regressor; other tile counts aim at one full round of three blocks per CU.
-int fx_wgrad_splits(const p3d_conv_desc* d) {
-    const int64_t tiles = ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
+// image-fed weight gradients of 64-input-channel multi-tap layers pack two taps into a column tile (fx_wgrad_kernel<.., TAPS 2>)
+bool fx_wgrad_two_taps(const p3d_conv_desc* d, bool images) {
+    static const bool env_on = [] { const char* e = getenv("P3D_TWO_TAPS"); return !(e && atoi(e) == 0); }();      // P3D_TWO_TAPS=0: A/B from the environment
+    return g_two_taps && env_on && images && d->C == 64 && d->R * d->S > 1 && (d->Wo & 15) == 0;
+}
+int fx_wgrad_splits(const p3d_conv_desc* d, bool images) {
+    const int64_t tiles = fx_wgrad_two_taps(d, images) ? ceil_div(d->K, FX_BM) * ceil_div(d->R * d->S, 2) : ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
     int64_t target;
     if (g_wgrad_target > 0) target = g_wgrad_target;          // (tuning aid: p3d_fx_tune, tools/split_sweep.py)
@@ -1914,6 +1987,7 @@ int fx_wgrad_splits(const p3d_conv_desc* d) {
     else switch ((int)tiles) {
         case 2: target = 384; break;
         case 4: target = 640; break;
+        case 5: target = 512; break;          // (two-tap column tiles of a 64 -> 64 3x3: tools/r4_i.sh)
         case 8: case 32: case 36: target = 512; break;
         case 16: target = 256; break;
         case 128: target = 1024; break;
@@ -1936,6 +2010,7 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.nsplit = splits;
     p.spb = (int)ceil_div((int64_t)d->N * (d->Ho * d->Wo / FX_BK), splits);
+    p.order = fx_wgrad_order(d);
     bool aimg = false, bimg = false, masked = false;
     if (fuse) {
         if (fuse->dy_img) { aimg = true; p.DYimg = (const unsigned char*)fuse->dy_img; p.dy_plane = (size_t)d->N * d->K * d->Ho * d->Wo * 2; }
@@ -1950,6 +2025,10 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     }
     if ((aimg && (d->K & 15)) || (bimg && (d->C & 15)) || (bimg && !aimg)) { set_error("fx_conv_wgrad: image operands need channel counts in steps of 16 (and a dy image beside an x image)"); return P3D_EINVAL; }
     const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
+    if (fx_wgrad_two_taps(d, aimg && bimg && !masked)) {
+        hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 2>), dim3((unsigned)ceil_div(d->R * d->S, 2), (unsigned)ceil_div(d->K, FX_BM), (unsigned)splits), dim3(256), 0, st, p);
+        return check_launch("fx_conv_wgrad");
+    }
     if (masked && aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, true>), grid, dim3(256), 0, st, p);
     else if (masked) hipLaunchKernelGGL((fx_wgrad_kernel<false, false, true>), grid, dim3(256), 0, st, p);
     else if (aimg && bimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false>), grid, dim3(256), 0, st, p);
@@ -2110,9 +2189,9 @@ int32_t fx_stem_wgrad(const float* dy, const float* mult, const void* x_img, flo
     p.spb = (int)ceil_div((int64_t)N * (H2 * W2 / FX_BK), p.nsplit);
     if (mult) {      // partial convolution: dw = wgrad(dy * mult, x * mask_in); the image holds x * mask_in, dy is scaled on its way into LDS
         p.amask = mult;
-        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, true, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, true, 1>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
     } else
-        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, true>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, 1>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
     hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K, 4), dim3(1024), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
     return check_launch("fx_stem_wgrad");
 }

@@ -7,7 +7,7 @@ partial blocks as an (x, veil) tuple; layer3/4 and every shortcut are dense (par
 import torch
 
 from . import ops
-from ._trunk import BasicBlock, Bottleneck, TrunkBase, kaiming_fan_out_, stage_geometry
+from ._trunk import BasicBlock, Bottleneck, TrunkBase, kaiming_fan_out_, stage_geometry, stem_tail
 from .nn import BatchNorm2d, Conv2d, MaxPool2d
 from .partial_conv import PartialConv
 
@@ -36,7 +36,7 @@ class ResNet(TrunkBase):
         with torch.no_grad():
             veil = ops.nonzero_mask(x)                       # fp32 [B,1,H,W] in both precisions
         x, veil = self.conv1(self._half_in(x), veil)
-        x = self.maxpool(self.bn1(x, relu=True))
+        x = stem_tail(self.bn1, self.maxpool, x)
         with torch.no_grad():
             veil = self.maxpool(veil)
         x, veil = self.layer1((x, veil))

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._trunk import BasicBlock, Bottleneck, TrunkBase, normal_fan_out_, stage_geometry, stem
+from ._trunk import BasicBlock, Bottleneck, TrunkBase, normal_fan_out_, stage_geometry, stem, stem_tail
 from .fusionnet import Fusion, manual_update
 from .nn import BatchNorm2d, Conv2d, MaxPool2d
 from .partial_conv import PartialConv
@@ -48,7 +48,7 @@ class ResNet(TrunkBase):
         with torch.no_grad():
             veil = ops.nonzero_mask(y)                                           # partial_fusionnet.py:255
         y, veil = self.conv2(self._half_in(y), veil)
-        y = self.maxpool(self.bn2(y, relu=True))
+        y = stem_tail(self.bn2, self.maxpool, y)
         with torch.no_grad():
             veil = self.maxpool(veil)
         x = self.layer2(self.layer1(x))

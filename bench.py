@@ -188,6 +188,10 @@ def main():
     # what the process group itself reports (N > 1: 'nccl' = RCCL with the world size it was built with; N = 1: no group)
     dist_backend = dist.get_backend() if dist.is_initialized() else None
     dist_world = dist.get_world_size() if dist.is_initialized() else 1
+    # may the bucketed all-reduce run beside the backward pass?  (dist.rccl_overlap_allowed: NCCL_ALGO=Ring and the scanned librccl build, else the reducer sends every
+    # bucket after the pass) -- what the reducer of THIS run decided, with its reason
+    red = trainer.reducer
+    rccl_overlap = {'active': bool(red.active), 'overlapped_with_backward': bool(red.overlap), 'reason': red.overlap_reason} if red.active else None
 
     def sync():
         if dist.is_initialized():
@@ -231,7 +235,7 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'crops/sec (fwd+bwd) ResNet-50 pose head, 256x256 bs=64/GPU', 'value': round(opt.batch * world * opt.steps / elapsed, 2), 'unit': 'crops/s',
                               'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup, 'ms_per_step': round(elapsed / opt.steps * 1e3, 3), 'lean': True,
-                              'dist_backend': dist_backend, 'dist_world_size': dist_world,
+                              'dist_backend': dist_backend, 'dist_world_size': dist_world, 'rccl_overlap': rccl_overlap,
                               'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank))),
                               'step_ms_min_med_max': [round(v, 2) for v in (lambda d: (d[0], d[len(d) // 2], d[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(opt.steps)))],
                               'slowest_step': (lambda d: {'index': d.index(max(d)), 'gpu_ms': round(max(d), 2), 'host_enqueue_ms': round(host[d.index(max(d))], 2),
@@ -351,11 +355,11 @@ def main():
             'config': {'workload': '%s %s pose head, 256x256 crops, batch %d/GPU, full step: fwd + soft-argmax + SmoothL1 + bwd + '
                                    'RCCL grad all-reduce + clip + Adam%s' % (opt.family, opt.model, opt.batch, '; on-GPU colour + eraser augmentation + normalisation of the RGB batch' if opt.augment else ''),
                        'global_batch': opt.batch * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_value, 4),
-                       'dist_backend': dist_backend, 'dist_world_size': dist_world,
+                       'dist_backend': dist_backend, 'dist_world_size': dist_world, 'rccl_overlap': rccl_overlap,
                        'wgrad_stream_runs_beside_launch_stream': ops.SIDE_STREAM_OVERLAPS.get(device, ops.SIDE_STREAM_OVERLAPS.get(torch.device('cuda', local_rank)))},
             'roofline': {'bound': 'mfma',
                          'kernel': 'p3d::hconv_gather_kernel / hconv_wgrad_kernel (fp16 MFMA, NHWC)' if opt.half else
-                                   ('p3d::fx_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16)' if x3_on else
+                                   ('p3d::fx_conv_kernel / fx16_conv_kernel / fx_wgrad_kernel (conv fwd/dgrad/wgrad: exact fp32 as 6 bf16 piece products on v_mfma_f32_32x32x16_bf16; the 64- and 96-row tiles on v_mfma_f32_16x16x32_bf16)' if x3_on else
                                     'p3d::igemm_kernel (conv fwd/dgrad/wgrad on v_mfma_f32_32x32x2_f32)'),
                          'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'peak_note': 'dense f16 MFMA peak' if opt.half else ('fp32-equivalent ceiling of the pipe the kernel runs on: 2500 TFLOP/s dense bf16 / 6 piece products' if x3_on else 'dense fp32 MFMA peak'),

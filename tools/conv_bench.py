@@ -44,7 +44,11 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--mode', default='all', help='all | fwd | dgrad | wgrad')
     ap.add_argument('--img', action='store_true', help='also time the image-fed instances (pre-split activation / gradient images, pre-built weight images: what the block executor launches)')
+    ap.add_argument('--tune', default='', help='p3d_fx_tune settings for this run, e.g. "7=1,8=0" (7: conv block order, 8: wgrad block order; -1 / unset = built-in choice)')
     a = ap.parse_args()
+    for kv in filter(None, a.tune.split(',')):
+        what, value = kv.split('=')
+        L.p3d_fx_tune(int(what), int(value))
     tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0)
     tot_img = dict(fwd=0.0, dgrad=0.0, wgrad=0.0)
     totf = 0.0
