@@ -154,6 +154,10 @@ struct CloseFin {
     float* table;
 };
 __device__ __forceinline__ void close_finalize(const CloseFin& f, int ch, int C, double count, bool owner, double* red /*[12]*/, float& sc, float& sh) {
+    if (f.rows <= 0) {            // finalized by a launch of its own (many partial rows: every (channel, image group) block would re-read them all): the table holds the constants
+        sc = f.table[(size_t)ch * FX_TAB]; sh = f.table[(size_t)ch * FX_TAB + 1];
+        return;
+    }
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int r = threadIdx.x; r < f.rows; r += 256) {
         const float2 v = *reinterpret_cast<const float2*>(f.partial + ((size_t)r * C + ch) * 2);
@@ -189,26 +193,32 @@ __global__ __launch_bounds__(256) void block_close_fwd_kernel(const float* __res
     close_finalize(fin, ch, C, count, s == 0, red, sc, sh);
     const bool ds = rfin.partial != nullptr;
     if (ds) close_finalize(rfin, ch, C, count, s == 0, red, rsc, rsh);
-    for (int n = s; n < N; n += split) {
-        const size_t off = ((size_t)n * C + ch) * HW;
-        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
-        const f32x4* rv = reinterpret_cast<const f32x4*>(res + off);
-        f32x4* ov = reinterpret_cast<f32x4*>(out + off);
-        unsigned char* mv = omask ? omask + off / 4 : nullptr;
-        for (int i = threadIdx.x; i < HW / 4; i += 256) {
-            f32x4 q = cv[i];
-            const f32x4 r = rv[i];
-            unsigned m = 0;
+    // One flat index over (this block's images, 16-B groups of the channel's plane): on the 16 x 16 maps a plane is 64 groups, and a loop per image would leave three
+    // quarters of the block idle in every trip; two groups per trip keep four 16-B loads in flight per thread.
+    const int q4 = HW >> 2, nimg = (N - s + split - 1) / split, total = nimg * q4;
+    auto at = [&](int j) { const int k = j / q4; return ((size_t)(s + k * split) * C + ch) * (size_t)q4 + (j - k * q4); };      // index in 16-B groups
+    const f32x4* cv = reinterpret_cast<const f32x4*>(c);
+    const f32x4* rv = reinterpret_cast<const f32x4*>(res);
+    f32x4* ov = reinterpret_cast<f32x4*>(out);
+    auto one = [&](f32x4 q, const f32x4 r, size_t g) {
+        unsigned m = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = fmaf(q[e], sc, sh) + (ds ? fmaf(r[e], rsc, rsh) : r[e]);
-                m |= (v > 0.f ? 1u : 0u) << e;
-                q[e] = relu ? fmaxf(v, 0.f) : v;
-            }
-            ov[i] = q;
-            if (mv) mv[i] = (unsigned char)m;             // which of the four outputs are positive: what the backward pass needs of `out` (1 byte instead of 16)
+        for (int e = 0; e < 4; ++e) {
+            float v = fmaf(q[e], sc, sh) + (ds ? fmaf(r[e], rsc, rsh) : r[e]);
+            m |= (v > 0.f ? 1u : 0u) << e;
+            q[e] = relu ? fmaxf(v, 0.f) : v;
         }
+        ov[g] = q;
+        if (omask) omask[g] = (unsigned char)m;           // which of the four outputs are positive: what the backward pass needs of `out` (1 byte instead of 16)
+    };
+    int j = threadIdx.x;
+    for (; j + 256 < total; j += 512) {
+        const size_t g0 = at(j), g1 = at(j + 256);
+        const f32x4 q0 = cv[g0], r0 = rv[g0], q1 = cv[g1], r1 = rv[g1];
+        one(q0, r0, g0);
+        one(q1, r1, g1);
     }
+    if (j < total) { const size_t g0 = at(j); one(cv[g0], rv[g0], g0); }
 }
 
 // Opens the block in backward: g = relu ? dout * [out > 0] : dout (written to gbuf when relu), and per channel the sums of g, g * (c - mean) and, with a
@@ -221,39 +231,39 @@ __global__ __launch_bounds__(256) void block_open_bwd_kernel(const float* __rest
     const int ch = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     const float mean = tab[ch * FX_TAB + 2], rmean = rtab ? rtab[ch * FX_TAB + 2] : 0.f;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int n = s; n < N; n += split) {
-        const size_t off = ((size_t)n * C + ch) * HW;
-        const f32x4* dv = reinterpret_cast<const f32x4*>(dout + off);
-        const f32x4* ov = reinterpret_cast<const f32x4*>(out + off);
-        const f32x4* cv = reinterpret_cast<const f32x4*>(c + off);
-        const f32x4* rv = rc ? reinterpret_cast<const f32x4*>(rc + off) : nullptr;
-        f32x4* gv = reinterpret_cast<f32x4*>(gbuf + off);
-        const unsigned char* mv = omask ? omask + off / 4 : nullptr;
-        for (int i = threadIdx.x; i < HW / 4; i += 256) {
-            f32x4 g = dv[i];
-            const f32x4 q = cv[i];
-            if (relu) {
-                if (mv) {
-                    const unsigned m = mv[i];
+    // (one flat index over this block's images and 16-B groups, as in block_close_fwd_kernel: the 16 x 16 maps have 64 groups per plane)
+    const int q4 = HW >> 2, nimg = (N - s + split - 1) / split, total = nimg * q4;
+    const f32x4* dv = reinterpret_cast<const f32x4*>(dout);
+    const f32x4* ov = reinterpret_cast<const f32x4*>(out);
+    const f32x4* cv = reinterpret_cast<const f32x4*>(c);
+    const f32x4* rv = reinterpret_cast<const f32x4*>(rc);
+    f32x4* gv = reinterpret_cast<f32x4*>(gbuf);
+    for (int j = threadIdx.x; j < total; j += 256) {
+        const int k = j / q4;
+        const size_t i = ((size_t)(s + k * split) * C + ch) * (size_t)q4 + (j - k * q4);
+        f32x4 g = dv[i];
+        const f32x4 q = cv[i];
+        if (relu) {
+            if (omask) {
+                const unsigned m = omask[i];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
-                } else {
-                    const f32x4 o = ov[i];
+                for (int e = 0; e < 4; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+            } else {
+                const f32x4 o = ov[i];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-                }
-                if (gbuf) gv[i] = g;           // (null: a block with a downsample branch and mask bytes -- nobody reads g as a tensor, the image passes mask dout themselves)
+                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
             }
-            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a1 += g[e]; a2 = fmaf(g[e], q[e] - mean, a2); }
-            if (rv) {
-                const f32x4 r = rv[i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a3 = fmaf(g[e], r[e] - rmean, a3);
-            }
-            s1 += a1; s2 += a2; s3 += a3;
+            if (gbuf) gv[i] = g;           // (null: a block with a downsample branch and mask bytes -- nobody reads g as a tensor, the image passes mask dout themselves)
         }
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a1 += g[e]; a2 = fmaf(g[e], q[e] - mean, a2); }
+        if (rc) {
+            const f32x4 r = rv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a3 = fmaf(g[e], r[e] - rmean, a3);
+        }
+        s1 += a1; s2 += a2; s3 += a3;
     }
     __shared__ double red[12];
     blk_sum3(s1, s2, s3, red);
@@ -468,6 +478,17 @@ int32_t p3d_block_fwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
     CloseFin rf{};
     if (b->has_downsample)
         rf = CloseFin{partial2, fx_partial_rows_fwd(&b->conv[3]), io->gamma[3], io->beta[3], io->running_mean[3], io->running_var[3], b->momentum[3], b->eps[3], io->table[3]};
+    // With many partial rows (layer1: 2048 pixel tiles) the closing pass's blocks -- one per (channel, image group) -- would each sum all of them again, strided, in front
+    // of their streaming loop (measured: the pass ran at 4.2 TB/s); a finalize launch of its own then costs less (round 4).  rows = 0 tells the pass to read the table.
+    const double cnt_close = (double)dl->N * HW;
+    for (CloseFin* f : {&cf, &rf}) {
+        if (f->partial && f->rows > FX_FIN_MAX_ROWS) {
+            const int slot = f == &cf ? last : 3;
+            hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)ceil_div(dl->K, FIN_CH)), dim3(fin_threads(f->rows)), 0, st, (const float*)f->partial, f->rows, dl->K, cnt_close,
+                               io->gamma[slot], io->beta[slot], io->running_mean[slot], io->running_var[slot], b->momentum[slot], b->eps[slot], io->table[slot]);
+            f->rows = 0;
+        }
+    }
     hipLaunchKernelGGL(block_close_fwd_kernel, dim3(dl->K, close_split(dl->N, dl->K)), dim3(256), 0, st, (const float*)io->c[last], cf,
                        b->has_downsample ? (const float*)io->c[3] : io->x, rf, io->out, b->relu_out ? io->out_mask : (unsigned char*)nullptr, dl->N, dl->K, HW, b->relu_out,
                        (double)dl->N * HW);

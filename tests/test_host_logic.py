@@ -270,3 +270,31 @@ def test_shards_have_equal_length(pkg, monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '1')
     monkeypatch.setenv('RANK', '0')
     assert pkg.depth_datasets.shard(samples, 'train') == samples
+
+
+def test_rccl_overlap_verdict_fails_closed(pkg, monkeypatch):
+    """dist.rccl_overlap_allowed: collectives may run beside the backward pass only with NCCL_ALGO=Ring in this process's environment AND the scanned librccl build
+    mapped; anything else -- a launcher's own NCCL_ALGO, no library to verify, another build -- gives (False, reason), and P3D_RCCL_OVERLAP overrides either way."""
+    d = pkg.dist
+    def verdict(env, mapped=None, size=None):
+        for k in ('NCCL_ALGO', 'P3D_RCCL_OVERLAP'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setattr(d, '_overlap_verdict', None)
+        monkeypatch.setattr(d, '_loaded_rccl_path', lambda: mapped)
+        if size is not None:
+            monkeypatch.setattr(d.os.path, 'getsize', lambda p: size)
+            monkeypatch.setattr(d.os.path, 'exists', lambda p: True)
+        return d.rccl_overlap_allowed()
+    ok, why = verdict({})
+    assert not ok and 'Ring' in why                               # NCCL_ALGO unset: RCCL may pick the tree kernels
+    ok, why = verdict({'NCCL_ALGO': 'Tree'})
+    assert not ok and 'Tree' in why
+    ok, why = verdict({'NCCL_ALGO': 'Ring'})
+    assert not ok and 'no librccl' in why                         # nothing mapped to verify
+    ok, why = verdict({'NCCL_ALGO': 'ring'}, mapped='/somewhere/librccl.so', size=123)
+    assert not ok and 'not the librccl build' in why              # another build: its kernels were never looked at
+    assert verdict({'NCCL_ALGO': 'Tree', 'P3D_RCCL_OVERLAP': '1'})[0]
+    assert not verdict({'NCCL_ALGO': 'Ring', 'P3D_RCCL_OVERLAP': '0'})[0]
+    monkeypatch.setattr(d, '_overlap_verdict', None)
