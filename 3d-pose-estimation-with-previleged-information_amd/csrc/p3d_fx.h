@@ -112,7 +112,7 @@ size_t fx_dgrad_workspace(const p3d_conv_desc* d);
 int fx_partial_rows_fwd(const p3d_conv_desc* d);
 int fx_partial_rows_dgrad(const p3d_conv_desc* d);
 int fx_wgrad_splits(const p3d_conv_desc* d, bool images = false);      // images: dy AND x arrive as images (the slab count of fx_wgrad_two_taps layers differs)
-bool fx_wgrad_two_taps(const p3d_conv_desc* d, bool images);
+int fx_wgrad_two_taps(const p3d_conv_desc* d, bool images);      // taps per column tile: 0 (one-tap tiles), 2 or 3
 int32_t fx_conv_fwd(const p3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                     const FxFuse* fuse, hipStream_t st);
 int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes, const FxFuse* fuse,

@@ -982,9 +982,11 @@ __global__ __launch_bounds__(256) void fx_reduce_kernel(const float* __restrict_
 // chunk is the pixel's one 32-B row, fetched at the tap's offset.  grid (taps / 8, K tiles, splits); slabs [split][k][taps * 16].
 // TAPS 2 (image-fed 64-input-channel layers with a multi-tap filter: ResNet-50's layer1 3x3, ResNet-18's): a 128-column tile = TWO filter taps x 64 channels, so a 64 x 64
 // weight block per tap no longer leaves three of the four waves without work (both column waves live).  grid (ceil(taps / 2), K tiles, splits); slabs as ever.
+// TAPS 3 (the same with at most 64 OUTPUT channels too -- every 3x3 of ResNet-50's layer1 and ResNet-18's): dy fills half of the A image, the other half carries a third tap of
+// x, and three of the four waves multiply dy by one tap each (one block = one filter row of a 3x3).  grid (ceil(taps / 3), 1, splits).
 template <bool AIMG, bool BIMG, bool MASKED, int TAPS = 0>
 __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p) {
-    static_assert(TAPS != 2 || (AIMG && BIMG && !MASKED), "the two-tap column tile is an image-fed instance");
+    static_assert(TAPS < 2 || (AIMG && BIMG && !MASKED), "the multi-tap column tiles are image-fed instances");
     static_assert(!MASKED || !AIMG || !BIMG, "the partial-convolution factors are applied by the in-kernel split of an fp32 operand (an image carries its factor already)");
     static_assert(!TAPS || BIMG, "tap-major columns come from an image operand");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * 3 * FX_PIECE];
@@ -1035,10 +1037,15 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     const bool a_ok[2] = {m0 + row < p.K, m0 + row + 64 < p.K}, b_ok[2] = {n0 + row < p.C, n0 + row + 64 < p.C};
     const int KG = p.K >> 4, CG = TAPS == 1 ? 1 : p.C >> 4;
     // TAPS 1 / 2: this thread's filter tap (one per 16-column / 64-column group of the tile) and its input offset
-    const int t_tap = TAPS == 2 ? 2 * bx + (icg >> 2) : (n0 >> 4) + icg;
+    const int t_tap = TAPS >= 2 ? TAPS * bx + (icg >> 2) : (n0 >> 4) + icg;
     const int t_dh = (t_tap / p.S) * p.dil - p.pad, t_dw = (t_tap - (t_tap / p.S) * p.S) * p.dil - p.pad;
-    const int a_cg = (m0 >> 4) + icg, b_cg = TAPS == 1 ? 0 : TAPS == 2 ? (icg & 3) : (n0 >> 4) + icg;
-    const bool ai_ok = a_cg < KG, bi_ok = TAPS == 1 ? true : TAPS == 2 ? t_tap < p.R * p.S : b_cg < CG;
+    const int a_cg = (m0 >> 4) + icg, b_cg = TAPS == 1 ? 0 : TAPS >= 2 ? (icg & 3) : (n0 >> 4) + icg;
+    const bool ai_ok = a_cg < KG, bi_ok = TAPS == 1 ? true : TAPS >= 2 ? t_tap < p.R * p.S : b_cg < CG;
+    // TAPS 3 (64 output AND 64 input channels): dy fills only columns 0-63 of the A image, so its columns 64-127 carry a THIRD tap of x (fetched by waves 2 and 3, whose
+    // threads own those columns' chunks); waves 0, 1, 2 each multiply dy by one tap's 64 channels, wave 3 only stages
+    const int a3_tap = 3 * bx + 2;
+    const int a3_dh = (a3_tap / p.S) * p.dil - p.pad, a3_dw = (a3_tap - (a3_tap / p.S) * p.S) * p.dil - p.pad;
+    const bool a3_ok = a3_tap < p.R * p.S;
     // Buffer-load fetch (see fx_conv_kernel): per-thread byte offsets with the out-of-range bit for rows beyond the tensor / padding pixels, the image and
     // pixel position of the K step in a wave-uniform scalar offset.  (fx_wgrad_applies bounds every tensor below 2^29 elements.)
     i32x4 rA, rB, rAi[3], rBi[3];
@@ -1070,9 +1077,19 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     auto fetch = [&]() {
         // operand A (dy)
         if constexpr (AIMG) {
-            const int a_so = (f_img * KG * OHW + f_p) * 32;
+            if (TAPS == 3 && wave >= 2) {                 // (wave-uniform) columns 64-127 of the A image: x at the third tap of the block
+                int hi, wi;
+                if (rowwise) { hi = f_oh * p.stride + a3_dh; wi = (f_ow + ipix) * p.stride + a3_dw; }
+                else { const int q = f_p + ipix, oh = q / p.OW, ow = q - oh * p.OW; hi = oh * p.stride + a3_dh; wi = ow * p.stride + a3_dw; }
+                const int voff = (a3_ok && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) ? ((icg & 3) * HWi + hi * p.Wi + wi) * 32 + 16 * ih : FX_OOB;
+                const int x_so = f_img * CG * HWi * 32;
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) rai[pc] = fx_buffer_load_i32x4(rAi[pc], ai_voff, FX_SO(a_so), 0);
+                for (int pc = 0; pc < 3; ++pc) rai[pc] = fx_buffer_load_i32x4(rBi[pc], voff, FX_SO(x_so), 0);
+            } else {
+                const int a_so = (f_img * KG * OHW + f_p) * 32;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) rai[pc] = fx_buffer_load_i32x4(rAi[pc], ai_voff, FX_SO(a_so), 0);
+            }
         } else {
             const int a_so = (f_img * p.K * OHW + f_p) * 4;
 #pragma unroll
@@ -1178,13 +1195,15 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     int rd_a[2][2], rd_b[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        if constexpr (AIMG) fx_tr_frag_off(lane, wm * 64 + a * 32, rd_a[a]);
+        if constexpr (AIMG) fx_tr_frag_off(lane, (TAPS == 3 ? 0 : wm * 64) + a * 32, rd_a[a]);      // (TAPS 3: every wave's rows are dy's 64 channels)
         else rd_a[a][0] = rd_a[a][1] = fx_rc_off(wm * 64 + a * 32 + fr, fh);
-        if constexpr (BIMG) fx_tr_frag_off(lane, wn * 64 + a * 32, rd_b[a]);
+        if constexpr (BIMG) fx_tr_frag_off(lane, (TAPS == 3 ? (wave ? 64 : 0) : wn * 64) + a * 32, rd_b[a]);      // (TAPS 3: wave 1 the second tap of Bs, wave 2 the tap in As)
         else rd_b[a][0] = rd_b[a][1] = fx_rc_off(wn * 64 + a * 32 + fr, fh);
     }
-    const int live_a = fx_live_subtiles(m0 + wm * 64, p.K);
-    const int live_b = TAPS == 2 ? (2 * bx + wn < p.R * p.S ? 2 : 0) : fx_live_subtiles(n0 + wn * 64, p.C);      // (TAPS 2: a column wave = one tap's 64 channels)
+    const int live_a = TAPS == 3 ? (wave < 3 ? fx_live_subtiles(m0, p.K) : 0) : fx_live_subtiles(m0 + wm * 64, p.K);
+    const int live_b = TAPS == 3 ? (wave < 3 && 3 * bx + wave < p.R * p.S ? 2 : 0)
+                     : TAPS == 2 ? (2 * bx + wn < p.R * p.S ? 2 : 0) : fx_live_subtiles(n0 + wn * 64, p.C);      // (TAPS 2 / 3: a column wave = one tap's 64 channels)
+    const unsigned char* const Bsrc = (TAPS == 3 && wave == 2) ? As : Bs;
     if (nk > 0) { fetch(); stage(0); if (nk > 1) fetch(); }       // software pipeline as in fx_conv_kernel: stage step kt + 1 at the head of step kt, fetch step kt + 2
     __syncthreads();
     auto kloop = [&](auto nat, auto nbt) {             // see fx_conv_kernel: one straight-line copy of the loop per count of live sub-tiles
@@ -1205,7 +1224,7 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
                     if (a < NB) {
-                        if constexpr (BIMG) bf[pc][a] = fx_tr_read(Bs + (buf * 3 + pc) * FX_PIECE, rd_b[a]);
+                        if constexpr (BIMG) bf[pc][a] = fx_tr_read(Bsrc + (buf * 3 + pc) * FX_PIECE, rd_b[a]);
                         else bf[pc][a] = *reinterpret_cast<const bf8*>(Bs + (buf * 3 + pc) * FX_PIECE + rd_b[a][0]);
                     }
             };
@@ -1240,16 +1259,17 @@ __global__ __launch_bounds__(256, 3) void fx_wgrad_kernel(const FxWgradParams p)
     // C/D layout: col = lane & 31 (input channel c, contiguous in the slab), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel k)
     const int RS = TAPS == 1 ? 1 : p.R * p.S;
     float* out = p.slabs + (size_t)split * p.K * p.C * RS;
-    const int otap = TAPS == 2 ? 2 * bx + wn : tap;                         // (TAPS 2: the column wave's tap; its 64 columns are the layer's 64 input channels)
+    // (TAPS 2 / 3: the wave's tap; its 64 columns are the layer's 64 input channels.  Wave 3 of a three-tap block holds nothing)
+    const int otap = TAPS == 3 ? (wave < 3 ? 3 * bx + wave : RS) : TAPS == 2 ? 2 * bx + wn : tap;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int c = TAPS == 2 ? b * 32 + fr : n0 + wn * 64 + b * 32 + fr;
+            const int c = TAPS >= 2 ? b * 32 + fr : n0 + wn * 64 + b * 32 + fr;
             if (c >= p.C || otap >= RS) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int k = m0 + (TAPS == 3 ? 0 : wm * 64) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (k < p.K) out[((size_t)k * RS + otap) * p.C + c] = acc[a][b][r];
             }
         }
@@ -1592,7 +1612,7 @@ static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0
 // regressor's forward (2048 channels x 9 taps) fetches 5.5x fewer bytes beyond L2 and runs 2 % faster; the 512-channel 3x3 layers fetch 3.1x fewer but run 2 % slower
 // (a tap change per K step costs more than their re-reads out of the Infinity Cache): 1024 takes the first and leaves the second
 static int g_tap_inner_min = 1024;
-static int g_two_taps = 1;             // image-fed weight gradients of 64-input-channel multi-tap layers: two taps per column tile; p3d_fx_tune(9, 0): off (A/B)
+static int g_two_taps = 1;             // image-fed weight gradients of 64-input-channel multi-tap layers: two / three taps per column tile; p3d_fx_tune(9, 0): off, (9, 2): never three (A/B)
 static int g_conv_order = -1, g_wgrad_order = -1;      // -1: the built-in choice (fx_conv_order / fx_wgrad_order); 0 / 1 forced (p3d_fx_tune(7 / 8, v): A/B)
 // Which operand should the blocks an XCD runs at one time share?  An XCD's L2 holds 4 MB.  With the channel tile fastest an activation tile is fetched once and every
 // pixel tile streams the WHOLE weight image past the L2 (fine while that image stays in it); with the pixel tile fastest the ~96 resident blocks stream one
@@ -1627,7 +1647,7 @@ static int fx16_bm(int M, bool img, int pro, int epi) {
 void fx_tune(int what, int value) {
     if (what == 3) { g_pair_map = value; return; }      // 0: the two opening image passes of a downsample block as two launches (A/B, tests)
     if (what == 5) { g_class_launches = value ? 1 : 0; return; }
-    if (what == 9) { g_two_taps = value ? 1 : 0; return; }
+    if (what == 9) { g_two_taps = value < 0 ? 1 : value; return; }
     if (what == 10) { g_tap_inner_min = value; return; }
     if (what == 7) { g_conv_order = value; return; }
     if (what == 8) { g_wgrad_order = value; return; }
@@ -1974,12 +1994,15 @@ bool fx_dgrad_accumulates_from_source(const p3d_conv_desc* d) { return d->stride
 // one XCD.  The round-2 plan (576 blocks for the 3x3 grids, 512 / 768 for powers of two, 3072 for the regressor) left 15-22 % on the 9-, 16-, 36- and
 // 144-tile classes and 3 % on the regressor; other tile counts aim at one full round of three blocks per CU.
 // image-fed weight gradients of 64-input-channel multi-tap layers pack two taps into a column tile (fx_wgrad_kernel<.., TAPS 2>)
-bool fx_wgrad_two_taps(const p3d_conv_desc* d, bool images) {
-    static const bool env_on = [] { const char* e = getenv("P3D_TWO_TAPS"); return !(e && atoi(e) == 0); }();      // P3D_TWO_TAPS=0: A/B from the environment
-    return g_two_taps && env_on && images && d->C == 64 && d->R * d->S > 1 && (d->Wo & 15) == 0;
+// (returns the taps per column tile: 0 = the ordinary one-tap tiles, 2, or 3 when the output channels fit half an A image too)
+int fx_wgrad_two_taps(const p3d_conv_desc* d, bool images) {
+    static const int env = [] { const char* e = getenv("P3D_TWO_TAPS"); return e ? atoi(e) : 1; }();      // P3D_TWO_TAPS=0: one tap, =2: never three (A/B from the environment)
+    if (!g_two_taps || !env || !images || d->C != 64 || d->R * d->S <= 1 || (d->Wo & 15)) return 0;
+    return (g_two_taps == 1 && env == 1 && d->K <= 64) ? 3 : 2;
 }
 int fx_wgrad_splits(const p3d_conv_desc* d, bool images) {
-    const int64_t tiles = fx_wgrad_two_taps(d, images) ? ceil_div(d->K, FX_BM) * ceil_div(d->R * d->S, 2) : ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
+    const int tt = fx_wgrad_two_taps(d, images);
+    const int64_t tiles = tt ? ceil_div(d->K, FX_BM) * ceil_div(d->R * d->S, tt) : ceil_div(d->K, FX_BM) * ceil_div(d->C, FX_BN) * d->R * d->S;
     const int64_t total = (int64_t)d->N * (d->Ho * d->Wo / FX_BK);
     int64_t target;
     if (g_wgrad_target > 0) target = g_wgrad_target;          // (tuning aid: p3d_fx_tune, tools/split_sweep.py)
@@ -2025,8 +2048,10 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     }
     if ((aimg && (d->K & 15)) || (bimg && (d->C & 15)) || (bimg && !aimg)) { set_error("fx_conv_wgrad: image operands need channel counts in steps of 16 (and a dy image beside an x image)"); return P3D_EINVAL; }
     const dim3 grid((unsigned)ceil_div(d->C, FX_BN), (unsigned)ceil_div(d->K, FX_BM), (unsigned)(splits * d->R * d->S));
-    if (fx_wgrad_two_taps(d, aimg && bimg && !masked)) {
-        hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 2>), dim3((unsigned)ceil_div(d->R * d->S, 2), (unsigned)ceil_div(d->K, FX_BM), (unsigned)splits), dim3(256), 0, st, p);
+    if (const int tt = fx_wgrad_two_taps(d, aimg && bimg && !masked)) {
+        const dim3 tg((unsigned)ceil_div(d->R * d->S, tt), (unsigned)ceil_div(d->K, FX_BM), (unsigned)splits);
+        if (tt == 3) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 3>), tg, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 2>), tg, dim3(256), 0, st, p);
         return check_launch("fx_conv_wgrad");
     }
     if (masked && aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, true>), grid, dim3(256), 0, st, p);

@@ -644,7 +644,9 @@ def test_activation_image_is_an_exact_split(pkg):
 
 #             N   C    H   K  ks st dil
 IMG_CASES = [(2, 64, 16, 64, 3, 1, 1), (2, 128, 16, 272, 3, 1, 1), (3, 256, 16, 128, 1, 1, 1), (2, 128, 32, 128, 3, 2, 1), (2, 128, 16, 128, 3, 1, 2),
-             (2, 64, 32, 256, 1, 1, 1), (2, 256, 32, 64, 1, 1, 1), (2, 256, 32, 512, 1, 2, 1), (5, 128, 8, 160, 3, 1, 1), (16, 512, 16, 512, 3, 1, 1)]
+             (2, 64, 32, 256, 1, 1, 1), (2, 256, 32, 64, 1, 1, 1), (2, 256, 32, 512, 1, 2, 1), (5, 128, 8, 160, 3, 1, 1), (16, 512, 16, 512, 3, 1, 1),
+             # 64 input channels, a multi-tap filter: the two- / three-tap column tiles of the weight gradient (fx_wgrad_kernel<.., TAPS 2 / 3>)
+             (2, 64, 16, 128, 3, 1, 1), (3, 64, 32, 48, 3, 1, 1), (2, 64, 32, 64, 3, 2, 1), (2, 64, 16, 64, 5, 1, 1), (2, 64, 16, 32, 3, 1, 2)]
 
 
 @pytest.mark.parametrize('case', IMG_CASES, ids=['n%d_c%d_h%d_k%d_%dx%d_s%d_d%d' % (c[0], c[1], c[2], c[3], c[4], c[4], c[5], c[6]) for c in IMG_CASES])
