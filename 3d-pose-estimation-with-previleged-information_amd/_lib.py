@@ -73,6 +73,7 @@ SIGNATURES = {
     'p3d_stem_wgrad_masked': (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_profile_enable': (_i32, [_i32]),
     'p3d_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    'p3d_profile_collect2': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'p3d_mask_count_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr]),
     'p3d_nonzero_mask': (_i32, [_ptr, _ptr, _i64, _ptr]),
     'p3d_bn_workspace_bytes': (_sz, [_i32, _i32, _i32]),
@@ -116,6 +117,10 @@ SIGNATURES = {
     'p3d_hconv2d_fwd': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'p3d_hscale_pixels': (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     'p3d_hconv2d_dgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_hblock_fuse_sums': (_i32, [_i32]),
+    'p3d_hconv2d_sum_rows': (_i32, [_desc, _i32]),
+    'p3d_hconv2d_fwd_stats': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'p3d_hconv2d_dgrad_sums': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'p3d_hconv2d_wgrad_workspace_bytes': (_sz, [_desc]),
     'p3d_hconv2d_wgrad': (_i32, [_desc, _ptr, _ptr, _ptr, _ptr, _i32, _f32, _ptr, _sz, _ptr]),
     'p3d_hconv2d_bgrad': (_i32, [_ptr, _i32, _i32, _ptr, _f32, _i32, _ptr]),
@@ -128,6 +133,8 @@ SIGNATURES = {
     'p3d_hbn_eval_fwd': (_i32, [_ptr] * 7 + [_i32, _i32, _f32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_train_bwd': (_i32, [_ptr] * 8 + [_i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_frozen_bwd': (_i32, [_ptr] * 8 + [_i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
+    'p3d_hbn_train_fwd_partial': (_i32, [_ptr] * 8 + [_i32, _i32, _f32, _f32, _i32, _ptr, _i32, _ptr]),
+    'p3d_hbn_train_bwd_partial': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
     'p3d_hbn_eval_coef': (_i32, [_ptr] * 5 + [_i32, _f32, _ptr]),
     'p3d_hconcat': (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _ptr]),
     'p3d_hrelu': (_i32, [_ptr, _ptr, _ptr, _i64, _ptr]),

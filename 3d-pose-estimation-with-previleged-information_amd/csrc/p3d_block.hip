@@ -333,20 +333,26 @@ static hipEvent_t mark_position(hipStream_t signaller) {
 }
 
 // ---- conv launch profile (bench.py's roofline brackets): HIP events around every conv call of the executor, on the stream it runs on ----------
-struct ProfRec { int kind; double flops; hipEvent_t a, b; };
+struct ProfRec { int kind; double flops; hipEvent_t a, b, m; };
+static thread_local ProfScope* g_prof_cur = nullptr;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
 ProfScope::ProfScope(int kind_, const p3d_conv_desc* d, hipStream_t st_) : st(st_), kind(kind_) {
     flops = 2.0 * d->N * d->K * d->Ho * d->Wo * (double)d->C * d->R * d->S;
-    if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
+    if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { (void)hipEventRecord(a, st); g_prof_cur = this; }
+}
+void prof_kernel_done(hipStream_t st) {
+    ProfScope* ps = g_prof_cur;
+    if (ps && ps->a && !ps->m && ps->st == st && hipEventCreate(&ps->m) == hipSuccess) (void)hipEventRecord(ps->m, st);
 }
 ProfScope::~ProfScope() {
     if (a && b) {
         (void)hipEventRecord(b, st);
         std::lock_guard<std::mutex> lock(g_prof_mu);
-        g_prof.push_back({kind, flops, a, b});
+        g_prof.push_back({kind, flops, a, b, m});
     }
+    if (g_prof_cur == this) g_prof_cur = nullptr;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -700,13 +706,31 @@ int32_t p3d_block_bwd(const p3d_block_desc* b, const p3d_block_io* io, void* wor
 
 // ---- the same block on the fp16 NHWC kernels (-half_acc): host-side fusion of the per-layer entry points into one call per block and direction -------------------
 static bool hblock_slot(const p3d_block_desc* b, int i) { return i < b->nconv || (i == 3 && b->has_downsample); }
+// BatchNorm sums in the conv epilogues (p3d_hconv2d_fwd_stats / p3d_hconv2d_dgrad_sums); P3D_HALF_FUSED=0: the stand-alone statistics / reduce passes (A/B, and the
+// configuration in which the executor is bit-identical to the per-layer path)
+static int g_hblock_fused = [] { const char* e = getenv("P3D_HALF_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+static bool hblock_fused() { return g_hblock_fused != 0; }
+// main workspace of a layer: [the partial table: max(512 stand-alone blocks, pixel tiles of either pass) rows][K float4 of constants]
+static size_t hblock_rows(const p3d_conv_desc* d) {
+    const int r0 = p3d_hconv2d_sum_rows(d, 0), r1 = p3d_hconv2d_sum_rows(d, 1);
+    const int r = r0 > r1 ? r0 : r1;
+    return (size_t)(r > 512 ? r : 512);
+}
+
+/* on = 1 / 0: BatchNorm sums from the conv epilogues / from stand-alone passes (the latter is bit-identical to the per-layer path); on < 0: query.  Returns the previous setting. */
+int32_t p3d_hblock_fuse_sums(int32_t on) {
+    const int32_t before = g_hblock_fused;
+    if (on >= 0) g_hblock_fused = on ? 1 : 0;
+    return before;
+}
 
 int32_t p3d_hblock_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes) {
     P3D_REQUIRE(b && (b->nconv == 2 || b->nconv == 3), "hblock: nconv must be 2 or 3");
     size_t mw = 0, sw = 0;
     for (int i = 0; i < 4; ++i) {
         if (!hblock_slot(b, i)) continue;
-        const size_t a = p3d_hbn_workspace_bytes(b->conv[i].K), w = p3d_hconv2d_wgrad_workspace_bytes(&b->conv[i]);
+        const int kc = b->conv[i].K > b->conv[i].C ? b->conv[i].K : b->conv[i].C;
+        const size_t a = hblock_rows(&b->conv[i]) * kc * 2 * sizeof(float) + (size_t)kc * 4 * sizeof(float), w = p3d_hconv2d_wgrad_workspace_bytes(&b->conv[i]);
         if (a > mw) mw = a;
         if (w > sw) sw = w;
     }
@@ -721,13 +745,23 @@ int32_t p3d_hblock_fwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* w
     for (int i = 0; i < 4; ++i)
         if (hblock_slot(b, i)) P3D_REQUIRE(io->w_krsc[i] && io->c[i] && io->coef[i] && io->gamma[i] && io->beta[i] && (i == last || io->a[i]), "hblock_fwd: null tensor of conv %d", i);
     hipStream_t st = (hipStream_t)stream;
+    const bool fused = hblock_fused();
+    {
+        size_t need = 0;
+        if (int32_t e = p3d_hblock_workspace_bytes(b, &need, nullptr)) return e;
+        if (!workspace || workspace_bytes < need) { set_error("hblock_fwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    }
     auto conv = [&](int i, const void* in) -> int32_t {
         const p3d_conv_desc* d = &b->conv[i];
         ProfScope ps(0, d, st);
+        if (fused) return p3d_hconv2d_fwd_stats(d, in, io->w_krsc[i], io->c[i], (float*)workspace, stream);       // (the table is consumed by bn(i) before the next conv runs)
         return p3d_hconv2d_fwd(d, in, io->w_krsc[i], nullptr, nullptr, nullptr, io->c[i], stream);
     };
     auto bn = [&](int i, const void* res, void* y, int relu) -> int32_t {
         const p3d_conv_desc* d = &b->conv[i];
+        if (fused)
+            return p3d_hbn_train_fwd_partial(io->c[i], res, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], y, io->coef[i], d->N * d->Ho * d->Wo, d->K,
+                                             b->momentum[i], b->eps[i], relu, (const float*)workspace, p3d_hconv2d_sum_rows(d, 0), stream);
         return p3d_hbn_train_fwd(io->c[i], res, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], y, io->coef[i], d->N * d->Ho * d->Wo, d->K,
                                  b->momentum[i], b->eps[i], relu, workspace, workspace_bytes, stream);
     };
@@ -767,11 +801,30 @@ int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* w
         ProfScope ps(2, &d, ss);
         return p3d_hconv2d_wgrad(&d, io->dc[i], xin, nullptr, io->dw[i], io->c_real[i], 1.0f, two ? side_workspace : side_workspace, side_bytes, (void*)ss);
     };
+    {
+        size_t need = 0;
+        if (int32_t e = p3d_hblock_workspace_bytes(b, &need, nullptr)) return e;
+        if (!workspace || workspace_bytes < need) { set_error("hblock_bwd: workspace %zu B < required %zu B", workspace_bytes, need); return P3D_EWORKSPACE; }
+    }
     auto dgrad = [&](int i, void* dx, int accumulate) -> int32_t {
         p3d_conv_desc d = b->conv[i];
         d.accumulate = accumulate;
         ProfScope ps(1, &d, st);
         return p3d_hconv2d_dgrad(&d, io->dc[i], io->w_crsk[i], nullptr, dx, stream);
+    };
+    // the data gradient of conv i (i > 0, stride 1) also takes the sums of the BatchNorm + ReLU in front of it; bn_bwd_fused(i - 1) then only finalizes and applies
+    auto fusable = [&](int i) { return hblock_fused() && i > 0 && b->conv[i].stride == 1; };
+    auto dgrad_sums = [&](int i) -> int32_t {
+        p3d_conv_desc d = b->conv[i];
+        d.accumulate = 0;
+        ProfScope ps(1, &d, st);
+        return p3d_hconv2d_dgrad_sums(&d, io->dc[i], io->w_crsk[i], io->da[i - 1], io->c[i - 1], io->coef[i - 1], (float*)workspace, stream);
+    };
+    auto bn_bwd_fused = [&](int j, int rows) -> int32_t {
+        const p3d_conv_desc* d = &b->conv[j];
+        float* coef2 = (float*)((char*)workspace + hblock_rows(&b->conv[j + 1]) * d->K * 2 * sizeof(float));
+        return p3d_hbn_train_bwd_partial(io->da[j], io->c[j], io->coef[j], io->dc[j], io->dgamma[j], io->dbeta[j], d->N * d->Ho * d->Wo, d->K, acc, (const float*)workspace, rows,
+                                         coef2, stream);
     };
     // closing BatchNorm: d c_last, and the gradient that enters the shortcut (dout masked by the block's output)
     if (int32_t e = bn_bwd(last, io->dout, io->out, io->da[3], 1)) return e;
@@ -787,9 +840,15 @@ int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* w
     }
     for (int i = last; i >= 0; --i) {
         if (i > 0) {
-            if (int32_t e = dgrad(i, io->da[i - 1], 0)) return e;
-            if (int32_t e = wgrad(i, io->a[i - 1], ready)) return e;
-            if (int32_t e = bn_bwd(i - 1, io->da[i - 1], nullptr, nullptr, 1)) return e;
+            if (fusable(i)) {
+                if (int32_t e = dgrad_sums(i)) return e;
+                if (int32_t e = wgrad(i, io->a[i - 1], ready)) return e;
+                if (int32_t e = bn_bwd_fused(i - 1, p3d_hconv2d_sum_rows(&b->conv[i], 1))) return e;
+            } else {
+                if (int32_t e = dgrad(i, io->da[i - 1], 0)) return e;
+                if (int32_t e = wgrad(i, io->a[i - 1], ready)) return e;
+                if (int32_t e = bn_bwd(i - 1, io->da[i - 1], nullptr, nullptr, 1)) return e;
+            }
             ready = two ? mark_position(st) : nullptr;
         } else {
             // the first conv's data gradient joins what the shortcut already delivered: the branch's data gradient (dx), or with an identity shortcut da[3] itself
@@ -949,7 +1008,17 @@ int32_t p3d_profile_enable(int32_t on) {
 
 // Synchronises, sums the bracketed time per kind (0 forward, 1 data gradient, 2 weight gradient) and clears the records.
 int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind) {
-    for (int k = 0; k < 3; ++k) { if (ms_by_kind) ms_by_kind[k] = 0; if (flops_by_kind) flops_by_kind[k] = 0; if (launches_by_kind) launches_by_kind[k] = 0; }
+    return p3d_profile_collect2(ms_by_kind, nullptr, flops_by_kind, launches_by_kind);
+}
+
+// The same with, per kind, the time of the conv kernels alone (the bracket up to the point where a split-K / slab sum was queued behind the kernel).
+int32_t p3d_profile_collect2(double* ms_by_kind, double* kernel_ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind) {
+    for (int k = 0; k < 3; ++k) {
+        if (ms_by_kind) ms_by_kind[k] = 0;
+        if (kernel_ms_by_kind) kernel_ms_by_kind[k] = 0;
+        if (flops_by_kind) flops_by_kind[k] = 0;
+        if (launches_by_kind) launches_by_kind[k] = 0;
+    }
     std::vector<ProfRec> recs;
     { std::lock_guard<std::mutex> lock(g_prof_mu); recs.swap(g_prof); }
     for (ProfRec& r : recs) {
@@ -958,8 +1027,12 @@ int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* 
             if (ms_by_kind) ms_by_kind[r.kind] += ms;
             if (flops_by_kind) flops_by_kind[r.kind] += r.flops;
             if (launches_by_kind) launches_by_kind[r.kind] += 1;
+            float kms = ms;
+            if (r.m && hipEventElapsedTime(&kms, r.a, r.m) != hipSuccess) kms = ms;
+            if (kernel_ms_by_kind) kernel_ms_by_kind[r.kind] += kms;
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        if (r.m) (void)hipEventDestroy(r.m);
     }
     return P3D_OK;
 }

@@ -83,13 +83,15 @@ constexpr int FX_TAB = 8;   // floats per channel of a table
 
 // HIP-event bracket around one conv launch (p3d_block.hip keeps the records; no-op unless p3d_profile_enable(1))
 struct ProfScope {
-    hipEvent_t a = nullptr, b = nullptr;
+    hipEvent_t a = nullptr, b = nullptr, m = nullptr;        // m: where the conv kernel itself ended, when slab / split-K sums follow inside the bracket
     hipStream_t st;
     int kind;
     double flops;
     ProfScope(int kind, const p3d_conv_desc* d, hipStream_t st);
     ~ProfScope();
 };
+// called by the launchers between a conv kernel and the pass that sums its slabs: the open bracket of this host thread notes the position (once)
+void prof_kernel_done(hipStream_t st);
 
 bool fx_enabled();
 void fx_tune(int what, int value);

@@ -1800,6 +1800,7 @@ static void fx_launch_conv(const FxConvParams& p_in, bool img, int pro, int epi,
 static void fx_launch_reduce(int epi, dim3 grid, hipStream_t st, const float* slabs, float* y, const float* bias, int nsplit, size_t slab_stride, int N, int M,
                              int OHW, int accumulate, const float* ep_c, const float* ep_tab, float* partial, const float* emask) {
     if (epi == 5 || epi == 6 || epi == 7 || epi == 4) epi = epi == 5 ? 1 : epi == 6 ? 2 : 0;      // the masked epilogues: the base sums over the result times emask
+    prof_kernel_done(st);
     if (epi == 1) hipLaunchKernelGGL(fx_reduce_kernel<1>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
     else if (epi == 2) hipLaunchKernelGGL(fx_reduce_kernel<2>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
     else hipLaunchKernelGGL(fx_reduce_kernel<0>, grid, dim3(256), 0, st, slabs, y, bias, nsplit, slab_stride, N, M, OHW, accumulate, ep_c, ep_tab, partial, emask);
@@ -2052,6 +2053,7 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
         const dim3 tg((unsigned)ceil_div(d->R * d->S, tt), (unsigned)ceil_div(d->K, FX_BM), (unsigned)splits);
         if (tt == 3) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 3>), tg, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false, 2>), tg, dim3(256), 0, st, p);
+        prof_kernel_done(st);
         return check_launch("fx_conv_wgrad");
     }
     if (masked && aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, true>), grid, dim3(256), 0, st, p);
@@ -2059,6 +2061,7 @@ int32_t fx_conv_wgrad_slabs(const p3d_conv_desc* d, const float* dy, const float
     else if (aimg && bimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, true, false>), grid, dim3(256), 0, st, p);
     else if (aimg) hipLaunchKernelGGL((fx_wgrad_kernel<true, false, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fx_wgrad_kernel<false, false, false>), grid, dim3(256), 0, st, p);
+    prof_kernel_done(st);
     return check_launch("fx_conv_wgrad");
 }
 
@@ -2217,6 +2220,7 @@ int32_t fx_stem_wgrad(const float* dy, const float* mult, const void* x_img, flo
         hipLaunchKernelGGL((fx_wgrad_kernel<false, true, true, 1>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
     } else
         hipLaunchKernelGGL((fx_wgrad_kernel<false, true, false, 1>), dim3(2, (unsigned)ceil_div(K, FX_BM), (unsigned)p.nsplit), dim3(256), 0, st, p);
+    prof_kernel_done(st);
     hipLaunchKernelGGL(fx_stem_dw_kernel, dim3((unsigned)K, 4), dim3(1024), 0, st, (const float*)workspace, p.nsplit, dw, K, Cin, accumulate);
     return check_launch("fx_stem_wgrad");
 }

@@ -358,6 +358,22 @@ int32_t p3d_hbn_train_fwd(const void* x, const void* res, const float* gamma, co
     return check_launch("hbn_train_fwd");
 }
 
+/* The same with the statistics already summed per (pixel tile, channel) by the convolution that produced x (p3d_hconv2d_fwd_stats): finalize + apply, no pass over x
+ * for the sums.  partial [rows][C / 8][16]. */
+int32_t p3d_hbn_train_fwd_partial(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows, void* stream) {
+    P3D_REQUIRE(x && gamma && beta && y && coef && partial && rows > 0, "hbn_train_fwd_partial: null tensor");
+    P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_fwd_partial: bad shape P=%d C=%d (C/8 must divide or be a multiple of 256)", P, C);
+    P3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hbn_train_fwd_partial: running stats must come as a pair");
+    const HbnGeom g = hbn_geom(P, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, partial, rows, gamma, beta,
+                       running_mean, running_var, (float4*)coef, P, C, momentum, eps);
+    hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
+                       (_Float16*)y, P, C, relu);
+    return check_launch("hbn_train_fwd_partial");
+}
+
 int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, void* y, int32_t P, int32_t C, float eps, int32_t relu, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -395,6 +411,20 @@ static int32_t hbn_bwd_impl(const void* dy, const void* x, const void* y, const 
 int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     return hbn_bwd_impl(dy, x, y, coef, dx, dres, dgamma, dbeta, P, C, relu, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+/* The backward pass of a BatchNorm + ReLU layer without a residual whose sums the data gradient that produced dy already took (p3d_hconv2d_dgrad_sums): finalize + apply.
+ * partial [rows][C / 8][16]; coef2: C float4 of scratch. */
+int32_t p3d_hbn_train_bwd_partial(const void* dy, const void* x, const float* coef, void* dx, float* dgamma, float* dbeta, int32_t P, int32_t C, int32_t accumulate,
+                                  const float* partial, int32_t rows, float* coef2, void* stream) {
+    P3D_REQUIRE(dy && x && coef && dx && dgamma && dbeta && partial && rows > 0 && coef2, "hbn_train_bwd_partial: null tensor");
+    P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_bwd_partial: bad shape P=%d C=%d", P, C);
+    const HbnGeom g = hbn_geom(P, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, partial, rows, dgamma, dbeta, (float4*)coef2, P, C, accumulate, 0);
+    hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)nullptr,
+                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)nullptr, P, C, 1);
+    return check_launch("hbn_train_bwd_partial");
 }
 
 int32_t p3d_hbn_frozen_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,

@@ -55,6 +55,9 @@ struct HGatherParams {
     int accumulate;           // D += result (a dgrad joining the gradient of a second consumer of its input)
     const float* bmask;       // partial conv: {0,1} mask over the pixels of B ([N][Hb][Wb]); a masked pixel contributes 0.  or null
     const float* dscale;      // partial conv: per-pixel factor of the result ([N][Hd][Wd]): mult (forward) / mask_in (dgrad).  or null
+    float* partial;           // EPI 2 / 3: per-(pixel tile, channel) sums [tiles_n][M / 8][16] (0..7: first sum of the group's 8 channels, 8..15: second), the layout of p3d_hbn.hip
+    const _Float16* ep_x;     // EPI 3: the raw conv output behind the BatchNorm this gradient enters, NHWC like D
+    const float4* ep_coef;    // EPI 3: that BatchNorm's {sc, sh, mean, invstd} per channel
     int Hc[HMS], Wc[HMS];
     int r0[HMS], rstep[HMS], nr[HMS], hadd[HMS], hstep[HMS];
     int s0[HMS], sstep[HMS], ns[HMS], wadd[HMS], wstep[HMS];
@@ -65,7 +68,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BK>
+// EPI 0: the accumulator goes to NHWC as it lies (8-B stores; bias, per-pixel factor, accumulate).  EPI 1: through LDS, so that a pixel's 128 channels leave as 16-B
+// stores of one 256-B run.  EPI 2: + the statistics of the BatchNorm behind this convolution (sum y, sum y^2 of the ROUNDED fp16 values, i.e. what a pass over y would
+// read).  EPI 3: + the sums of the BatchNorm in front of a data gradient (sum g, sum g * xhat with g = the result masked by that layer's ReLU, recomputed from its raw
+// output and constants as hbn_bwd_reduce_kernel does).  EPI 2 / 3 need one pixel class (every block owns a full row of the partial table).
+template <int BK, int EPI>
 __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
     constexpr int BM = 128, BN = 128;
     constexpr int CH = BK / 8;                 // 16-B chunks per tile row
@@ -183,6 +190,76 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
 
     // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (channel):
     //      registers 4g .. 4g+3 are four consecutive channels of one pixel -> one 8-B NHWC store ----
+    if constexpr (EPI != 0) {
+        constexpr int EPITCH = 272;                            // bytes per staged pixel row (128 channels + 16: the b128 reads of a 16-lane phase spread over all banks)
+        static_assert(128 * EPITCH <= 2 * (BM + BN) * ROWB, "the staging tile lives in the operand buffers");
+        unsigned char* T = smem;                               // (the K loop ended on a barrier)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[a][b][4 * g + e];
+                    *reinterpret_cast<h4*>(T + (wn * 64 + b * 32 + fr) * EPITCH + (wm * 64 + a * 32 + 8 * g + 4 * fh) * 2) = o;
+                }
+        __syncthreads();
+        const int cc = t & 15, pr = t >> 4;                    // this thread: 16-B chunk cc (8 channels) of pixel rows pr, pr + 16, ...
+        const int ch = m0 + cc * 8;
+        const bool ch_ok = ch < p.M;
+        float s[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        float sc[8], sh[8], mu[8], is[8];
+        if constexpr (EPI == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 q = ch_ok ? p.ep_coef[ch + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sc[e] = q.x; sh[e] = q.y; mu[e] = q.z; is[e] = q.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pl = pr + 16 * i, n = n0 + pl;
+            if (n >= ncols || !ch_ok) continue;
+            const h8 v = *reinterpret_cast<const h8*>(T + pl * EPITCH + cc * 16);
+            const int img = n / (Hc * Wc), rem = n - img * (Hc * Wc);
+            const int ii = rem / Wc, jj = rem - ii * Wc;
+            const size_t off = ((size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw) * p.M + ch;
+            *reinterpret_cast<h8*>(p.D + off) = v;
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; s[8 + e] = fmaf(f, f, s[8 + e]); }
+            }
+            if constexpr (EPI == 3) {
+                const h8 xv = *reinterpret_cast<const h8*>(p.ep_x + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float gq = (float)v[e];
+                    const float xf = (float)xv[e];
+                    if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f;
+                    s[e] += gq;
+                    s[8 + e] = fmaf(gq, (xf - mu[e]) * is[e], s[8 + e]);
+                }
+            }
+        }
+        if constexpr (EPI >= 2) {
+            __syncthreads();                                   // every read of the staging tile is done
+            float* R = reinterpret_cast<float*>(smem);         // [16 values][16 pixel rows][16 chunks]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) R[(e * 16 + pr) * 16 + cc] = s[e];
+            __syncthreads();
+            const int e2 = t >> 4, c2 = t & 15;
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += R[(e2 * 16 + q) * 16 + c2];
+            const int G = p.M >> 3, g = (m0 >> 3) + c2;
+            if (g < G) p.partial[((size_t)tile_n * G + g) * 16 + e2] = tot;
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int n = n0 + wn * 64 + b * 32 + fr;
@@ -520,10 +597,15 @@ static int32_t hvalidate(const p3d_conv_desc* d, const char* what) {
     return P3D_OK;
 }
 
-static void launch_gather(const HGatherParams& p, int ncls, int max_cols, hipStream_t st) {
+// epi: 0 plain, 2 + BatchNorm statistics, 3 + BatchNorm-backward sums (p.partial etc. set); a plain launch without bias / factor / accumulate stores through LDS (EPI 1)
+static bool g_hstage = [] { const char* e = getenv("P3D_HALF_STAGED_STORE"); return !(e && atoi(e) == 0); }();      // P3D_HALF_STAGED_STORE=0: A/B
+static void launch_gather(const HGatherParams& p, int ncls, int max_cols, hipStream_t st, int epi = 0) {
     const int tiles_n = (int)ceil_div(max_cols, 128);
     dim3 grid((unsigned)(p.tiles_m * tiles_n), (unsigned)ncls);
-    hipLaunchKernelGGL(hconv_gather_kernel<32>, grid, dim3(256), 0, st, p);
+    if (epi == 2) hipLaunchKernelGGL((hconv_gather_kernel<32, 2>), grid, dim3(256), 0, st, p);
+    else if (epi == 3) hipLaunchKernelGGL((hconv_gather_kernel<32, 3>), grid, dim3(256), 0, st, p);
+    else if (g_hstage && !p.bias && !p.dscale && !p.accumulate) hipLaunchKernelGGL((hconv_gather_kernel<32, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((hconv_gather_kernel<32, 0>), grid, dim3(256), 0, st, p);
 }
 
 }  // namespace p3d
@@ -532,11 +614,12 @@ using namespace p3d;
 
 extern "C" {
 
-int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krsc, const float* bias, const float* mask_in, const float* mult, void* y,
-                        void* stream) {
+static int32_t hconv_fwd_impl(const p3d_conv_desc* d, const void* x, const void* w_krsc, const float* bias, const float* mask_in, const float* mult, void* y,
+                              float* partial, void* stream) {
     if (int32_t e = hvalidate(d, "hconv2d_fwd")) return e;
     P3D_REQUIRE(x && w_krsc && y, "hconv2d_fwd: null tensor");
     HGatherParams p = {};
+    p.partial = partial;
     p.A = (const _Float16*)w_krsc; p.B = (const _Float16*)x; p.D = (_Float16*)y; p.bias = bias;
     p.bmask = mask_in; p.dscale = mult;
     p.a_bytes = (size_t)d->K * d->R * d->S * d->C * 2; p.b_bytes = (size_t)d->N * d->H * d->W * d->C * 2;
@@ -547,15 +630,35 @@ int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krs
     p.Hc[0] = d->Ho; p.Wc[0] = d->Wo;
     p.r0[0] = 0; p.rstep[0] = 1; p.nr[0] = d->R; p.hadd[0] = -d->pad; p.hstep[0] = d->dil;
     p.s0[0] = 0; p.sstep[0] = 1; p.ns[0] = d->S; p.wadd[0] = -d->pad; p.wstep[0] = d->dil;
-    launch_gather(p, 1, d->N * d->Ho * d->Wo, (hipStream_t)stream);
+    launch_gather(p, 1, d->N * d->Ho * d->Wo, (hipStream_t)stream, partial ? 2 : 0);
     return check_launch("hconv2d_fwd");
 }
 
+int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x, const void* w_krsc, const float* bias, const float* mask_in, const float* mult, void* y,
+                        void* stream) {
+    return hconv_fwd_impl(d, x, w_krsc, bias, mask_in, mult, y, nullptr, stream);
+}
+
+/* rows of the per-(pixel tile, channel) sum table a convolution's epilogue leaves: forward (pass 0) over the output pixels, data gradient (pass 1, stride 1) over the input pixels */
+int32_t p3d_hconv2d_sum_rows(const p3d_conv_desc* d, int32_t pass) {
+    if (!d) return 0;
+    return (int32_t)ceil_div((int64_t)d->N * (pass == 0 ? d->Ho * d->Wo : d->H * d->W), 128);
+}
+
+/* y = conv(x) and, from the same launch, the batch statistics of y for the BatchNorm behind it: partial [rows][K / 8][16] floats (p3d_hconv2d_sum_rows(d, 0) rows), what
+ * p3d_hbn_train_fwd_partial finalizes.  The sums are taken of the rounded fp16 results, i.e. of what a statistics pass over y would read. */
+int32_t p3d_hconv2d_fwd_stats(const p3d_conv_desc* d, const void* x, const void* w_krsc, void* y, float* partial, void* stream) {
+    P3D_REQUIRE(partial, "hconv2d_fwd_stats: null table");
+    return hconv_fwd_impl(d, x, w_krsc, nullptr, nullptr, nullptr, y, partial, stream);
+}
+
 /* dx[n][hi][wi][c] = sum_{k,r,s} dy[n][ho][wo][k] * w[k][r][s][c]; w_crsk is the [C][R][S][K] weight image */
-int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_crsk, const float* mask_in, void* dx, void* stream) {
+static int32_t hconv_dgrad_impl(const p3d_conv_desc* d, const void* dy, const void* w_crsk, const float* mask_in, void* dx, const void* c_prev, const float* coef_prev,
+                                float* partial, void* stream) {
     if (int32_t e = hvalidate(d, "hconv2d_dgrad")) return e;
     P3D_REQUIRE(dy && w_crsk && dx, "hconv2d_dgrad: null tensor");
     HGatherParams p = {};
+    p.partial = partial; p.ep_x = (const _Float16*)c_prev; p.ep_coef = (const float4*)coef_prev;
     p.A = (const _Float16*)w_crsk; p.B = (const _Float16*)dy; p.D = (_Float16*)dx; p.bias = nullptr;
     p.bmask = nullptr; p.dscale = mask_in;
     p.a_bytes = (size_t)d->K * d->R * d->S * d->C * 2; p.b_bytes = (size_t)d->N * d->Ho * d->Wo * d->K * 2;
@@ -579,8 +682,20 @@ int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_
             const int cols = d->N * p.Hc[a] * p.Wc[b];
             if (cols > max_cols) max_cols = cols;
         }
-    launch_gather(p, d->stride * d->stride, max_cols, (hipStream_t)stream);
+    launch_gather(p, d->stride * d->stride, max_cols, (hipStream_t)stream, partial ? 3 : 0);
     return check_launch("hconv2d_dgrad");
+}
+
+int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy, const void* w_crsk, const float* mask_in, void* dx, void* stream) {
+    return hconv_dgrad_impl(d, dy, w_crsk, mask_in, dx, nullptr, nullptr, nullptr, stream);
+}
+
+/* dx = dgrad(dy) (stride 1, no accumulate) and, from the same launch, the backward sums of the BatchNorm + ReLU layer whose output x is: c_prev = that layer's raw conv
+ * output (NHWC like dx), coef_prev its forward constants; partial [rows][C / 8][16] (p3d_hconv2d_sum_rows(d, 1) rows), what p3d_hbn_train_bwd_partial finalizes. */
+int32_t p3d_hconv2d_dgrad_sums(const p3d_conv_desc* d, const void* dy, const void* w_crsk, void* dx, const void* c_prev, const float* coef_prev, float* partial, void* stream) {
+    P3D_REQUIRE(d && d->stride == 1 && !d->accumulate, "hconv2d_dgrad_sums: stride-1, non-accumulating data gradients only");
+    P3D_REQUIRE(c_prev && coef_prev && partial, "hconv2d_dgrad_sums: null tensor");
+    return hconv_dgrad_impl(d, dy, w_crsk, nullptr, dx, c_prev, coef_prev, partial, stream);
 }
 
 static void hwgrad_plan(const p3d_conv_desc* d, int* splits, int* kchunk) {

@@ -946,10 +946,13 @@ def profile_convs(on):
     return bool(lib().p3d_profile_enable(int(bool(on))))
 
 
-def collect_conv_profile():
-    """Synchronises; dict(kind -> (ms, algorithmic flops, launches)) for 'fwd', 'dgrad', 'wgrad' since the last collect."""
-    ms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
-    check(lib().p3d_profile_collect(ms, fl, n), 'p3d_profile_collect')
+def collect_conv_profile(kernel_only=False):
+    """Synchronises; dict(kind -> (ms, algorithmic flops, launches)) for 'fwd', 'dgrad', 'wgrad' since the last collect.  kernel_only: (ms, flops, launches,
+    ms of the conv kernels alone -- without the split-K / slab sums queued behind them)."""
+    ms, kms, fl, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+    check(lib().p3d_profile_collect2(ms, kms, fl, n), 'p3d_profile_collect2')
+    if kernel_only:
+        return {k: (float(ms[i]), float(fl[i]), int(n[i]), float(kms[i])) for i, k in enumerate(('fwd', 'dgrad', 'wgrad'))}
     return {k: (float(ms[i]), float(fl[i]), int(n[i])) for i, k in enumerate(('fwd', 'dgrad', 'wgrad'))}
 
 

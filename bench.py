@@ -284,7 +284,9 @@ def main():
     sync()
     serial_elapsed = time.perf_counter() - t1
     ops.profile_convs(False)
-    prof = ops.collect_conv_profile()
+    prof4 = ops.collect_conv_profile(kernel_only=True)
+    kernel_only_ms = {k: v[3] for k, v in prof4.items()}          # the conv kernels alone (the bracket up to where a split-K / slab sum was queued)
+    prof = {k: v[:3] for k, v in prof4.items()}
     if opt.half:
         recs, ops.PROFILE = ops.PROFILE or [], None
         for kind, fl, start, end in recs:
@@ -367,6 +369,13 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_source, 'launches_per_step': launches,
                          'avg_launch_ms': round(conv_total_ms / max(nlaunch, 1), 4),
                          'conv_ms_per_step': {k: round(v / ksteps, 3) for k, v in conv_ms.items()},
+                         # `achieved` charges a conv launch with the split-K / slab sums queued behind its kernel (the accounting of every round so far); the conv
+                         # kernels alone -- what a rocprofv3 kernel table of the same command shows for them -- give:
+                         'kernels_alone': None if opt.half else {
+                             'ms_per_step': {k: round(v / ksteps, 3) for k, v in kernel_only_ms.items()},
+                             'avg_launch_ms': round(sum(kernel_only_ms.values()) / max(nlaunch, 1), 4),
+                             'achieved': round(gflop_crop * opt.batch * ksteps / max(sum(kernel_only_ms.values()), 1e-9), 2),
+                             'frac': round(gflop_crop * opt.batch * ksteps / max(sum(kernel_only_ms.values()), 1e-9) / peak, 4)},
                          'algorithmic_gflop_per_step': round(gflop_crop * opt.batch, 1),
                          'conv_paths': coverage,
                          'measured': 'HIP events around every conv launch (recorded inside the library on the launch stream) over %d extra steps of this run '

@@ -229,6 +229,9 @@ typedef struct p3d_hblock_io {
     int32_t c_real[4];          /* real (unpadded) input channels of conv i */
 } p3d_hblock_io;
 int32_t p3d_hblock_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
+/* BatchNorm sums of the block's layers from the conv epilogues (1, the default; P3D_HALF_FUSED=0 in the environment: 0) or from stand-alone passes (0: bit-identical to
+ * the per-layer entry points); on < 0 queries.  Returns the previous setting. */
+int32_t p3d_hblock_fuse_sums(int32_t on);
 int32_t p3d_hblock_fwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* stream);
 int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* workspace, size_t workspace_bytes, void* side_workspace, size_t side_bytes,
                        void* stream, void* side_stream);
@@ -282,6 +285,8 @@ int32_t p3d_stem_wgrad_masked(const float* dy, const float* mult, const void* x_
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */
 int32_t p3d_profile_enable(int32_t on);
 int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind);
+/* the same plus, per kind, the milliseconds of the conv kernels alone (without the split-K / slab sums queued behind them inside the bracket) */
+int32_t p3d_profile_collect2(double* ms_by_kind, double* kernel_ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d (+ fused residual add and ReLU): nn.BatchNorm2d, F.relu, out + res
@@ -450,6 +455,17 @@ int32_t p3d_hconv2d_fwd(const p3d_conv_desc* d, const void* x_nhwc, const void* 
 int32_t p3d_hscale_pixels(const void* src_nhwc, const float* scale, void* dst_nhwc, int64_t P, int32_t C, void* stream);
 /* d->accumulate != 0: dx += result (joins the gradient another consumer of the same input already wrote) */
 int32_t p3d_hconv2d_dgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, const float* mask_in, void* dx_nhwc, void* stream);
+/* A convolution whose epilogue also leaves the channel sums of the BatchNorm next to it (round 4; what the fp32 path's EPI 1 / 2 do), so that the BatchNorm costs no
+ * pass over the tensor for its sums (reference: the nn.BatchNorm2d behind / in front of every conv of a residual block, depthnet.py:42-56,98-116).
+ *   p3d_hconv2d_sum_rows(d, pass)  rows of the table: pixel tiles of the forward output (pass 0) / of the data gradient's result (pass 1, stride 1)
+ *   p3d_hconv2d_fwd_stats          y = conv(x) + partial [rows][K/8][16] fp32: per (pixel tile, 8-channel group) sum y (0..7) and sum y^2 (8..15) of the ROUNDED fp16 results
+ *   p3d_hconv2d_dgrad_sums         dx = dgrad(dy) (stride 1, no accumulate) + partial [rows][C/8][16]: sum g, sum g * xhat of the BatchNorm + ReLU layer whose output x is,
+ *                                  g = dx masked by that layer's ReLU (recomputed from its raw output c_prev and forward constants coef_prev, as p3d_hbn_train_bwd does)
+ * p3d_hbn_train_fwd_partial / p3d_hbn_train_bwd_partial finalize such a table and run the apply pass. */
+int32_t p3d_hconv2d_sum_rows(const p3d_conv_desc* d, int32_t pass);
+int32_t p3d_hconv2d_fwd_stats(const p3d_conv_desc* d, const void* x_nhwc, const void* w_krsc, void* y_nhwc, float* partial, void* stream);
+int32_t p3d_hconv2d_dgrad_sums(const p3d_conv_desc* d, const void* dy_nhwc, const void* w_crsk, void* dx_nhwc, const void* c_prev, const float* coef_prev, float* partial,
+                               void* stream);
 size_t p3d_hconv2d_wgrad_workspace_bytes(const p3d_conv_desc* d);
 /* dw (fp32 master gradient [K][c_real][R][S]) = (d->accumulate ? dw : 0) + scale * wgrad; c_real <= d->C (stem: 3 of 8) */
 int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy_nhwc, const void* x_nhwc, const float* mask_in, float* dw, int32_t c_real, float scale,
@@ -479,6 +495,11 @@ int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, con
                          void* workspace, size_t workspace_bytes, void* stream);
 int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with the sums already taken by a convolution's epilogue (partial [rows][C/8][16]); bwd: a BatchNorm + ReLU layer without residual, coef2 = C float4 of scratch */
+int32_t p3d_hbn_train_fwd_partial(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows, void* stream);
+int32_t p3d_hbn_train_bwd_partial(const void* dy, const void* x, const float* coef, void* dx, float* dgamma, float* dbeta, int32_t P, int32_t C, int32_t accumulate,
+                                  const float* partial, int32_t rows, float* coef2, void* stream);
 /* BatchNorm with FROZEN statistics inside a training step (freeze_batchnorm, depthnet.py:158-161, under -do_freeze): the forward is
  * p3d_hbn_eval_fwd; p3d_hbn_eval_coef writes the {scale, shift, mean, invstd} table of the running statistics for the backward, which is
  * dx = scale * g (no batch-statistics terms), dgamma = sum g * xhat, dbeta = sum g with g the ReLU-masked incoming gradient. */

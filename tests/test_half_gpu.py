@@ -96,6 +96,63 @@ def test_hconv_fwd_dgrad_wgrad(case, pkg):
     assert relerr(dw.cpu().numpy(), dw_ref) < 2e-5
 
 
+SUM_CASES = [('1x1', 2, 64, 16, 16, 128, 1, 1, 0, 1), ('1x1s2', 2, 48, 17, 15, 40, 1, 2, 0, 1), ('3x3', 2, 32, 20, 20, 64, 3, 1, 1, 1), ('3x3d2', 2, 16, 16, 16, 272, 3, 1, 2, 2),
+             ('ragged', 3, 24, 13, 11, 72, 3, 1, 1, 1), ('big', 4, 256, 16, 16, 256, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize('case', SUM_CASES, ids=[c[0] for c in SUM_CASES])
+def test_hconv_epilogue_sums(case, pkg):
+    """p3d_hconv2d_fwd_stats / p3d_hconv2d_dgrad_sums: the tensor is bit-identical to the plain launch's, and the per-(pixel tile, channel) table sums to the
+    BatchNorm statistics of the rounded output (forward) / to sum g, sum g * xhat of the ReLU-masked gradient (data gradient), the sums p3d_hbn_train_fwd / bwd take
+    in passes of their own (depthnet.py:42-56,98-116: the BatchNorm behind / in front of every conv of a block)."""
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    name, n, c, h, w, k, ks, st, pad, dil = case
+    rng = np.random.default_rng(abs(hash(name)) % 2 ** 31 + 1)
+    x = r16(rng.standard_normal((n, c, h, w)))
+    wt = r16(rng.standard_normal((k, c, ks, ks)) / np.sqrt(c * ks * ks))
+    d = ops._desc((n, c, h, w), (k, c, ks, ks), st, pad, dil)
+    stream, p = ops._stream(), ops._p
+    xt = nhwc16(x)
+    krsc = torch.empty(k, ks, ks, c, dtype=torch.float16, device='cuda')
+    crsk = torch.empty(c, ks, ks, k, dtype=torch.float16, device='cuda')
+    pkg._lib.check(L.p3d_weight_images_f16(p(torch.from_numpy(wt).cuda()), p(krsc), p(crsk), k, c, ks * ks, c, stream), 'images')
+    y0 = torch.empty(n, d.Ho, d.Wo, k, dtype=torch.float16, device='cuda')
+    y1 = torch.full_like(y0, float('nan'))
+    pkg._lib.check(L.p3d_hconv2d_fwd(ctypes.byref(d), p(xt), p(krsc), None, None, None, p(y0), stream), 'fwd')
+    rows = L.p3d_hconv2d_sum_rows(ctypes.byref(d), 0)
+    assert rows == -(-n * d.Ho * d.Wo // 128)
+    part = torch.full((rows, k // 8, 16), float('nan'), device='cuda')
+    pkg._lib.check(L.p3d_hconv2d_fwd_stats(ctypes.byref(d), p(xt), p(krsc), p(y1), p(part), stream), 'fwd_stats')
+    assert torch.equal(y0, y1)
+    yf = y1.double().reshape(-1, k)
+    tot = part.double().sum(0)                                   # [K/8][16]
+    s1, s2 = tot[:, :8].reshape(-1), tot[:, 8:].reshape(-1)
+    assert (s1 - yf.sum(0)).abs().max() <= 1e-5 * yf.abs().sum(0).max()
+    assert (s2 - (yf * yf).sum(0)).abs().max() <= 1e-5 * (yf * yf).sum(0).max()
+    if st != 1:
+        return
+    # data gradient: dx and the sums of the BatchNorm + ReLU layer whose output x was (its raw conv output c_prev, constants coef)
+    dy = nhwc16(r16(rng.standard_normal((n, k, d.Ho, d.Wo))))
+    c_prev = nhwc16(r16(rng.standard_normal((n, c, h, w))))
+    coef = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, c), rng.standard_normal(c) * 0.3, rng.standard_normal(c) * 0.2, rng.uniform(0.5, 2.0, c)], 1).astype(np.float32)).cuda()
+    dx0 = torch.empty(n, h, w, c, dtype=torch.float16, device='cuda')
+    dx1 = torch.full_like(dx0, float('nan'))
+    pkg._lib.check(L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dy), p(crsk), None, p(dx0), stream), 'dgrad')
+    rows = L.p3d_hconv2d_sum_rows(ctypes.byref(d), 1)
+    part = torch.full((rows, c // 8, 16), float('nan'), device='cuda')
+    pkg._lib.check(L.p3d_hconv2d_dgrad_sums(ctypes.byref(d), p(dy), p(crsk), p(dx1), p(c_prev), p(coef), p(part), stream), 'dgrad_sums')
+    assert torch.equal(dx0, dx1)
+    cf, gf = c_prev.float().reshape(-1, c), dx1.float().reshape(-1, c)
+    live = torch.addcmul(coef[:, 1], cf, coef[:, 0]) > 0            # fmaf(x, sc, sh) > 0, in fp32 like the kernel
+    g = torch.where(live, gf, torch.zeros_like(gf)).double()
+    xhat = ((cf - coef[:, 2]) * coef[:, 3]).double()
+    tot = part.double().sum(0)
+    s1, s2 = tot[:, :8].reshape(-1), tot[:, 8:].reshape(-1)
+    assert (s1 - g.sum(0)).abs().max() <= 1e-5 * g.abs().sum(0).max()
+    assert (s2 - (g * xhat).sum(0)).abs().max() <= 1e-5 * (g * xhat).abs().sum(0).max()
+
+
 @pytest.mark.parametrize('case', [(2, 16, 20, 20, 64, 3, 1, 1, 1), (2, 8, 33, 31, 72, 3, 2, 1, 1), (2, 64, 16, 16, 128, 1, 1, 0, 1), (1, 1, 65, 63, 64, 7, 2, 3, 1)])
 def test_hconv_partial(case, pkg):
     """Partial conv on the fp16 kernels (mask in the operand fetch, mult in the epilogue, pre-scaled dy in backward) against the
@@ -458,7 +515,9 @@ def test_half_frozen_distillation_step(pkg):
                          ids=lambda c: '%s_c%d_p%d_s%d_d%d%s' % (c[0], c[1], c[2], c[3], c[4], '_ds' if c[7] else ''))
 def test_half_block_executor_equals_the_per_layer_path(case, pkg):
     """p3d_hblock_fwd / p3d_hblock_bwd (one C call per block and direction) run the same fp16 kernels in the same order as the per-layer autograd path
-    (depthnet.py:40-56,96-116 under model.half()): output, input gradient, every parameter gradient and the running statistics are bit-identical."""
+    (depthnet.py:40-56,96-116 under model.half()): with the BatchNorm sums from stand-alone passes (p3d_hblock_fuse_sums(0)) output, input gradient, every parameter
+    gradient and the running statistics are bit-identical; with the sums from the conv epilogues (the default) the statistics are the same sums in another order, so the
+    results agree to fp16 rounding (a value may land on the neighbouring fp16 number)."""
     import test_block_gpu as tb
     kind, inplanes, planes, stride, dil, n, h, with_ds = case
     oh = pkg.ops_half
@@ -467,8 +526,10 @@ def test_half_block_executor_equals_the_per_layer_path(case, pkg):
     gen = torch.Generator(device='cuda').manual_seed(3)
     x0 = torch.randn(n, inplanes, h, h, device='cuda', generator=gen).relu_().half().contiguous(memory_format=torch.channels_last)
     res = []
-    for fused in (False, True):
+    L = pkg._lib.lib()
+    for fused, sums in ((False, 0), (True, 0), (True, 1)):
         oh.HALF_BLOCKS = fused
+        before = L.p3d_hblock_fuse_sums(sums)
         try:
             state = {k: v.clone() for k, v in block.state_dict().items()}
             block.zero_grad(set_to_none=True)
@@ -485,9 +546,19 @@ def test_half_block_executor_equals_the_per_layer_path(case, pkg):
             block.load_state_dict(state)
         finally:
             oh.HALF_BLOCKS = True
-    a, b = res
+            L.p3d_hblock_fuse_sums(before)
+    a, b, c = res
     assert torch.equal(a['y'], b['y']) and torch.equal(a['dx'], b['dx'])
     for k in a['grads']:
         assert torch.equal(a['grads'][k], b['grads'][k]), k
     for k in a['buffers']:
         assert torch.equal(a['buffers'][k], b['buffers'][k]), k
+    # sums from the epilogues: the same values up to fp16 rounding of intermediate tensors; in the backward pass a rounding step at a ReLU's zero crossing flips that
+    # element's mask, so gradients are compared in the mean (an indexing or scaling mistake moves every element)
+    close = lambda p, q, tol: (p.float() - q.float()).abs().max().item() <= tol * max(q.float().abs().max().item(), 1e-6)
+    close_mean = lambda p, q, tol: (p.float() - q.float()).abs().mean().item() <= tol * max(q.float().abs().mean().item(), 1e-9)
+    assert close(c['y'], a['y'], 4e-3) and close_mean(c['dx'], a['dx'], 1e-2)
+    for k in a['grads']:
+        assert close_mean(c['grads'][k], a['grads'][k], 2e-2), k
+    for k in a['buffers']:
+        assert close(c['buffers'][k], a['buffers'][k], 1e-4), k
