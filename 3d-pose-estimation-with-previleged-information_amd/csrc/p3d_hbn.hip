@@ -12,6 +12,7 @@ namespace p3d {
 
 using h8 = _Float16 __attribute__((ext_vector_type(8)));
 constexpr int HBN_MAX_BLOCKS = 512;
+constexpr int HBN_U = 4;              // pixels per loop trip of the streaming passes
 
 struct HbnGeom { int G, Gb, PL, nblk; };
 
@@ -128,20 +129,33 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(const _Float16* __restri
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float4 q = coef[g * 8 + e]; sc[e] = q.x; sh[e] = q.y; }
-    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
-        const size_t off = (size_t)p * C + g * 8;
-        const h8 v = *reinterpret_cast<const h8*>(x + off);
-        h8 r;
-        if (res) r = *reinterpret_cast<const h8*>(res + off);
-        h8 o;
+    // (HBN_U pixels per trip, every load of the trip issued before the first use: one 16-B load in flight per thread leaves the pass at 3 TB/s)
+    const int step = gridDim.x * PL;
+    for (int p0 = blockIdx.x * PL + pl; p0 < P; p0 += HBN_U * step) {
+        h8 v[HBN_U], r[HBN_U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = fmaf((float)v[e], sc[e], sh[e]);
-            if (res) f += (float)r[e];
-            if (relu) f = fmaxf(f, 0.f);
-            o[e] = (_Float16)f;
+        for (int u = 0; u < HBN_U; ++u) {
+            const int p = p0 + u * step;
+            if (p < P) {
+                const size_t off = (size_t)p * C + g * 8;
+                v[u] = *reinterpret_cast<const h8*>(x + off);
+                if (res) r[u] = *reinterpret_cast<const h8*>(res + off);
+            }
         }
-        *reinterpret_cast<h8*>(y + off) = o;
+#pragma unroll
+        for (int u = 0; u < HBN_U; ++u) {
+            const int p = p0 + u * step;
+            if (p >= P) continue;
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = fmaf((float)v[u][e], sc[e], sh[e]);
+                if (res) f += (float)r[u][e];
+                if (relu) f = fmaxf(f, 0.f);
+                o[e] = (_Float16)f;
+            }
+            *reinterpret_cast<h8*>(y + (size_t)p * C + g * 8) = o;
+        }
     }
 }
 
@@ -159,20 +173,31 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
     float acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
-        const size_t off = (size_t)p * C + g * 8;
-        const h8 gv = *reinterpret_cast<const h8*>(dy + off);
-        const h8 xv = *reinterpret_cast<const h8*>(x + off);
-        h8 yv;
-        if (relu && !recompute) yv = *reinterpret_cast<const h8*>(y + off);
+    const int step = gridDim.x * PL;
+    for (int p0 = blockIdx.x * PL + pl; p0 < P; p0 += HBN_U * step) {         // (the pixels of a trip in ascending order: the sums are those of the one-pixel loop)
+        h8 gv[HBN_U], xv[HBN_U], yv[HBN_U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float gq = (float)gv[e];
-            const float xf = (float)xv[e];
-            if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
-            else if (relu && !((float)yv[e] > 0.f)) gq = 0.f;
-            acc[e] += gq;
-            acc[8 + e] = fmaf(gq, (xf - mu[e]) * is[e], acc[8 + e]);
+        for (int u = 0; u < HBN_U; ++u) {
+            const int p = p0 + u * step;
+            if (p < P) {
+                const size_t off = (size_t)p * C + g * 8;
+                gv[u] = *reinterpret_cast<const h8*>(dy + off);
+                xv[u] = *reinterpret_cast<const h8*>(x + off);
+                if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HBN_U; ++u) {
+            if (p0 + u * step >= P) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gq = (float)gv[u][e];
+                const float xf = (float)xv[u][e];
+                if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+                else if (relu && !((float)yv[u][e] > 0.f)) gq = 0.f;
+                acc[e] += gq;
+                acc[8 + e] = fmaf(gq, (xf - mu[e]) * is[e], acc[8 + e]);
+            }
         }
     }
     hbn_block_reduce(acc, sm, partial, G, Gb, PL, blockIdx.y * Gb);
@@ -204,24 +229,37 @@ __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __re
         const float4 q = coef[g * 8 + e], r = coef2[g * 8 + e];
         sc[e] = q.x; sh[e] = q.y; mu[e] = q.z; is[e] = q.w; k1[e] = r.x; k2[e] = r.y;
     }
-    for (int p = blockIdx.x * PL + pl; p < P; p += gridDim.x * PL) {
-        const size_t off = (size_t)p * C + g * 8;
-        const h8 gv = *reinterpret_cast<const h8*>(dy + off);
-        const h8 xv = *reinterpret_cast<const h8*>(x + off);
-        h8 yv;
-        if (relu && !recompute) yv = *reinterpret_cast<const h8*>(y + off);
-        h8 o, gr;
+    const int step = gridDim.x * PL;
+    for (int p0 = blockIdx.x * PL + pl; p0 < P; p0 += HBN_U * step) {
+        h8 gv[HBN_U], xv[HBN_U], yv[HBN_U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float gq = (float)gv[e];
-            const float xf = (float)xv[e];
-            if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
-            else if (relu && !((float)yv[e] > 0.f)) gq = 0.f;
-            gr[e] = (_Float16)gq;
-            o[e] = (_Float16)(sc[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
+        for (int u = 0; u < HBN_U; ++u) {
+            const int p = p0 + u * step;
+            if (p < P) {
+                const size_t off = (size_t)p * C + g * 8;
+                gv[u] = *reinterpret_cast<const h8*>(dy + off);
+                xv[u] = *reinterpret_cast<const h8*>(x + off);
+                if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
+            }
         }
-        *reinterpret_cast<h8*>(dx + off) = o;
-        if (dres) *reinterpret_cast<h8*>(dres + off) = gr;
+#pragma unroll
+        for (int u = 0; u < HBN_U; ++u) {
+            const int p = p0 + u * step;
+            if (p >= P) continue;
+            const size_t off = (size_t)p * C + g * 8;
+            h8 o, gr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gq = (float)gv[u][e];
+                const float xf = (float)xv[u][e];
+                if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+                else if (relu && !((float)yv[u][e] > 0.f)) gq = 0.f;
+                gr[e] = (_Float16)gq;
+                o[e] = (_Float16)(sc[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
+            }
+            *reinterpret_cast<h8*>(dx + off) = o;
+            if (dres) *reinterpret_cast<h8*>(dres + off) = gr;
+        }
     }
 }
 

@@ -513,6 +513,21 @@ __global__ __launch_bounds__(256) void nhwc_f16_to_nchw_f32_kernel(const _Float1
         dst[i] = (float)src[(n * HW + hw) * C + c] * scale;
     }
 }
+// the same for C % 8 == 0: a thread reads one 16-B chunk (8 channels of a pixel) and writes eight floats, each store coalesced across the hw-consecutive threads of a wave
+// (the element-wise kernel above fetches 2 B per lane from 64 different lines: 92 us for the regressor's 64 x 272 x 16 x 16 output)
+__global__ __launch_bounds__(256) void nhwc_f16_to_nchw_f32_c8_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int N, int C, int HW,
+                                                                      float scale) {
+    const int C8 = C >> 3;
+    const size_t total = (size_t)N * C8 * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const int c8 = (int)((i / HW) % C8);
+        const size_t n = i / ((size_t)HW * C8);
+        const h8 v = *reinterpret_cast<const h8*>(src + (n * HW + hw) * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[(n * C + c8 * 8 + e) * HW + hw] = (float)v[e] * scale;
+    }
+}
 // fp32 master weight [K][C][R][S] -> fp16 [K][R][S][Cpad] (forward / wgrad image) and [Cpad][R][S][K] (dgrad image; may be null)
 __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restrict__ w, _Float16* __restrict__ krsc, _Float16* __restrict__ crsk,
                                                             int K, int C, int RS, int Cpad) {
@@ -765,6 +780,12 @@ int32_t p3d_nchw_f32_to_nhwc_f16(const float* src, void* dst, int32_t N, int32_t
 
 int32_t p3d_nhwc_f16_to_nchw_f32(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, float scale, void* stream) {
     P3D_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0, "nhwc_f16_to_nchw_f32: bad argument");
+    if (C % 8 == 0 && ((uintptr_t)src & 15) == 0) {
+        const int64_t total8 = (int64_t)N * (C / 8) * HW;
+        const unsigned blocks8 = (unsigned)(ceil_div(total8, 256) < 8192 ? ceil_div(total8, 256) : 8192);
+        hipLaunchKernelGGL(nhwc_f16_to_nchw_f32_c8_kernel, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, N, C, HW, scale);
+        return check_launch("nhwc_f16_to_nchw_f32");
+    }
     const int64_t total = (int64_t)N * C * HW;
     const unsigned blocks = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
     hipLaunchKernelGGL(nhwc_f16_to_nchw_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, N, C, HW, scale);
