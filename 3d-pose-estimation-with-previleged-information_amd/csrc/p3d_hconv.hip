@@ -224,10 +224,15 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
         for (int i = 0; i < 8; ++i) {
             const int pl = pr + 16 * i, n = n0 + pl;
             if (n >= ncols || !ch_ok) continue;
-            const h8 v = *reinterpret_cast<const h8*>(T + pl * EPITCH + cc * 16);
+            h8 v = *reinterpret_cast<const h8*>(T + pl * EPITCH + cc * 16);
             const int img = n / (Hc * Wc), rem = n - img * (Hc * Wc);
             const int ii = rem / Wc, jj = rem - ii * Wc;
             const size_t off = ((size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw) * p.M + ch;
+            if (EPI == 1 && p.accumulate) {                    // the sum of two fp16 gradients, as autograd adds them (each rounded, then added)
+                const h8 old = *reinterpret_cast<const h8*>(p.D + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)old[e] + (float)v[e]);
+            }
             *reinterpret_cast<h8*>(p.D + off) = v;
             if constexpr (EPI == 2) {
 #pragma unroll
@@ -619,7 +624,7 @@ static void launch_gather(const HGatherParams& p, int ncls, int max_cols, hipStr
     dim3 grid((unsigned)(p.tiles_m * tiles_n), (unsigned)ncls);
     if (epi == 2) hipLaunchKernelGGL((hconv_gather_kernel<32, 2>), grid, dim3(256), 0, st, p);
     else if (epi == 3) hipLaunchKernelGGL((hconv_gather_kernel<32, 3>), grid, dim3(256), 0, st, p);
-    else if (g_hstage && !p.bias && !p.dscale && !p.accumulate) hipLaunchKernelGGL((hconv_gather_kernel<32, 1>), grid, dim3(256), 0, st, p);
+    else if (g_hstage && !p.bias && !p.dscale) hipLaunchKernelGGL((hconv_gather_kernel<32, 1>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((hconv_gather_kernel<32, 0>), grid, dim3(256), 0, st, p);
 }
 

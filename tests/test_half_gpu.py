@@ -83,6 +83,13 @@ def test_hconv_fwd_dgrad_wgrad(case, pkg):
     assert np.isfinite(got).all()
     assert relerr(got[:, :c], dx_ref) < 1.5e-3
     assert not got[:, c:].any()
+    # d->accumulate: dx += result (the gradient another consumer of the same input already wrote: GradJoin, the first conv of a block with an identity shortcut)
+    base16 = r16(rng.standard_normal((n, c, h, w)))
+    acc = nhwc16(base16, cpad)
+    d.accumulate = 1
+    pkg._lib.check(L.p3d_hconv2d_dgrad(ctypes.byref(d), p(dyt), p(crsk), None, p(acc), stream), 'dgrad accumulate')
+    d.accumulate = 0
+    assert relerr(nchw32(acc)[:, :c], base16 + dx_ref) < 2e-3
     # wgrad: fp32 result, accumulated onto a given master gradient with a scale
     dw_ref = ref.conv2d_wgrad(dy, x, wt.shape, st, pad, dil)
     base = rng.standard_normal(wt.shape).astype(np.float32)
