@@ -2018,6 +2018,8 @@ int fx_wgrad_splits(const p3d_conv_desc* d, bool images) {
         case 144: target = 720; break;
         default: target = 768;              // (1, 9, 64 tiles; anything the sweep has not seen)
     }
+    static const int scale = [] { const char* e = getenv("P3D_WGRAD_SCALE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 100; }();      // percent of the plan's block count (tuning aid)
+    target = target * scale / 100;
     int64_t splits = (2 * target + tiles) / (2 * tiles);                 // nearest
     if (splits > total / 32) splits = total / 32;                        // at least 32 K steps per block
     if (g_force_wgrad_splits > 0) splits = g_force_wgrad_splits < total ? g_force_wgrad_splits : total;
