@@ -72,7 +72,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // stores of one 256-B run.  EPI 2: + the statistics of the BatchNorm behind this convolution (sum y, sum y^2 of the ROUNDED fp16 values, i.e. what a pass over y would
 // read).  EPI 3: + the sums of the BatchNorm in front of a data gradient (sum g, sum g * xhat with g = the result masked by that layer's ReLU, recomputed from its raw
 // output and constants as hbn_bwd_reduce_kernel does).  EPI 2 / 3 need one pixel class (every block owns a full row of the partial table).
-template <int BK, int EPI>
+// PIPE: the K step in the order of the fp32 path's kernels -- the registers fetched during the previous step go to LDS behind the step's first MFMAs, then the loads of
+// the step after next are issued, then the rest of the MFMAs run: a fetch has a whole step to arrive and the LDS stores complete under MFMAs instead of in front of the barrier.
+template <int BK, int EPI, bool PIPE>
 __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
     constexpr int BM = 128, BN = 128;
     constexpr int CH = BK / 8;                 // 16-B chunks per tile row
@@ -165,15 +167,21 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    if (nk > 0) { fetch(); stage(0); }
+    if (nk > 0) { fetch(); stage(0); if (PIPE && nk > 1) fetch(); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fetch();
+        if (!PIPE && kt + 1 < nk) fetch();
         const unsigned char* a_rd = As + (size_t)(buf * BM + wm * 64 + fr) * ROWB + fh * 16;
         const unsigned char* b_rd = Bs + (size_t)(buf * BN + wn * 64 + fr) * ROWB + fh * 16;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            if (PIPE && ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) stage(buf ^ 1);
+                if (kt + 2 < nk) fetch();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             h8 af[2], bf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const h8*>(a_rd + a * 32 * ROWB + ks * 32);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) stage(buf ^ 1);
+        if (!PIPE && kt + 1 < nk) stage(buf ^ 1);
         __syncthreads();
     }
 
@@ -622,10 +630,11 @@ static bool g_hstage = [] { const char* e = getenv("P3D_HALF_STAGED_STORE"); ret
 static void launch_gather(const HGatherParams& p, int ncls, int max_cols, hipStream_t st, int epi = 0) {
     const int tiles_n = (int)ceil_div(max_cols, 128);
     dim3 grid((unsigned)(p.tiles_m * tiles_n), (unsigned)ncls);
-    if (epi == 2) hipLaunchKernelGGL((hconv_gather_kernel<32, 2>), grid, dim3(256), 0, st, p);
-    else if (epi == 3) hipLaunchKernelGGL((hconv_gather_kernel<32, 3>), grid, dim3(256), 0, st, p);
-    else if (g_hstage && !p.bias && !p.dscale) hipLaunchKernelGGL((hconv_gather_kernel<32, 1>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((hconv_gather_kernel<32, 0>), grid, dim3(256), 0, st, p);
+    static const bool pipe = [] { const char* e = getenv("P3D_HALF_PIPE"); return !(e && atoi(e) == 0); }();      // P3D_HALF_PIPE=0: A/B
+    const int e = epi == 2 ? 2 : epi == 3 ? 3 : (g_hstage && !p.bias && !p.dscale) ? 1 : 0;
+#define P3D_HG_CASE(E) if (e == E) { if (pipe) hipLaunchKernelGGL((hconv_gather_kernel<32, E, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((hconv_gather_kernel<32, E, false>), grid, dim3(256), 0, st, p); return; }
+    P3D_HG_CASE(0) P3D_HG_CASE(1) P3D_HG_CASE(2) P3D_HG_CASE(3)
+#undef P3D_HG_CASE
 }
 
 }  // namespace p3d

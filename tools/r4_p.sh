@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4: -half_acc, pipelined K step of the gather kernel: tests, per-shape bench, step A/B
+O=gpurun_out/r4p; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_half_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1; echo "pytest exit $?" | tee -a $O/pytest.txt
+tail -3 $O/pytest.txt
+grep -q "pytest exit 0" $O/pytest.txt || exit 1
+b() { timeout -k 10 300 python bench.py --lean --half --steps 30 --warmup 5 2>/dev/null | tail -1 | sed 's/.*"value": \([0-9.]*\).*"ms_per_step": \([0-9.]*\).*/\1 crops\/s  \2 ms/'; }
+for rep in 1 2 3; do
+  echo "pipelined        : $(b)" | tee -a $O/ab.txt
+  echo "P3D_HALF_PIPE=0  : $(P3D_HALF_PIPE=0 b)" | tee -a $O/ab.txt
+done
+timeout -k 10 300 python tools/hconv_bench.py 2>&1 | grep -v amdgpu > $O/hconv_pipe.txt; tail -3 $O/hconv_pipe.txt
+P3D_HALF_PIPE=0 timeout -k 10 300 python tools/hconv_bench.py 2>&1 | grep -v amdgpu > $O/hconv_nopipe.txt; tail -3 $O/hconv_nopipe.txt
