@@ -407,13 +407,19 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
         return __builtin_bit_cast(h8, v);
     };
 
-    if (nk > 0) { fetch(0); stage(0); }
+    // (K step in the order of hconv_gather_kernel<.., PIPE>: the next step's stores and the loads of the step after it between the two halves of the step's MFMAs)
+    if (nk > 0) { fetch(0); stage(0); if (nk > 1) fetch(1); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fetch(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < BKP / 16; ++ks) {
+            if (ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) stage(buf ^ 1);
+                if (kt + 2 < nk) fetch(kt + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             h8 af[2], bf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = tr_frag(As + buf * BKP * 256, wm * 64 + a * 32, ks);
@@ -424,7 +430,6 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) stage(buf ^ 1);
         __syncthreads();
     }
 
