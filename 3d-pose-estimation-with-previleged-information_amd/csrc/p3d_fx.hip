@@ -1661,8 +1661,9 @@ static FxSplit fx_plan_split(int64_t tiles, int nk) {
     int64_t want;
     if (g_force_conv_splits > 0) want = g_force_conv_splits < nk ? g_force_conv_splits : nk;
     else {
-        if (tiles > 400 || nk < 64) return s;
-        want = ceil_div(768, tiles);
+        static const int target = [] { const char* e = getenv("P3D_SPLITK_BLOCKS"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : 768; }();      // (tuning aid; 0: never split)
+        if (tiles > 400 || nk < 64 || target == 0) return s;
+        want = ceil_div(target, tiles);
         if (want > nk / 32) want = nk / 32;
         if (want > 8) want = 8;
     }
