@@ -203,16 +203,26 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
         static_assert(128 * EPITCH <= 2 * (BM + BN) * ROWB, "the staging tile lives in the operand buffers");
         unsigned char* T = smem;                               // (the K loop ended on a barrier)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            float dsc = 1.f;                                   // partial conv: the per-pixel factor of the result, multiplied in before the one rounding (as EPI 0 does)
+            if (EPI == 1 && p.dscale) {
+                const int n = n0 + wn * 64 + b * 32 + fr;
+                if (n < ncols) {
+                    const int img = n / (Hc * Wc), rem = n - img * (Hc * Wc);
+                    const int ii = rem / Wc, jj = rem - ii * Wc;
+                    dsc = p.dscale[(size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw];
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     h4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[a][b][4 * g + e];
+                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)(EPI == 1 ? acc[a][b][4 * g + e] * dsc : acc[a][b][4 * g + e]);
                     *reinterpret_cast<h4*>(T + (wn * 64 + b * 32 + fr) * EPITCH + (wm * 64 + a * 32 + 8 * g + 4 * fh) * 2) = o;
                 }
+        }
         __syncthreads();
         const int cc = t & 15, pr = t >> 4;                    // this thread: 16-B chunk cc (8 channels) of pixel rows pr, pr + 16, ...
         const int ch = m0 + cc * 8;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             const int img = n / (Hc * Wc), rem = n - img * (Hc * Wc);
             const int ii = rem / Wc, jj = rem - ii * Wc;
             const size_t off = ((size_t)(img * p.Hd + p.dmul * ii + ph) * p.Wd + p.dmul * jj + pw) * p.M + ch;
-            if (EPI == 1 && p.accumulate) {                    // the sum of two fp16 gradients, as autograd adds them (each rounded, then added)
+            if (EPI == 1 && p.accumulate) {                    // the sum of two fp16 gradients, as autograd adds them (each rounded, then added; with a factor: see below)
                 const h8 old = *reinterpret_cast<const h8*>(p.D + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)old[e] + (float)v[e]);
@@ -636,7 +646,7 @@ static void launch_gather(const HGatherParams& p, int ncls, int max_cols, hipStr
     const int tiles_n = (int)ceil_div(max_cols, 128);
     dim3 grid((unsigned)(p.tiles_m * tiles_n), (unsigned)ncls);
     static const bool pipe = [] { const char* e = getenv("P3D_HALF_PIPE"); return !(e && atoi(e) == 0); }();      // P3D_HALF_PIPE=0: A/B
-    const int e = epi == 2 ? 2 : epi == 3 ? 3 : (g_hstage && !p.bias && !p.dscale) ? 1 : 0;
+    const int e = epi == 2 ? 2 : epi == 3 ? 3 : (g_hstage && !p.bias && !(p.dscale && p.accumulate)) ? 1 : 0;      // (bias, and a factor on an accumulating launch, keep the single rounding of EPI 0)
 #define P3D_HG_CASE(E) if (e == E) { if (pipe) hipLaunchKernelGGL((hconv_gather_kernel<32, E, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((hconv_gather_kernel<32, E, false>), grid, dim3(256), 0, st, p); return; }
     P3D_HG_CASE(0) P3D_HG_CASE(1) P3D_HG_CASE(2) P3D_HG_CASE(3)
 #undef P3D_HG_CASE
