@@ -133,7 +133,8 @@ SIGNATURES = {
     'p3d_hbn_eval_fwd': (_i32, [_ptr] * 7 + [_i32, _i32, _f32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_train_bwd': (_i32, [_ptr] * 8 + [_i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_frozen_bwd': (_i32, [_ptr] * 8 + [_i32, _i32, _i32, _i32, _ptr, _sz, _ptr]),
-    'p3d_hbn_train_fwd_partial': (_i32, [_ptr] * 8 + [_i32, _i32, _f32, _f32, _i32, _ptr, _i32, _ptr]),
+    'p3d_hbn_train_fwd_partial': (_i32, [_ptr] * 8 + [_i32, _i32, _f32, _f32, _i32, _ptr, _i32, _ptr, _ptr]),
+    'p3d_hbn_train_bwd_mask': (_i32, [_ptr] * 8 + [_i32, _i32, _i32, _ptr, _sz, _ptr]),
     'p3d_hbn_train_bwd_partial': (_i32, [_ptr] * 6 + [_i32, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
     'p3d_hbn_eval_coef': (_i32, [_ptr] * 5 + [_i32, _f32, _ptr]),
     'p3d_hconcat': (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _ptr]),

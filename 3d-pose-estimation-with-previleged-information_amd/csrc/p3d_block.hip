@@ -761,7 +761,8 @@ int32_t p3d_hblock_fwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* w
         const p3d_conv_desc* d = &b->conv[i];
         if (fused)
             return p3d_hbn_train_fwd_partial(io->c[i], res, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], y, io->coef[i], d->N * d->Ho * d->Wo, d->K,
-                                             b->momentum[i], b->eps[i], relu, (const float*)workspace, p3d_hconv2d_sum_rows(d, 0), stream);
+                                             b->momentum[i], b->eps[i], relu, (const float*)workspace, p3d_hconv2d_sum_rows(d, 0),
+                                             (i == last && res) ? (uint8_t*)io->out_mask : nullptr, stream);
         return p3d_hbn_train_fwd(io->c[i], res, io->gamma[i], io->beta[i], io->running_mean[i], io->running_var[i], y, io->coef[i], d->N * d->Ho * d->Wo, d->K,
                                  b->momentum[i], b->eps[i], relu, workspace, workspace_bytes, stream);
     };
@@ -826,8 +827,12 @@ int32_t p3d_hblock_bwd(const p3d_block_desc* b, const p3d_hblock_io* io, void* w
         return p3d_hbn_train_bwd_partial(io->da[j], io->c[j], io->coef[j], io->dc[j], io->dgamma[j], io->dbeta[j], d->N * d->Ho * d->Wo, d->K, acc, (const float*)workspace, rows,
                                          coef2, stream);
     };
-    // closing BatchNorm: d c_last, and the gradient that enters the shortcut (dout masked by the block's output)
-    if (int32_t e = bn_bwd(last, io->dout, io->out, io->da[3], 1)) return e;
+    // closing BatchNorm: d c_last, and the gradient that enters the shortcut (dout masked by the block's output, or by the mask bytes forward left of it)
+    if (hblock_fused() && io->out_mask) {
+        const p3d_conv_desc* d = &b->conv[last];
+        if (int32_t e = p3d_hbn_train_bwd_mask(io->dout, io->c[last], (const uint8_t*)io->out_mask, io->coef[last], io->dc[last], io->da[3], io->dgamma[last], io->dbeta[last],
+                                               d->N * d->Ho * d->Wo, d->K, acc, workspace, workspace_bytes, stream)) return e;
+    } else if (int32_t e = bn_bwd(last, io->dout, io->out, io->da[3], 1)) return e;
     hipEvent_t ready = two ? mark_position(st) : nullptr;
     // the downsample branch first (the order autograd runs the per-layer nodes in: dx = branch's data gradient, then the first conv's added onto it);
     // per layer the data gradient is queued before the weight gradient: it is the chain the next layer waits for

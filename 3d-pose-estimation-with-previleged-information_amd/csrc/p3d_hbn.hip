@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256) void hbn_eval_coef_kernel(const float* __restr
 }
 
 // y = act(x * sc + sh + res)
+// mask (or null): one byte per (pixel, 8-channel group), bit e = [y > 0] of the group's channel e -- what the backward pass of a layer WITH a residual needs of y
+// (2 B per element otherwise: the mask of such a layer cannot be recomputed from x alone)
 __global__ __launch_bounds__(256) void hbn_apply_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res, const float4* __restrict__ coef,
-                                                        _Float16* __restrict__ y, int P, int C, int relu) {
+                                                        _Float16* __restrict__ y, int P, int C, int relu, uint8_t* __restrict__ mask) {
     const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
     const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
     float sc[8], sh[8];
@@ -155,18 +157,26 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(const _Float16* __restri
                 o[e] = (_Float16)f;
             }
             *reinterpret_cast<h8*>(y + (size_t)p * C + g * 8) = o;
+            if (mask) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bits |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+                mask[(size_t)p * G + g] = (uint8_t)bits;
+            }
         }
     }
 }
 
 // backward pass 1: partial[blk][g][0..7] = sum g, [8..15] = sum g * xhat, g = dy masked by the ReLU (mask from y, or, with
 // y == nullptr (no residual), recomputed as fmaf(x, sc, sh) > 0 with the forward's own constants)
+// ymask (or null): the mask bytes hbn_apply_kernel left, in place of y
 __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
-                                                             const float4* __restrict__ coef, float* __restrict__ partial, int P, int C, int relu) {
+                                                             const float4* __restrict__ coef, float* __restrict__ partial, int P, int C, int relu,
+                                                             const uint8_t* __restrict__ ymask) {
     __shared__ float sm[256 * 16];
     const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
     const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
-    const bool recompute = relu && y == nullptr;
+    const bool recompute = relu && y == nullptr && ymask == nullptr;
     float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float4 q = coef[g * 8 + e]; sc[e] = q.x; sh[e] = q.y; mu[e] = q.z; is[e] = q.w; }
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
     const int step = gridDim.x * PL;
     for (int p0 = blockIdx.x * PL + pl; p0 < P; p0 += HBN_U * step) {         // (the pixels of a trip in ascending order: the sums are those of the one-pixel loop)
         h8 gv[HBN_U], xv[HBN_U], yv[HBN_U];
+        unsigned mb[HBN_U];
 #pragma unroll
         for (int u = 0; u < HBN_U; ++u) {
             const int p = p0 + u * step;
@@ -183,7 +194,8 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
                 const size_t off = (size_t)p * C + g * 8;
                 gv[u] = *reinterpret_cast<const h8*>(dy + off);
                 xv[u] = *reinterpret_cast<const h8*>(x + off);
-                if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
+                if (ymask) mb[u] = ymask[(size_t)p * G + g];
+                else if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
             }
         }
 #pragma unroll
@@ -193,7 +205,8 @@ __global__ __launch_bounds__(256) void hbn_bwd_reduce_kernel(const _Float16* __r
             for (int e = 0; e < 8; ++e) {
                 float gq = (float)gv[u][e];
                 const float xf = (float)xv[u][e];
-                if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+                if (ymask) { if (!((mb[u] >> e) & 1u)) gq = 0.f; }
+                else if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
                 else if (relu && !((float)yv[u][e] > 0.f)) gq = 0.f;
                 acc[e] += gq;
                 acc[8 + e] = fmaf(gq, (xf - mu[e]) * is[e], acc[8 + e]);
@@ -219,10 +232,10 @@ __global__ __launch_bounds__(256) void hbn_bwd_finalize_kernel(const float* __re
 // backward pass 2: dx = gamma*invstd*(g - k1 - xhat*k2) (gamma*invstd is the forward's sc), dres = g
 __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const _Float16* __restrict__ y,
                                                             const float4* __restrict__ coef, const float4* __restrict__ coef2, _Float16* __restrict__ dx,
-                                                            _Float16* __restrict__ dres, int P, int C, int relu) {
+                                                            _Float16* __restrict__ dres, int P, int C, int relu, const uint8_t* __restrict__ ymask) {
     const int G = C >> 3, Gb = G < 256 ? G : 256, PL = 256 / Gb;
     const int t = threadIdx.x, g = t % Gb + blockIdx.y * Gb, pl = t / Gb;
-    const bool recompute = relu && y == nullptr;
+    const bool recompute = relu && y == nullptr && ymask == nullptr;
     float mu[8], is[8], sc[8], sh[8], k1[8], k2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __re
     const int step = gridDim.x * PL;
     for (int p0 = blockIdx.x * PL + pl; p0 < P; p0 += HBN_U * step) {
         h8 gv[HBN_U], xv[HBN_U], yv[HBN_U];
+        unsigned mb[HBN_U];
 #pragma unroll
         for (int u = 0; u < HBN_U; ++u) {
             const int p = p0 + u * step;
@@ -239,7 +253,8 @@ __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __re
                 const size_t off = (size_t)p * C + g * 8;
                 gv[u] = *reinterpret_cast<const h8*>(dy + off);
                 xv[u] = *reinterpret_cast<const h8*>(x + off);
-                if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
+                if (ymask) mb[u] = ymask[(size_t)p * G + g];
+                else if (relu && !recompute) yv[u] = *reinterpret_cast<const h8*>(y + off);
             }
         }
 #pragma unroll
@@ -252,7 +267,8 @@ __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const _Float16* __re
             for (int e = 0; e < 8; ++e) {
                 float gq = (float)gv[u][e];
                 const float xf = (float)xv[u][e];
-                if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
+                if (ymask) { if (!((mb[u] >> e) & 1u)) gq = 0.f; }
+                else if (recompute) { if (!(fmaf(xf, sc[e], sh[e]) > 0.f)) gq = 0.f; }
                 else if (relu && !((float)yv[u][e] > 0.f)) gq = 0.f;
                 gr[e] = (_Float16)gq;
                 o[e] = (_Float16)(sc[e] * (gq - k1[e] - (xf - mu[e]) * is[e] * k2[e]));
@@ -392,14 +408,16 @@ int32_t p3d_hbn_train_fwd(const void* x, const void* res, const float* gamma, co
     hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, g.nblk, gamma, beta,
                        running_mean, running_var, (float4*)coef, P, C, momentum, eps);
     hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
-                       (_Float16*)y, P, C, relu);
+                       (_Float16*)y, P, C, relu, (uint8_t*)nullptr);
     return check_launch("hbn_train_fwd");
 }
 
 /* The same with the statistics already summed per (pixel tile, channel) by the convolution that produced x (p3d_hconv2d_fwd_stats): finalize + apply, no pass over x
- * for the sums.  partial [rows][C / 8][16]. */
+ * for the sums.  partial [rows][C / 8][16].  relu_mask (or NULL): P * C / 8 bytes, bit e of byte [pixel][group] = [y > 0] of the group's channel e -- what
+ * p3d_hbn_train_bwd_mask reads in place of y. */
 int32_t p3d_hbn_train_fwd_partial(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows, void* stream) {
+                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows,
+                                  uint8_t* relu_mask, void* stream) {
     P3D_REQUIRE(x && gamma && beta && y && coef && partial && rows > 0, "hbn_train_fwd_partial: null tensor");
     P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_fwd_partial: bad shape P=%d C=%d (C/8 must divide or be a multiple of 256)", P, C);
     P3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hbn_train_fwd_partial: running stats must come as a pair");
@@ -408,7 +426,7 @@ int32_t p3d_hbn_train_fwd_partial(const void* x, const void* res, const float* g
     hipLaunchKernelGGL(hbn_fwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, partial, rows, gamma, beta,
                        running_mean, running_var, (float4*)coef, P, C, momentum, eps);
     hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
-                       (_Float16*)y, P, C, relu);
+                       (_Float16*)y, P, C, relu, relu ? relu_mask : nullptr);
     return check_launch("hbn_train_fwd_partial");
 }
 
@@ -423,14 +441,15 @@ int32_t p3d_hbn_eval_fwd(const void* x, const void* res, const float* gamma, con
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hbn_eval_coef_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, coef, C, eps);
     hipLaunchKernelGGL(hbn_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)res, (const float4*)coef,
-                       (_Float16*)y, P, C, relu);
+                       (_Float16*)y, P, C, relu, (uint8_t*)nullptr);
     return check_launch("hbn_eval_fwd");
 }
 
 static int32_t hbn_bwd_impl(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
-                            int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream, int frozen) {
+                            int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream, int frozen,
+                            const uint8_t* ymask = nullptr) {
     P3D_REQUIRE(dy && x && coef && dx && dgamma && dbeta, "hbn_train_bwd: null tensor");
-    P3D_REQUIRE(!relu || y || !dres, "hbn_train_bwd: relu backward of a layer with a residual needs the forward output");
+    P3D_REQUIRE(!relu || y || ymask || !dres, "hbn_train_bwd: relu backward of a layer with a residual needs the forward output (or its mask bytes)");
     P3D_REQUIRE(P > 0 && hbn_shape_ok(C), "hbn_train_bwd: bad shape P=%d C=%d", P, C);
     if (!workspace || workspace_bytes < p3d_hbn_workspace_bytes(C)) { set_error("hbn_train_bwd: workspace too small"); return P3D_EWORKSPACE; }
     const HbnGeom g = hbn_geom(P, C);
@@ -438,17 +457,24 @@ static int32_t hbn_bwd_impl(const void* dy, const void* x, const void* y, const 
     float4* coef2 = (float4*)((char*)workspace + (size_t)HBN_MAX_BLOCKS * C * 2 * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hbn_bwd_reduce_kernel, dim3(g.nblk, g.G / g.Gb), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
-                       (const float4*)coef, partial, P, C, relu);
+                       (const float4*)coef, partial, P, C, relu, ymask);
     hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, g.nblk, dgamma, dbeta, coef2,
                        P, C, accumulate, frozen);
     hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)y,
-                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)dres, P, C, relu);
+                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)dres, P, C, relu, ymask);
     return check_launch("hbn_train_bwd");
 }
 
 int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     return hbn_bwd_impl(dy, x, y, coef, dx, dres, dgamma, dbeta, P, C, relu, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+/* p3d_hbn_train_bwd of a BatchNorm + residual + ReLU layer with the mask bytes of p3d_hbn_train_fwd_partial in place of the output y (1 B per 8 elements read instead of 16) */
+int32_t p3d_hbn_train_bwd_mask(const void* dy, const void* x, const uint8_t* relu_mask, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                               int32_t P, int32_t C, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    P3D_REQUIRE(relu_mask, "hbn_train_bwd_mask: null mask");
+    return hbn_bwd_impl(dy, x, nullptr, coef, dx, dres, dgamma, dbeta, P, C, 1, accumulate, workspace, workspace_bytes, stream, 0, relu_mask);
 }
 
 /* The backward pass of a BatchNorm + ReLU layer without a residual whose sums the data gradient that produced dy already took (p3d_hconv2d_dgrad_sums): finalize + apply.
@@ -461,7 +487,7 @@ int32_t p3d_hbn_train_bwd_partial(const void* dy, const void* x, const float* co
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(hbn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, partial, rows, dgamma, dbeta, (float4*)coef2, P, C, accumulate, 0);
     hipLaunchKernelGGL(hbn_bwd_apply_kernel, hbn_stream_grid(P, g), dim3(256), 0, st, (const _Float16*)dy, (const _Float16*)x, (const _Float16*)nullptr,
-                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)nullptr, P, C, 1);
+                       (const float4*)coef, (const float4*)coef2, (_Float16*)dx, (_Float16*)nullptr, P, C, 1, (const uint8_t*)nullptr);
     return check_launch("hbn_train_bwd_partial");
 }
 

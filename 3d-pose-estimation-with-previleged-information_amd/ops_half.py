@@ -395,6 +395,7 @@ def relu(x):
 import os as _os
 
 HALF_BLOCKS = _os.environ.get('P3D_HALF_BLOCKS', '1') != '0'
+HALF_MASK = _os.environ.get('P3D_HALF_MASK', '1') != '0'          # the closing ReLU's mask bytes instead of the block output in backward (A/B)
 _vp = ctypes.c_void_p
 
 
@@ -402,7 +403,7 @@ class HBlockIO(ctypes.Structure):
     """struct p3d_hblock_io"""
     _fields_ = [('x', _vp), ('out', _vp), ('w_krsc', _vp * 4), ('w_crsk', _vp * 4), ('c', _vp * 4), ('a', _vp * 4), ('coef', _vp * 4), ('gamma', _vp * 4), ('beta', _vp * 4),
                 ('running_mean', _vp * 4), ('running_var', _vp * 4), ('dout', _vp), ('dc', _vp * 4), ('da', _vp * 4), ('dx', _vp), ('dw', _vp * 4), ('dgamma', _vp * 4),
-                ('dbeta', _vp * 4), ('c_real', ctypes.c_int32 * 4)]
+                ('dbeta', _vp * 4), ('c_real', ctypes.c_int32 * 4), ('out_mask', _vp)]
 
 
 class _HPlan:
@@ -478,10 +479,16 @@ class HResidualBlockFn(torch.autograd.Function):
                 bn._ticked = False
             else:
                 bn.num_batches_tracked.add_(1)
+        # the closing ReLU's mask as one byte per 8 outputs: backward reads it in place of `out` (p3d_hblock_fuse_sums(1); ignored otherwise)
+        n, k, ho, wo = plan.out_shape
+        out_mask = torch.empty(n * ho * wo * (k // 8), dtype=torch.uint8, device=dev)
+        if HALF_MASK:
+            io.out_mask = out_mask.data_ptr()
         ws = workspace(dev, plan.main_bytes)
         check(lib().p3d_hblock_fwd(ctypes.byref(plan.desc), ctypes.byref(io), _p(ws), ws.numel(), _stream()), 'p3d_hblock_fwd')
         ctx.block, ctx.plan = block, plan
-        ctx.saved = (cs, acts, coefs)
+        ctx.fused = HALF_MASK and bool(lib().p3d_hblock_fuse_sums(-1))
+        ctx.saved = (cs, acts, coefs, out_mask)
         ctx.save_for_backward(x, out)
         return out
 
@@ -492,7 +499,7 @@ class HResidualBlockFn(torch.autograd.Function):
             raise P3DError('residual_block (fp16): backward called a second time on the same graph; run the forward again')
         block, plan = ctx.block, ctx.plan
         x, out = ctx.saved_tensors
-        cs, acts, coefs = ctx.saved
+        cs, acts, coefs, out_mask = ctx.saved
         ctx.saved = None
         dev = x.device
         dout = _cl(dout)
@@ -507,6 +514,8 @@ class HResidualBlockFn(torch.autograd.Function):
         grads = sinks if direct else [torch.empty(p.shape, dtype=torch.float32, device=dev) for _, _, p in params]
         io = HBlockIO()
         io.x, io.out, io.dout = x.data_ptr(), out.data_ptr(), dout.data_ptr()
+        if ctx.fused:                                      # (forward wrote the mask bytes only with the sums from the epilogues)
+            io.out_mask = out_mask.data_ptr()
         keep = []
         for slot, conv, bn in plan.layers:
             n, k, ho, wo = plan.shapes[slot]

@@ -227,6 +227,7 @@ typedef struct p3d_hblock_io {
     float* dgamma[4];
     float* dbeta[4];
     int32_t c_real[4];          /* real (unpadded) input channels of conv i */
+    void* out_mask;             /* or NULL: P * K_last / 8 bytes written by forward (bit = [out > 0]), read by backward in place of `out` (with p3d_hblock_fuse_sums(1)) */
 } p3d_hblock_io;
 int32_t p3d_hblock_workspace_bytes(const p3d_block_desc* b, size_t* main_bytes, size_t* side_bytes);
 /* BatchNorm sums of the block's layers from the conv epilogues (1, the default; P3D_HALF_FUSED=0 in the environment: 0) or from stand-alone passes (0: bit-identical to
@@ -497,7 +498,11 @@ int32_t p3d_hbn_train_bwd(const void* dy, const void* x, const void* y, const fl
                           int32_t P, int32_t C, int32_t relu, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* the same with the sums already taken by a convolution's epilogue (partial [rows][C/8][16]); bwd: a BatchNorm + ReLU layer without residual, coef2 = C float4 of scratch */
 int32_t p3d_hbn_train_fwd_partial(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows, void* stream);
+                                  void* y, float* coef, int32_t P, int32_t C, float momentum, float eps, int32_t relu, const float* partial, int32_t rows,
+                                  uint8_t* relu_mask /* or NULL: P * C / 8 bytes, bit e of byte [pixel][8-channel group] = [y > 0] */, void* stream);
+/* p3d_hbn_train_bwd of a BatchNorm + residual + ReLU layer (the closing one of a block, depthnet.py:52-56) reading those mask bytes in place of y */
+int32_t p3d_hbn_train_bwd_mask(const void* dy, const void* x, const uint8_t* relu_mask, const float* coef, void* dx, void* dres, float* dgamma, float* dbeta,
+                               int32_t P, int32_t C, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int32_t p3d_hbn_train_bwd_partial(const void* dy, const void* x, const float* coef, void* dx, float* dgamma, float* dbeta, int32_t P, int32_t C, int32_t accumulate,
                                   const float* partial, int32_t rows, float* coef2, void* stream);
 /* BatchNorm with FROZEN statistics inside a training step (freeze_batchnorm, depthnet.py:158-161, under -do_freeze): the forward is

@@ -160,6 +160,48 @@ def test_hconv_epilogue_sums(case, pkg):
     assert (s2 - (g * xhat).sum(0)).abs().max() <= 1e-5 * (g * xhat).abs().sum(0).max()
 
 
+@pytest.mark.parametrize('n,c,k,h', [(2, 64, 256, 16), (3, 32, 64, 9)])
+def test_hbn_relu_mask_bytes(n, c, k, h, pkg):
+    """The closing BatchNorm + shortcut + ReLU of a block (depthnet.py:52-56) with its statistics from the conv epilogue and the ReLU mask as one byte per 8 outputs:
+    the bytes are [y > 0], and p3d_hbn_train_bwd_mask returns bit for bit what p3d_hbn_train_bwd returns from y."""
+    L = pkg._lib.lib()
+    ops = pkg.ops
+    rng = np.random.default_rng(n + c + k)
+    stream, p = ops._stream(), ops._p
+    d = ops._desc((n, c, h, h), (k, c, 1, 1), 1, 0, 1)
+    x = nhwc16(r16(rng.standard_normal((n, c, h, h))))
+    krsc = nhwc16(r16(rng.standard_normal((k, c, 1, 1)) / np.sqrt(c)))
+    res = nhwc16(r16(rng.standard_normal((n, k, h, h))))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, k).astype(np.float32)).cuda()
+    beta = torch.from_numpy((rng.standard_normal(k) * 0.2).astype(np.float32)).cuda()
+    P = n * h * h
+    y = torch.empty(n, h, h, k, dtype=torch.float16, device='cuda')
+    out = torch.empty_like(y)
+    rows = L.p3d_hconv2d_sum_rows(ctypes.byref(d), 0)
+    part = torch.empty(rows, k // 8, 16, device='cuda')
+    coef = torch.empty(k, 4, device='cuda')
+    mask = torch.zeros(P * k // 8, dtype=torch.uint8, device='cuda')
+    pkg._lib.check(L.p3d_hconv2d_fwd_stats(ctypes.byref(d), p(x), p(krsc), p(y), p(part), stream), 'fwd_stats')
+    pkg._lib.check(L.p3d_hbn_train_fwd_partial(p(y), p(res), p(gamma), p(beta), None, None, p(out), p(coef), P, k, 0.1, 1e-5, 1, p(part), rows, p(mask), stream), 'fwd_partial')
+    bits = (out.reshape(P, k // 8, 8) > 0).to(torch.int32) * (2 ** torch.arange(8, device='cuda', dtype=torch.int32))
+    assert torch.equal(bits.sum(-1).to(torch.uint8).reshape(-1), mask)
+    want = torch.relu(y.float() * coef[:, 0] + coef[:, 1] + res.float())
+    assert (out.float() - want).abs().max() <= 2e-3 * want.abs().max()
+    dy = nhwc16(r16(rng.standard_normal((n, k, h, h))))
+    ws = torch.empty(L.p3d_hbn_workspace_bytes(k), dtype=torch.uint8, device='cuda')
+    got = []
+    for use_mask in (False, True):
+        dx, dres = torch.empty_like(y), torch.empty_like(y)
+        dg, db = torch.empty(k, device='cuda'), torch.empty(k, device='cuda')
+        if use_mask:
+            pkg._lib.check(L.p3d_hbn_train_bwd_mask(p(dy), p(y), p(mask), p(coef), p(dx), p(dres), p(dg), p(db), P, k, 0, p(ws), ws.numel(), stream), 'bwd_mask')
+        else:
+            pkg._lib.check(L.p3d_hbn_train_bwd(p(dy), p(y), p(out), p(coef), p(dx), p(dres), p(dg), p(db), P, k, 1, 0, p(ws), ws.numel(), stream), 'bwd')
+        got.append((dx, dres, dg, db))
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('case', [(2, 16, 20, 20, 64, 3, 1, 1, 1), (2, 8, 33, 31, 72, 3, 2, 1, 1), (2, 64, 16, 16, 128, 1, 1, 0, 1), (1, 1, 65, 63, 64, 7, 2, 3, 1)])
 def test_hconv_partial(case, pkg):
     """Partial conv on the fp16 kernels (mask in the operand fetch, mult in the epilogue, pre-scaled dy in backward) against the
