@@ -206,7 +206,7 @@ class HConv2dFn(torch.autograd.Function):
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device) if sink is None else sink
             d.accumulate = 0 if sink is None else 1
             nbytes = L.p3d_hconv2d_wgrad_workspace_bytes(ctypes.byref(d))
-            if ops.WGRAD_STREAM and sink is not None:
+            if ops.WGRAD_STREAM and sink is not None and not (ops.LAST_WGRAD_ON_LAUNCH and not ctx.needs_input_grad[0]):
                 side = ops._side_stream(x.device)
                 ops._queue_join()
                 side.wait_stream(torch.cuda.current_stream())

@@ -7,7 +7,7 @@ import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?')) for r in rows), key=lambda k: k[0])
-adams = [i for i, k in enumerate(ks) if 'adam_kernel' in k[2]]
+adams = [i for i, k in enumerate(ks) if 'adam_kernel' in k[2] or 'adam_dev_kernel' in k[2]]
 if len(adams) < back + 1:
     sys.exit('not enough steps in the trace')
 lo, hi = adams[-back - 1] + 1, adams[-back] + 1
