@@ -167,12 +167,16 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
+    // At most 64 result channels (layer1's 64-channel layers): the tile's rows 64-127 are padding, and with 64 x 64 wave tiles two of the four waves -- two of the CU's
+    // four SIMDs for this block -- would multiply zeros.  Narrow layout: every wave takes 32 of the 64 live rows (one row sub-tile) and its 64 columns.
+    const bool narrow = p.M <= 64;
+    const int rbase = narrow ? wm * 32 : wm * 64, na = narrow ? 1 : 2;
     if (nk > 0) { fetch(); stage(0); if (PIPE && nk > 1) fetch(); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (!PIPE && kt + 1 < nk) fetch();
-        const unsigned char* a_rd = As + (size_t)(buf * BM + wm * 64 + fr) * ROWB + fh * 16;
+        const unsigned char* a_rd = As + (size_t)(buf * BM + rbase + fr) * ROWB + fh * 16;
         const unsigned char* b_rd = Bs + (size_t)(buf * BN + wn * 64 + fr) * ROWB + fh * 16;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -184,13 +188,16 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             }
             h8 af[2], bf[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const h8*>(a_rd + a * 32 * ROWB + ks * 32);
+            for (int a = 0; a < 2; ++a)
+                if (a < na) af[a] = *reinterpret_cast<const h8*>(a_rd + a * 32 * ROWB + ks * 32);
 #pragma unroll
             for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const h8*>(b_rd + b * 32 * ROWB + ks * 32);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
+                if (a < na) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                }
         }
         if (!PIPE && kt + 1 < nk) stage(buf ^ 1);
         __syncthreads();
@@ -215,12 +222,14 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
+                if (a < na) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    h4 o;
+                    for (int g = 0; g < 4; ++g) {
+                        h4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)(EPI == 1 ? acc[a][b][4 * g + e] * dsc : acc[a][b][4 * g + e]);
-                    *reinterpret_cast<h4*>(T + (wn * 64 + b * 32 + fr) * EPITCH + (wm * 64 + a * 32 + 8 * g + 4 * fh) * 2) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(EPI == 1 ? acc[a][b][4 * g + e] * dsc : acc[a][b][4 * g + e]);
+                        *reinterpret_cast<h4*>(T + (wn * 64 + b * 32 + fr) * EPITCH + (rbase + a * 32 + 8 * g + 4 * fh) * 2) = o;
+                    }
                 }
         }
         __syncthreads();
@@ -296,8 +305,8 @@ __global__ __launch_bounds__(256) void hconv_gather_kernel(HGatherParams p) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ch = m0 + wm * 64 + a * 32 + 8 * g + 4 * fh;
-                if (ch >= p.M) continue;
+                const int ch = m0 + rbase + a * 32 + 8 * g + 4 * fh;
+                if (ch >= p.M || a >= na) continue;
                 h4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
