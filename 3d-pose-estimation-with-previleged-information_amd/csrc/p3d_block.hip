@@ -338,13 +338,14 @@ static thread_local ProfScope* g_prof_cur = nullptr;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
+static bool g_prof_marks = false;       // p3d_profile_enable(2): also note where the conv kernel itself ended (a third event per bracket: ~1 % on the bracketed time)
 ProfScope::ProfScope(int kind_, const p3d_conv_desc* d, hipStream_t st_) : st(st_), kind(kind_) {
     flops = 2.0 * d->N * d->K * d->Ho * d->Wo * (double)d->C * d->R * d->S;
     if (g_prof_on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { (void)hipEventRecord(a, st); g_prof_cur = this; }
 }
 void prof_kernel_done(hipStream_t st) {
     ProfScope* ps = g_prof_cur;
-    if (ps && ps->a && !ps->m && ps->st == st && hipEventCreate(&ps->m) == hipSuccess) (void)hipEventRecord(ps->m, st);
+    if (g_prof_marks && ps && ps->a && !ps->m && ps->st == st && hipEventCreate(&ps->m) == hipSuccess) (void)hipEventRecord(ps->m, st);
 }
 ProfScope::~ProfScope() {
     if (a && b) {
@@ -1006,8 +1007,9 @@ int32_t p3d_fx_weight_images_batched(const void* jobs, int32_t njobs, int32_t bl
 
 // ---- profile of the conv launches made by the executor (and by p3d_conv2d_* when enabled) ---------------------------------------------------------
 int32_t p3d_profile_enable(int32_t on) {
-    const int32_t before = g_prof_on ? 1 : 0;
+    const int32_t before = g_prof_on ? (g_prof_marks ? 2 : 1) : 0;
     g_prof_on = on != 0;
+    g_prof_marks = on == 2;
     return before;
 }
 

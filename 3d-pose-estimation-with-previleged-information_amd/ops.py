@@ -947,7 +947,7 @@ def conv2d_img(pass_, x_shape, w, stride, pad, dil, x_img=None, dy_img=None, x=N
 
 def profile_convs(on):
     """HIP-event brackets around every conv launch inside the library (p3d_profile_enable); returns the previous setting."""
-    return bool(lib().p3d_profile_enable(int(bool(on))))
+    return lib().p3d_profile_enable(int(on))          # 0 off, 1 brackets, 2 brackets + kernel-end marks (collect_conv_profile(kernel_only=True))
 
 
 def collect_conv_profile(kernel_only=False):

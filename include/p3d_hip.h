@@ -284,7 +284,7 @@ int32_t p3d_stem_wgrad_masked(const float* dy, const float* mult, const void* x_
 
 /* Brackets every convolution launch (p3d_conv2d_* and the block executor) with HIP events on the stream it runs on, for bench.py's roofline line.
  * p3d_profile_collect synchronises and returns, per kind (0 forward, 1 data gradient, 2 weight gradient), the summed milliseconds, algorithmic flops and launches. */
-int32_t p3d_profile_enable(int32_t on);
+int32_t p3d_profile_enable(int32_t on);      /* 0 off, 1 brackets, 2 brackets + the position where the conv kernel itself ended (p3d_profile_collect2's kernel_ms); returns the previous mode */
 int32_t p3d_profile_collect(double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind);
 /* the same plus, per kind, the milliseconds of the conv kernels alone (without the split-K / slab sums queued behind them inside the bracket) */
 int32_t p3d_profile_collect2(double* ms_by_kind, double* kernel_ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind);

@@ -37,9 +37,9 @@ def test_bench_line_schema():
     else:
         assert r['conv_paths']['x3_launches_per_step'] == 0
     assert r['traffic'] is None or r['traffic'] > 0
-    # the conv kernels alone are what `achieved` prices; the figure that also charges a launch with its split-K / slab sums (rounds 1-3) stays beside it and is never larger
-    w = r['with_slab_sums']
-    assert w['achieved'] <= r['achieved'] * 1.001 and w['avg_launch_ms'] >= r['avg_launch_ms'] * 0.999 and w['frac'] == pytest.approx(w['achieved'] / r['peak'], abs=1e-3)
+    # `achieved` charges a launch with the split-K / slab sums behind its kernel (rounds 1-3); the conv kernels alone stay beside it and are never slower
+    w = r['kernels_alone']
+    assert w['achieved'] >= r['achieved'] * 0.95 and w['avg_launch_ms'] <= r['avg_launch_ms'] * 1.05 and w['frac'] == pytest.approx(w['achieved'] / r['peak'], abs=1e-3)
     assert set(r['conv_ms_per_step']) == {'fwd', 'dgrad', 'wgrad'} and 'rocprofv3' in r['accounting']
     side = line['fp32_mfma_only']                                   # informational side measurement, never `value`
     assert side['unit'] == 'crops/s' and side['value'] > 0 and 'NOT the contract' in side['note']
