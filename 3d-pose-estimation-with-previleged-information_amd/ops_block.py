@@ -259,11 +259,33 @@ def _rebuild_stale_images(device):
         c.__dict__['_fx_images'] = (_image_key(c.weight), fwd, bwd)
 
 
+# P3D_IMAGES_EARLY=1: the optimizer step queues the rebuild of every weight image on the second stream right behind the Adam kernel, so that it runs beside the next
+# step's stem (whose own small image is not part of the batch) instead of on the launch stream in front of the first residual block.
+IMAGES_EARLY = os.environ.get('P3D_IMAGES_EARLY', '0') == '1'
+_images_event = {}
+
+
+def rebuild_images_early(device):
+    if not (IMAGES_EARLY and ops.WGRAD_STREAM and USE_WEIGHT_IMAGES) or torch.cuda.is_current_stream_capturing():
+        return
+    side = ops._side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))            # the optimizer's kernels
+    with torch.cuda.stream(side):
+        _rebuild_stale_images(device)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _images_event[device] = ev
+
+
 def weight_images(conv):
     """(forward image, data-gradient image) of conv.weight as device byte tensors (p3d_fx_weight_images*), rebuilt when the weight has changed:
     in-place edits through torch bump weight._version; writes behind torch's back (the optimizer kernels, broadcasts into the flat buffer) bump ops.WEIGHT_EPOCH."""
     import weakref
     w = conv.weight
+    if _images_event:
+        ev = _images_event.pop(w.device, None)
+        if ev is not None:
+            torch.cuda.current_stream(w.device).wait_event(ev)
     cached = conv.__dict__.get('_fx_images')
     if cached is not None and cached[0] == _image_key(w):
         return cached[1], cached[2]

@@ -114,6 +114,8 @@ class FlatAdam:
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count, max_norm or 0.0,
                       self.norm_sq if (max_norm and max_norm > 0) else None, grad_scale)
+        from . import ops_block
+        ops_block.rebuild_images_early(self.flat_p.device)
         return True
 
     def clip_and_step_dev(self, max_norm, grad_scale=1.0, skip_nonfinite=True):
