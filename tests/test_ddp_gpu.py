@@ -1,6 +1,8 @@
 """Data-parallel step on the GPU: two processes (gloo over the one card of the test box; RCCL needs one GPU per rank) run
 Trainer.train_step on different shards, and the result must equal the single-process composition of the same pieces:
-per-rank gradients with per-rank BN statistics and the GLOBAL valid-joint divisor, summed, scaled by 1/world, clipped, Adam."""
+per-rank gradients with per-rank BN statistics and the GLOBAL valid-joint divisor, summed, scaled by 1/world, clipped, Adam --
+composed once from the HIP kernels (exchange logic, to 1e-5) and once from the ORACLE's CPU port (arithmetic: every parameter's
+reduced gradient and both ranks' losses against oracle/torch_port.py)."""
 import os
 
 import numpy as np
@@ -76,6 +78,27 @@ def test_two_rank_step_equals_composed_reference(pkg, tmp_path):
         losses.append(float(loss))
     opt.flat_g.copy_(total)
     assert (total.cpu() - r0['flat_g']).abs().max().item() < 1e-5 * total.abs().max().item()      # the reduced gradient buffer itself
+    # The same composition on the ORACLE (oracle/torch_port.py, PyTorch on the CPU): per-rank forward / backward from the same weights with per-rank BatchNorm
+    # statistics; the oracle's loss is the local mean over 3 n_r elements, the data-parallel step divides by 3 N / world, so rank r's gradient is the oracle's
+    # times world * n_r / N.  This is the check that does not compare the HIP kernels with themselves (depth_main.py:72 spreads the model over GPUs; each replica
+    # normalises with its own batch statistics).
+    from oracle.torch_port import TorchPort
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    composed, oracle_losses = {}, []
+    for r in (0, 1):
+        port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family='depthnet', model='resnet18')
+        c, d, tc, tv = pkg.synth.make_batch(2, side=128, rank=r, step=0, invalid_frac=0.3 if r == 1 else 0.0)
+        want = port.train_step(c, d, tc, tv)
+        n_r = int(tv.sum())
+        oracle_losses.append(want['loss'] * 3 * n_r / float(divisor))
+        for k, g in want['grads'].items():
+            composed[k] = composed.get(k, 0) + g * (2.0 * n_r / n_valid)
+    assert r0['loss'] == pytest.approx(oracle_losses[0], rel=1e-4) and r1['loss'] == pytest.approx(oracle_losses[1], rel=1e-4)
+    worst = 0.0
+    for name, prm in model.named_parameters():
+        got, ref_g = prm.grad.detach().cpu().numpy(), composed[name]           # prm.grad is a view of opt.flat_g == the reduced buffer
+        worst = max(worst, float(np.abs(got - ref_g).max() / max(np.abs(ref_g).max(), 1e-12)))
+    assert worst < 2e-3, worst
     opt.clip_and_step(args.grad_norm, grad_scale=0.5)
     torch.cuda.synchronize()
     assert r0['loss'] == pytest.approx(losses[0], rel=1e-5) and r1['loss'] == pytest.approx(losses[1], rel=1e-5)
