@@ -1608,7 +1608,7 @@ static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0
 // image-fed forward / data gradient on v_mfma_f32_16x16x32_bf16 (fx16_conv_kernel): -1 = environment (P3D_FX16), 0 never, 1 (default) where its 64- and 96-row
 // channel tiles fit the layer better than 128 rows, 2 everywhere (the A/B of the two MFMA shapes: profiles/r04_fx16.md -- at 128 rows the 16x16x32 form is 1-3 %
 // SLOWER on the large layers, 20 fragment reads per step against 12, and the chip holds no higher clock on it in these kernels)
-// image-fed multi-tap launches with at least this many reduction channels walk the taps innermost (0: never; p3d_fx_tune(10, v)).  Measured (tools/r4_i.sh): the
+// image-fed multi-tap launches with at least this many reduction channels walk the taps innermost (0: never; p3d_fx_tune(10, v)).  Measured (tools/r04/r4_i.sh): the
 // regressor's forward (2048 channels x 9 taps) fetches 5.5x fewer bytes beyond L2 and runs 2 % faster; the 512-channel 3x3 layers fetch 3.1x fewer but run 2 % slower
 // (a tap change per K step costs more than their re-reads out of the Infinity Cache): 1024 takes the first and leaves the second
 static int g_tap_inner_min = 1024;
@@ -1617,7 +1617,7 @@ static int g_conv_order = -1, g_wgrad_order = -1;      // -1: the built-in choic
 // Which operand should the blocks an XCD runs at one time share?  An XCD's L2 holds 4 MB.  With the channel tile fastest an activation tile is fetched once and every
 // pixel tile streams the WHOLE weight image past the L2 (fine while that image stays in it); with the pixel tile fastest the ~96 resident blocks stream one
 // channel tile's weights together and each its own pixels.  Measured (profiles/r04_summary.md section 4): layer4 and the regressor fetched 3.7 - 28 x their algorithmic bytes.
-// MEASURED (tools/r4_g.sh, profiles/r04_summary.md section 4): the pixel-tile-fastest order is 1 - 46 % SLOWER on every shape, layer4 and the regressor included (forward
+// MEASURED (tools/r04/r4_g.sh, profiles/r04_summary.md section 4): the pixel-tile-fastest order is 1 - 46 % SLOWER on every shape, layer4 and the regressor included (forward
 // 0.896 vs 0.845 ms): the bytes FETCH_SIZE counts beyond L2 come out of the 256 MB Infinity Cache at a rate these matrix-pipe-bound kernels do not feel, while losing
 // the shared activation tile costs L2 hits they do.  So the built-in choice stays 0 everywhere; the switches remain for the record (p3d_fx_tune(7 / 8, 1)).
 static int fx_conv_order(size_t wimg_bytes, int tiles_m, int tiles_n) {
@@ -2012,7 +2012,7 @@ int fx_wgrad_splits(const p3d_conv_desc* d, bool images) {
     else switch ((int)tiles) {
         case 2: target = 384; break;
         case 4: target = 640; break;
-        case 5: target = 512; break;          // (two-tap column tiles of a 64 -> 64 3x3: tools/r4_i.sh)
+        case 5: target = 512; break;          // (two-tap column tiles of a 64 -> 64 3x3: tools/r04/r4_i.sh)
         case 8: case 32: case 36: target = 512; break;
         case 16: target = 256; break;
         case 128: target = 1024; break;

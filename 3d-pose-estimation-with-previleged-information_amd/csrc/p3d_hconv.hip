@@ -754,7 +754,7 @@ int32_t p3d_hconv2d_dgrad_sums(const p3d_conv_desc* d, const void* dy, const voi
 static void hwgrad_plan(const p3d_conv_desc* d, int* splits, int* kchunk) {
     const int64_t tiles = ceil_div(d->K, 128) * ceil_div((int64_t)d->R * d->S * d->C, 128);
     const int64_t ktot = (int64_t)d->N * d->Ho * d->Wo;
-    // blocks aimed at per layer.  Measured in the two-stream step (tools/r4_n.sh, -half_acc ResNet-50 batch 64): 1536 -> 15.22 ms, 1024 -> 15.05, 768 -> 14.81, 512 -> 14.71,
+    // blocks aimed at per layer.  Measured in the two-stream step (tools/r04/r4_n.sh, -half_acc ResNet-50 batch 64): 1536 -> 15.22 ms, 1024 -> 15.05, 768 -> 14.81, 512 -> 14.71,
     // 384 -> 14.64, 256 -> 15.26: every slab is 4 B per weight written and read again beside the launch stream's memory-bound passes, so the best count in the step is well
     // below the one that fills the chip for the kernel alone (P3D_HWGRAD_BLOCKS: tuning aid)
     static const int target = [] { const char* e = getenv("P3D_HWGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();

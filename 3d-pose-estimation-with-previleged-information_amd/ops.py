@@ -75,7 +75,7 @@ def workspace(device, nbytes):
 # join_side_stream() orders the launch stream after everything issued there (before an all-reduce / the optimizer reads .grad).
 WGRAD_STREAM = os.environ.get('P3D_WGRAD_STREAM', '1') != '0'
 # -half_acc: the weight gradient of a network's FIRST layer (no data gradient behind it) is the last kernel of the backward pass: queued on the second stream it waits
-# behind the weight gradients still pending there while the launch stream has nothing left to do; on the launch stream it runs beside them (tools/r4_t.sh: 14.04 / 14.03 ms
+# behind the weight gradients still pending there while the launch stream has nothing left to do; on the launch stream it runs beside them (tools/r04/r4_t.sh: 14.04 / 14.03 ms
 # against 14.09 / 14.11; P3D_LAST_WGRAD_MAIN=0: A/B).  The fp32 step measured no difference (28.17 / 28.11 / 28.10 against 28.29 / 28.05 / 27.99) and keeps the second stream.
 LAST_WGRAD_ON_LAUNCH = os.environ.get('P3D_LAST_WGRAD_MAIN', '1') != '0'
 _side_streams = {}
