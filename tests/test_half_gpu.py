@@ -567,7 +567,10 @@ def test_half_block_executor_equals_the_per_layer_path(case, pkg):
     (depthnet.py:40-56,96-116 under model.half()): with the BatchNorm sums from stand-alone passes (p3d_hblock_fuse_sums(0)) output, input gradient, every parameter
     gradient and the running statistics are bit-identical; with the sums from the conv epilogues (the default) the statistics are the same sums in another order, so the
     results agree to fp16 rounding (a value may land on the neighbouring fp16 number)."""
+    import os
     import test_block_gpu as tb
+    if os.environ.get('P3D_BLOCKS', '1') == '0':
+        pytest.skip('the block executors are switched off in this run (P3D_BLOCKS=0)')
     kind, inplanes, planes, stride, dil, n, h, with_ds = case
     oh = pkg.ops_half
     block = tb.build(pkg, kind, inplanes, planes, stride, dil, with_ds, seed=5)
