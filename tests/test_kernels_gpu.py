@@ -389,6 +389,38 @@ def test_conv_adjoint_identities_at_full_size(shape, pkg):
         assert abs(form - via_x) < 2e-5 * scale, (form, via_x)
 
 
+@pytest.mark.parametrize('shape', R50_CLASSES[1:], ids=['c%d_h%d_k%d_%dx%d_s%d_d%d' % (s[0], s[1], s[2], s[3], s[3], s[4], s[5]) for s in R50_CLASSES[1:]])
+def test_image_fed_adjoint_identities_at_full_size(shape, pkg):
+    """The same trilinear-form property for the IMAGE-FED instances the block executor launches (p3d_fx_conv_*_img on pre-split activation / gradient images) at
+    BASELINE's batch 64: the 64- and 96-row tiles of fx16_conv_kernel, the tap-inner K order of the regressor, the one-launch strided data gradient, the two- / three-tap
+    column tiles of the 64-channel weight gradients and every split / slab plan of the production sizes; and each result against the fp32-fed kernels on the same data."""
+    ops = pkg.ops
+    c, h, k, ks, st, dil = shape
+    pad = dil * (ks - 1) // 2
+    gen = torch.Generator(device='cuda').manual_seed(c * 5 + k + ks)
+    x = torch.randn(64, c, h, h, device='cuda', generator=gen)
+    w = torch.randn(k, c, ks, ks, device='cuda', generator=gen) / (c * ks * ks) ** 0.5
+    x_img = ops.act_image(x)
+    y = ops.conv2d_img('fwd', x.shape, w, st, pad, dil, x_img=x_img)
+    dy = torch.randn(y.shape, device='cuda', generator=gen)
+    dy_img = ops.act_image(dy)
+    dx = ops.conv2d_img('dgrad', x.shape, w, st, pad, dil, dy_img=dy_img)
+    dw = ops.conv2d_img('wgrad', x.shape, w, st, pad, dil, dy_img=dy_img, x_img=x_img)
+    torch.cuda.synchronize()
+    form = (dy.double() * y.double()).sum().item()
+    scale = (dy.double().norm() * y.double().norm()).item()
+    assert abs(form - (dw.double() * w.double()).sum().item()) < 2e-5 * scale
+    assert abs(form - (dx.double() * x.double()).sum().item()) < 2e-5 * scale
+    # against the fp32-fed kernels (the in-kernel split): same products, another accumulation order
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y0 = ops.conv2d(xr, wr, None, st, pad, dil)
+    y0.backward(dy)
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    for name, got, ref_t in (('fwd', y, y0.detach()), ('dgrad', dx, xr.grad), ('wgrad', dw, wr.grad)):
+        assert (got - ref_t).abs().max().item() <= 1e-5 * ref_t.abs().max().item(), name
+
+
 # Sampled-oracle parity at BASELINE's batch: the plans the bench runs (tile choice, split-K, parity classes, slab folds, weight images,
 # x3 kernels) are compared with the float64 oracle itself, evaluated only at randomly chosen outputs.  Beyond the ResNet-50 classes:
 # the shapes only the fusion / partial networks have (fusionnet.py:130-140: 2C -> C 1x1 over the concat at 32x32, batch 32; the 1-channel
