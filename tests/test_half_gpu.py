@@ -104,7 +104,9 @@ def test_hconv_fwd_dgrad_wgrad(case, pkg):
 
 
 SUM_CASES = [('1x1', 2, 64, 16, 16, 128, 1, 1, 0, 1), ('1x1s2', 2, 48, 17, 15, 40, 1, 2, 0, 1), ('3x3', 2, 32, 20, 20, 64, 3, 1, 1, 1), ('3x3d2', 2, 16, 16, 16, 272, 3, 1, 2, 2),
-             ('ragged', 3, 24, 13, 11, 72, 3, 1, 1, 1), ('big', 4, 256, 16, 16, 256, 3, 1, 1, 1)]
+             ('ragged', 3, 24, 13, 11, 72, 3, 1, 1, 1), ('big', 4, 256, 16, 16, 256, 3, 1, 1, 1),
+             # BASELINE's batch: 2048 table rows (layer1: more rows than the 512 blocks of a stand-alone statistics pass) and the widest result
+             ('full_layer1', 64, 64, 64, 64, 64, 3, 1, 1, 1), ('full_layer4', 64, 512, 16, 16, 2048, 1, 1, 0, 1)]
 
 
 @pytest.mark.parametrize('case', SUM_CASES, ids=[c[0] for c in SUM_CASES])
@@ -560,7 +562,8 @@ def test_half_frozen_distillation_step(pkg):
 
 
 @pytest.mark.parametrize('case', [('bottleneck', 256, 64, 1, 1, 4, 32, False), ('bottleneck', 256, 128, 2, 1, 4, 32, True), ('bottleneck', 512, 256, 1, 2, 2, 16, True),
-                                  ('basic', 64, 64, 1, 1, 4, 32, False), ('basic', 64, 128, 2, 1, 4, 32, True)],
+                                  ('basic', 64, 64, 1, 1, 4, 32, False), ('basic', 64, 128, 2, 1, 4, 32, True),
+                                  ('bottleneck', 256, 64, 1, 1, 64, 64, False)],          # a layer1 block at BASELINE's batch: 2048-row sum tables, the workspace sized for them
                          ids=lambda c: '%s_c%d_p%d_s%d_d%d%s' % (c[0], c[1], c[2], c[3], c[4], '_ds' if c[7] else ''))
 def test_half_block_executor_equals_the_per_layer_path(case, pkg):
     """p3d_hblock_fwd / p3d_hblock_bwd (one C call per block and direction) run the same fp16 kernels in the same order as the per-layer autograd path
