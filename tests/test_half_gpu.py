@@ -387,6 +387,48 @@ def test_half_train_step_matches_reference_half(case, pkg):
     assert torch.equal(img.krsc, want.contiguous())
 
 
+def test_half_contract_batch_step_against_the_fp32_oracle(pkg):
+    """The -half_acc step at BASELINE's workload (ResNet-50, 256 x 256, batch 64: depth_train.py:73-83,413-449 on the contract configuration) against the oracle's
+    fp32 CPU port from the same deterministic weights and batch.  The reference's goldens for fp16 stop at batch 2; at batch 64 the fp16 path picks the plans the
+    bench runs (2048-row sum tables from the conv epilogues, 384-block weight-gradient slab plans, the narrow 64-channel layout).  Two bars: against fp32, the
+    noise of fp16 storage through 53 layers (loss 5e-3, joints 2e-2 of the largest coordinate, clip norm 5e-2); and, isolating this round's epilogue sums, the same
+    step with the BatchNorm sums from stand-alone passes (both fp16, rounded at the same places: joints 3e-3)."""
+    from oracle.torch_port import TorchPort
+    from test_step_gpu import build
+    meta = dict(model='resnet50', side=256, extra=['-stride', '16', '-depth', '16', '-depth_range', '1000', '-loss_div', '10', '-learn_rate', '5e-5',
+                                                   '-weight_decay', '4e-5', '-grad_norm', '5', '-half_acc'])
+    args, model, trainer = build(pkg, meta)
+    assert trainer.half_acc
+    model.train()
+    trainer.adapt_learn_rate(1)
+    lr = trainer.optimizer.param_groups[0]['lr']
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    port = TorchPort(pkg.synth.det_state_dict(shapes, 0), family='depthnet', model='resnet50')
+    c, d, tc, tv = pkg.synth.make_batch(64, side=256, rank=0, step=0)
+    want = port.train_step(c, d, tc, tv, lr=lr, weight_decay=4e-5, grad_norm=5.0, loss_div=10.0)
+    loss = float(trainer.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+    spec = trainer.last_spec_cam.cpu().numpy()
+    assert trainer.skipped_steps == 0
+    scale = np.abs(want['spec_cam']).max()
+    assert abs(loss - want['loss']) < 5e-3 * abs(want['loss']), (loss, want['loss'])
+    assert np.abs(spec - want['spec_cam']).max() < 2e-2 * scale
+    total = trainer.optimizer.total_norm(1.0 / args.grad_scaling)
+    assert abs(total - want['clip_total']) < 5e-2 * want['clip_total'], (total, want['clip_total'])
+    # the same step with the sums from stand-alone passes
+    L = pkg._lib.lib()
+    before = L.p3d_hblock_fuse_sums(0)
+    try:
+        args2, model2, trainer2 = build(pkg, meta)
+        model2.train()
+        trainer2.adapt_learn_rate(1)
+        loss2 = float(trainer2.train_step(torch.from_numpy(c).cuda(), None, torch.from_numpy(tc).cuda(), torch.from_numpy(tv).cuda()))
+        spec2 = trainer2.last_spec_cam.cpu().numpy()
+    finally:
+        L.p3d_hblock_fuse_sums(before)
+    assert abs(loss - loss2) < 2e-3 * abs(loss2), (loss, loss2)
+    assert np.abs(spec - spec2).max() < 3e-3 * scale
+
+
 def test_half_overflow_skips_the_step(pkg):
     import json
     from conftest import golden_path
