@@ -1611,7 +1611,7 @@ static int g_force_conv_splits = 0, g_force_wgrad_splits = 0, g_wgrad_target = 0
 // image-fed multi-tap launches with at least this many reduction channels walk the taps innermost (0: never; p3d_fx_tune(10, v)).  Measured (tools/r04/r4_i.sh): the
 // regressor's forward (2048 channels x 9 taps) fetches 5.5x fewer bytes beyond L2 and runs 2 % faster; the 512-channel 3x3 layers fetch 3.1x fewer but run 2 % slower
 // (a tap change per K step costs more than their re-reads out of the Infinity Cache): 1024 takes the first and leaves the second
-static int g_tap_inner_min = 1024;
+static int g_tap_inner_min = [] { const char* e = getenv("P3D_TAP_INNER_MIN"); return e ? atoi(e) : 1024; }();      // (environment: A/B in the step)
 static int g_two_taps = 1;             // image-fed weight gradients of 64-input-channel multi-tap layers: two / three taps per column tile; p3d_fx_tune(9, 0): off, (9, 2): never three (A/B)
 static int g_conv_order = -1, g_wgrad_order = -1;      // -1: the built-in choice (fx_conv_order / fx_wgrad_order); 0 / 1 forced (p3d_fx_tune(7 / 8, v): A/B)
 // Which operand should the blocks an XCD runs at one time share?  An XCD's L2 holds 4 MB.  With the channel tile fastest an activation tile is fetched once and every
@@ -1624,9 +1624,14 @@ static int fx_conv_order(size_t wimg_bytes, int tiles_m, int tiles_n) {
     (void)wimg_bytes; (void)tiles_m; (void)tiles_n;
     return g_conv_order > 0 ? 1 : 0;
 }
+// The weight gradient of a WIDE multi-tap layer (>= 512 input channels) takes the tap-fastest order: the nine tap blocks of one (x tile, dy tile) pair then run side by side on
+// one XCD and the shifted views of the x tile are fetched once instead of once per tap -- FETCH_SIZE per launch 2.20 -> 0.80 GB for the 2048 -> 272 regressor, 254 -> 147 MB for
+// the 512 -> 512 3x3, at unchanged time (0.980 / 0.978 ms, 0.398 / 0.396; tools/r04/r4_w.sh).  Narrower layers keep order 0 (no traffic to win, +-2 % either way).
 static int fx_wgrad_order(const p3d_conv_desc* d) {
-    (void)d;
-    return g_wgrad_order > 0 ? 1 : 0;
+    static const int env = [] { const char* e = getenv("P3D_WGRAD_ORDER"); return e ? atoi(e) : -1; }();      // 0 / 1: forced (A/B from the environment)
+    const int forced = g_wgrad_order >= 0 ? g_wgrad_order : env;
+    if (forced >= 0) return forced > 0 ? 1 : 0;
+    return (d->R * d->S > 1 && d->C >= 512) ? 1 : 0;
 }
 static int g_class_launches = 0;      // 1: one launch per parity class of a strided data gradient (the round-3 form; p3d_fx_tune(5, 1), A/B and tests)
 static int g_fx16 = -1;
