@@ -334,6 +334,7 @@ struct HWgradParams {
     int N, C, H, W, K, R, S, stride, pad, dil, Ho, Wo;
     int kchunk;               // pixels per split (multiple of 32)
     int tiles_m;
+    int tap_fast;             // column tiles walked tap-fastest (C % 128 == 0): the taps of one 128-channel chunk of x side by side (the fp32 path's fx_wgrad_order)
 };
 
 // byte offset of 16-B chunk `ch` (0..15) of row `row` in a [rows][128 halves] image that serves ds_read_b64_tr_b16 without
@@ -349,7 +350,9 @@ __global__ __launch_bounds__(256) void hconv_wgrad_kernel(HWgradParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid % p.tiles_m, tile_n = bid / p.tiles_m;
+    const int tile_m = bid % p.tiles_m;
+    int tile_n = bid / p.tiles_m;
+    if (p.tap_fast) { const int rs = p.R * p.S, tp = tile_n % rs, ct = tile_n / rs; tile_n = tp * (p.C >> 7) + ct; }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int RSC = p.R * p.S * p.C, C8 = p.C >> 3, HoWo = p.Ho * p.Wo;
     const int ktot = p.N * HoWo;
@@ -794,6 +797,9 @@ int32_t p3d_hconv2d_wgrad(const p3d_conv_desc* d, const void* dy, const void* x,
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.Ho = d->Ho; p.Wo = d->Wo;
     p.kchunk = kchunk;
     p.tiles_m = (int)ceil_div(d->K, 128);
+    // (P3D_HWGRAD_TAP_FAST=1: measured in the fp16 step -- 14.10 / 14.12 / 14.14 ms against 14.13 / 14.11 / 14.12, no difference, unlike the fp32 path's 6-B images -- so off)
+    static const int tap_fast_env = [] { const char* e = getenv("P3D_HWGRAD_TAP_FAST"); return e ? atoi(e) : 0; }();
+    p.tap_fast = (tap_fast_env > 0 && d->R * d->S > 1 && d->C % 128 == 0) ? 1 : 0;
     const int tiles_n = (int)ceil_div((int64_t)d->R * d->S * d->C, 128);
     hipLaunchKernelGGL(hconv_wgrad_kernel, dim3((unsigned)(p.tiles_m * tiles_n), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, p);
     if (int32_t e = check_launch("hconv2d_wgrad")) return e;
