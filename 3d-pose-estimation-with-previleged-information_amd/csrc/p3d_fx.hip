@@ -1903,7 +1903,9 @@ int32_t fx_conv_dgrad(const p3d_conv_desc* d, const float* dy, const float* w, f
         if (masked) { pro = img ? 0 : 4; epi = fuse->partial ? 6 : (img ? 7 : 4); p.pmask = fuse->pmask; p.emask = fuse->emask; }
     }
     const bool dsplit = d->stride == 1 && fx_dgrad_split(d).splits > 1;
-    p.tap_inner = img && RS > 1 && g_tap_inner_min > 0 && d->K >= g_tap_inner_min;
+    static const int tap_inner_bwd = [] { const char* e = getenv("P3D_TAP_INNER_MIN_BWD"); return e ? atoi(e) : -1; }();      // (environment: the data gradient's own threshold, A/B in the step)
+    const int ti_min = tap_inner_bwd >= 0 ? tap_inner_bwd : g_tap_inner_min;
+    p.tap_inner = img && RS > 1 && ti_min > 0 && d->K >= ti_min;
     if (fuse && fuse->tail_c) {
         if (!(img && epi == 0 && pro == 0 && fx_dgrad_tail_applies(d) && fuse->tail_tab && fuse->tail_partial && (!fuse->tail_rc || fuse->tail_rtab))) {
             set_error("fx_conv_dgrad: the tail sums need an image-fed, dense, unsplit stride-1 data gradient without a BatchNorm epilogue (fx_dgrad_tail_applies)"); return P3D_EINVAL;
